@@ -1,0 +1,150 @@
+#!/usr/bin/env python3
+"""Mint golden vectors by running the UNMODIFIED reference in this container.
+
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py
+
+Reads  /root/reference/{defences,malicious}.py (imported, never copied).
+Writes tests/golden/reference_vectors.npz: for each case the seeded input matrix
+and whatever the reference returned.  The reference ships no fixtures of its own
+(SURVEY.md section 4), so "the reference's output in this image" (numpy 2.2.6,
+OpenBLAS 0.3.29) is the pin for both the CPU oracle and the HIP path.
+"""
+import os
+import sys
+import warnings
+
+import numpy as np
+
+sys.dont_write_bytecode = True
+sys.path.insert(0, '/root/reference')
+import defences as ref_defences  # noqa: E402
+import malicious as ref_malicious  # noqa: E402
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def gaussian(seed, n, d):
+    return np.random.default_rng(seed).standard_normal((n, d)).astype(np.float32)
+
+
+def scaled(seed, n, d):
+    """Well-separated Krum scores: row i scaled by 1 + 0.5*perm(i)/n."""
+    rng = np.random.default_rng(seed)
+    g = rng.standard_normal((n, d)).astype(np.float32)
+    s = (1.0 + 0.5 * rng.permutation(n) / n).astype(np.float32)
+    return g * s[:, None]
+
+
+class FakeUser:
+    def __init__(self, grads):
+        self.grads = grads
+        self.original_params = None
+        self.learning_rate = None
+
+
+def attacked(seed, n, d, m, z=1.5, family=gaussian):
+    """Rows 0..m-1 replaced by the reference's own drift vector (malicious.py)."""
+    g = family(seed, n, d)
+    users = [FakeUser(g[i].copy()) for i in range(m)]
+    ref_malicious.DriftAttack(z).attack(users)
+    for i in range(m):
+        g[i] = users[i].grads
+    return g
+
+
+def bulyan_selection(g, n, f):
+    """Replay defences.py:59-68 with the reference's own functions to expose the picks."""
+    dist = ref_defences._krum_create_distances(g)
+    picks = []
+    while len(picks) < n - 2 * f:
+        idx = ref_defences.krum(g, n - len(picks), f, dist, True)
+        picks.append(idx)
+        dist.pop(idx)
+        for r in dist:
+            dist[r].pop(idx)
+    return np.asarray(picks, dtype=np.int64)
+
+
+def dense(dist_dict, n):
+    out = np.full((n, n), np.inf, dtype=np.float32)
+    for i, row in dist_dict.items():
+        for j, v in row.items():
+            out[i, j] = v
+    return out
+
+
+def main():
+    out = {}
+
+    def put(case, **kv):
+        for k, v in kv.items():
+            out['%s/%s' % (case, k)] = np.asarray(v)
+
+    # --- no_defense -------------------------------------------------------------------
+    g = gaussian(11, 7, 130)
+    put('nodef_7x130', G=g, out=ref_defences.no_defense(g, 7, 1))
+
+    # --- krum ------------------------------------------------------------------------
+    for name, g, f in [
+        ('krum_iid_10x257', gaussian(21, 10, 257), 2),
+        ('krum_scaled_33x1000', scaled(22, 33, 1000), 8),
+        ('krum_attacked_12x300', attacked(23, 12, 300, 3), 3),       # identical rows -> exact ties
+        ('krum_allsame_6x64', np.tile(gaussian(24, 1, 64), (6, 1)), 1),  # every score ties -> row 1
+        ('krum_f0_5x40', gaussian(25, 5, 40), 0),                      # prefix longer than the list
+    ]:
+        n = len(g)
+        put(name, G=g, f=f,
+            dist=dense(ref_defences._krum_create_distances(g), n),
+            index=ref_defences.krum(g, n, f, return_index=True),
+            out=ref_defences.krum(g, n, f))
+    g = np.full((4, 8), np.nan, dtype=np.float32)
+    put('krum_allnan_4x8', G=g, f=1, index=ref_defences.krum(g, 4, 1, return_index=True))
+
+    # --- trimmed_mean ----------------------------------------------------------------
+    for name, g, c in [
+        ('tm_odd_11x97', gaussian(31, 11, 97), 2),
+        ('tm_even_10x97', gaussian(32, 10, 97), 2),
+        ('tm_100x64', gaussian(33, 100, 64), 20),
+        ('tm_attacked_20x50', attacked(34, 20, 50, 4), 4),
+        ('tm_c0_9x33', gaussian(35, 9, 33), 0),
+    ]:
+        put(name, G=g, c=c, out=ref_defences.trimmed_mean(g, len(g), c))
+    # +a / -a ties at the window edge: the lower row index must win (stable sort)
+    col = np.array([0.0, 3.0, -3.0, 1.0, -1.0, 5.0, -5.0], dtype=np.float32)  # median 0
+    g = np.stack([col, col[::-1].copy(), np.roll(col, 3)], axis=1)
+    for c in (1, 2, 3, 4):
+        put('tm_edge_ties_c%d' % c, G=g, c=c, out=ref_defences.trimmed_mean(g, 7, c))
+    g = gaussian(36, 6, 20)
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        put('tm_kzero_6x20', G=g, c=5, out=ref_defences.trimmed_mean(g, 6, 5))      # k = 0 -> NaN
+    put('tm_kneg_6x20', G=g, c=7, out=ref_defences.trimmed_mean(g, 6, 7))           # k = -2 -> [:-2]
+
+    # --- bulyan ----------------------------------------------------------------------
+    for name, g, f in [
+        ('bulyan_iid_11x200', gaussian(41, 11, 200), 2),
+        ('bulyan_boundary_15x120', gaussian(42, 15, 120), 3),            # n == 4f + 3
+        ('bulyan_scaled_40x500', scaled(43, 40, 500), 9),
+        ('bulyan_attacked_23x150', attacked(44, 23, 150, 5), 5),
+        ('bulyan_f0_6x30', gaussian(45, 6, 30), 0),
+    ]:
+        n = len(g)
+        put(name, G=g, f=f, selection=bulyan_selection(g, n, f), out=ref_defences.bulyan(g, n, f))
+
+    # --- attack ----------------------------------------------------------------------
+    for name, g, z in [('attack_5x300_z1.5', gaussian(51, 5, 300), 1.5),
+                       ('attack_24x100_z0.5', gaussian(52, 24, 100) * 3 + 7, 0.5),
+                       ('attack_3x64_z0', gaussian(53, 3, 64), 0.0)]:
+        users = [FakeUser(r.copy()) for r in g]
+        att = ref_malicious.DriftAttack(z)
+        att.attack(users)
+        put(name, G=g, z=z, stored_mean=att.grads_mean, stored_stdev=att.grads_stdev,
+            user0=users[0].grads, aliased=int(all(u.grads is users[0].grads for u in users)))
+
+    path = os.path.join(HERE, 'reference_vectors.npz')
+    np.savez_compressed(path, **out)
+    print('wrote %s: %d arrays, %.1f KiB' % (path, len(out), os.path.getsize(path) / 1024))
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,78 @@
+"""The CPU oracle against the golden vectors minted from the reference (bit-exact)."""
+import warnings
+
+import numpy as np
+import pytest
+
+from oracle import faithful, ideal
+
+
+def same(a, b):
+    a, b = np.asarray(a), np.asarray(b)
+    return a.shape == b.shape and np.array_equal(a, b, equal_nan=True)
+
+
+def test_no_defense(golden):
+    c = golden['nodef_7x130']
+    assert same(faithful.no_defense(c['G'], 7, 1), c['out'])
+
+
+@pytest.mark.parametrize('case', ['krum_iid_10x257', 'krum_scaled_33x1000', 'krum_attacked_12x300',
+                                  'krum_allsame_6x64', 'krum_f0_5x40'])
+def test_krum(golden, case):
+    c = golden[case]
+    g, f = c['G'], int(c['f'])
+    dist = faithful.distance_matrix(g)
+    assert same(dist, c['dist'])
+    assert faithful.krum(g, len(g), f, return_index=True) == int(c['index'])
+    assert same(faithful.krum(g, len(g), f), c['out'])
+    # the fp64 tier agrees on the index (these cases have margins far above fp32 noise or exact ties)
+    assert ideal.krum_index(ideal.distance_matrix(g), len(g), f) == int(c['index'])
+
+
+def test_krum_all_nan_keeps_minus_one(golden):
+    c = golden['krum_allnan_4x8']
+    assert faithful.krum(c['G'], 4, int(c['f']), return_index=True) == int(c['index']) == -1
+
+
+@pytest.mark.parametrize('case', ['tm_odd_11x97', 'tm_even_10x97', 'tm_100x64', 'tm_attacked_20x50',
+                                  'tm_c0_9x33', 'tm_edge_ties_c1', 'tm_edge_ties_c2',
+                                  'tm_edge_ties_c3', 'tm_edge_ties_c4', 'tm_kzero_6x20', 'tm_kneg_6x20'])
+def test_trimmed_mean(golden, case):
+    c = golden[case]
+    g, cc = c['G'], int(c['c'])
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        assert same(faithful.trimmed_mean(g, len(g), cc), c['out'])
+        fast = ideal.trimmed_mean(g, cc)
+    assert np.allclose(fast, c['out'], rtol=1e-6, atol=1e-6, equal_nan=True)
+
+
+@pytest.mark.parametrize('case', ['bulyan_iid_11x200', 'bulyan_boundary_15x120', 'bulyan_scaled_40x500',
+                                  'bulyan_attacked_23x150', 'bulyan_f0_6x30'])
+def test_bulyan(golden, case):
+    c = golden[case]
+    g, f = c['G'], int(c['f'])
+    agg, picked = faithful.bulyan(g, len(g), f, return_selection=True)
+    assert picked == c['selection'].tolist()
+    assert same(agg, c['out'])
+    agg64, picked64 = ideal.bulyan(g, len(g), f, return_selection=True)
+    assert picked64 == c['selection'].tolist()
+    assert np.allclose(agg64, c['out'], rtol=1e-6, atol=1e-6)
+
+
+@pytest.mark.parametrize('case', ['attack_5x300_z1.5', 'attack_24x100_z0.5', 'attack_3x64_z0'])
+def test_attack(golden, case):
+    c = golden[case]
+    g, z = c['G'], float(c['z'])
+    mean, stdev = faithful.attack_statistics(g)
+    assert same(stdev, c['stored_stdev'])
+    vec = faithful.drift_vector(g, z)
+    if z == 0:
+        assert vec is None and same(mean, c['stored_mean']) and same(c['user0'], g[0])
+    else:
+        # the reference overwrites attacker.grads_mean with the drifted vector (malicious.py:35)
+        assert same(vec, c['stored_mean']) and same(vec, c['user0'])
+        v64, _, s64 = ideal.drift_vector(g, z)
+        assert np.allclose(v64, vec, rtol=1e-5, atol=1e-5)
+        assert np.allclose(s64, stdev, rtol=1e-5, atol=1e-6)

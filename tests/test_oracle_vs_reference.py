@@ -1,0 +1,101 @@
+"""Randomised bit-for-bit checks of oracle.faithful against the reference itself.
+
+Runs only where /root/reference exists (the build container); the GPU box relies on
+the golden vectors instead.
+"""
+import numpy as np
+import pytest
+
+from oracle import faithful, ideal
+
+pytestmark = pytest.mark.reference
+
+
+class FakeUser:
+    def __init__(self, grads):
+        self.grads, self.original_params, self.learning_rate = grads, None, None
+
+
+def ref_selection(ref, g, n, f):
+    dist = ref._krum_create_distances(g)
+    picks = []
+    while len(picks) < n - 2 * f:
+        idx = ref.krum(g, n - len(picks), f, dist, True)
+        picks.append(idx)
+        dist.pop(idx)
+        for r in dist:
+            dist[r].pop(idx)
+    return picks
+
+
+def matrices(seed, n, d, kind):
+    rng = np.random.default_rng(seed)
+    g = rng.standard_normal((n, d)).astype(np.float32)
+    if kind == 'dup':           # blocks of identical rows, like the drift attack produces
+        g[: n // 3] = g[0]
+    elif kind == 'quantised':   # many exact ties in every column
+        g = np.round(g * 2).astype(np.float32) / 2
+    return g
+
+
+@pytest.mark.parametrize('kind', ['iid', 'dup', 'quantised'])
+@pytest.mark.parametrize('n,d,f', [(2, 5, 0), (3, 17, 1), (9, 64, 2), (16, 33, 3), (31, 257, 7)])
+def test_krum_and_distances(reference_modules, kind, n, d, f):
+    ref = reference_modules['defences']
+    g = matrices(100 + n, n, d, kind)
+    dist_ref = ref._krum_create_distances(g)
+    assert list(dist_ref.keys()) == faithful.visit_order(n)
+    dist = faithful.distance_matrix(g)
+    for i in dist_ref:
+        for j, v in dist_ref[i].items():
+            assert dist[i, j] == v and type(v) is np.float32
+    assert faithful.krum(g, n, f, return_index=True) == ref.krum(g, n, f, return_index=True)
+    if n >= 2 * f + 1:
+        assert np.array_equal(faithful.krum(g, n, f), ref.krum(g, n, f))
+
+
+@pytest.mark.parametrize('kind', ['iid', 'dup', 'quantised'])
+@pytest.mark.parametrize('n,d,c', [(4, 9, 1), (7, 40, 2), (10, 33, 2), (25, 19, 6), (64, 12, 15)])
+def test_trimmed_mean(reference_modules, kind, n, d, c):
+    ref = reference_modules['defences']
+    g = matrices(200 + n, n, d, kind)
+    want = ref.trimmed_mean(g, n, c)
+    assert np.array_equal(faithful.trimmed_mean(g, n, c), want)
+    assert np.allclose(ideal.trimmed_mean(g, c), want, rtol=1e-6, atol=1e-6)
+
+
+@pytest.mark.parametrize('kind', ['iid', 'dup', 'quantised'])
+@pytest.mark.parametrize('n,d,f', [(3, 8, 0), (7, 30, 1), (11, 50, 2), (19, 21, 4), (27, 100, 6)])
+def test_bulyan(reference_modules, kind, n, d, f):
+    ref = reference_modules['defences']
+    g = matrices(300 + n, n, d, kind)
+    agg, picked = faithful.bulyan(g, n, f, return_selection=True)
+    assert picked == ref_selection(ref, g, n, f)
+    assert np.array_equal(agg, ref.bulyan(g, n, f))
+
+
+def test_assertions_match(reference_modules):
+    ref = reference_modules['defences']
+    g = matrices(1, 6, 10, 'iid')
+    for fn_ref, fn in ((ref.krum, faithful.krum), (ref.bulyan, faithful.bulyan)):
+        with pytest.raises(AssertionError):
+            fn_ref(g, 6, 3)
+        with pytest.raises(AssertionError):
+            fn(g, 6, 3)
+    # the Krum assert is skipped when only the index is requested (defences.py:24)
+    assert faithful.krum(g, 6, 3, return_index=True) == ref.krum(g, 6, 3, return_index=True)
+
+
+@pytest.mark.parametrize('m,d,z', [(1, 10, 1.5), (4, 77, 1.5), (13, 300, 0.3), (5, 20, 0.0)])
+def test_attack(reference_modules, m, d, z):
+    ref = reference_modules['malicious']
+    g = matrices(400 + m, m, d, 'iid') * 2 + 1
+    users = [FakeUser(r.copy()) for r in g]
+    att = ref.DriftAttack(z)
+    att.attack(users)
+    vec = faithful.drift_vector(g, z)
+    if z == 0:
+        assert vec is None and np.array_equal(users[0].grads, g[0])
+    else:
+        assert np.array_equal(vec, users[0].grads)
+    assert np.array_equal(faithful.attack_statistics(g)[1], att.grads_stdev)
