@@ -1,0 +1,189 @@
+// Shared host-side plumbing of libbyzagg: the context, error reporting, workspace growth and the
+// per-kernel event timing used by bench.py.  gfx950 only; no other target is considered.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <string>
+#include <vector>
+
+#include "../../include/byzagg.h"
+
+namespace byz {
+
+void set_error(const char* fmt, ...);
+
+#define BYZ_HIP(expr)                                                                       \
+    do {                                                                                    \
+        hipError_t e_ = (expr);                                                             \
+        if (e_ != hipSuccess) {                                                             \
+            ::byz::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, \
+                             __LINE__);                                                     \
+            return BYZ_E_HIP;                                                               \
+        }                                                                                   \
+    } while (0)
+
+#define BYZ_TRY(expr)            \
+    do {                         \
+        int rc_ = (expr);        \
+        if (rc_ != BYZ_OK) return rc_; \
+    } while (0)
+
+#define BYZ_REQUIRE(cond, ...)          \
+    do {                                \
+        if (!(cond)) {                  \
+            ::byz::set_error(__VA_ARGS__); \
+            return BYZ_E_INVALID;       \
+        }                               \
+    } while (0)
+
+// A device buffer that only ever grows; growth happens between kernels, never inside the hot loop
+// once byz_ctx_reserve has been called with the largest shape.
+struct Buffer {
+    void* ptr = nullptr;
+    size_t bytes = 0;
+    int ensure(size_t need) {
+        if (need <= bytes) return BYZ_OK;
+        if (ptr) BYZ_HIP(hipFree(ptr));
+        ptr = nullptr;
+        bytes = 0;
+        BYZ_HIP(hipMalloc(&ptr, need));
+        bytes = need;
+        return BYZ_OK;
+    }
+    void release() {
+        if (ptr) (void)hipFree(ptr);
+        ptr = nullptr;
+        bytes = 0;
+    }
+    template <typename T>
+    T* as() const { return static_cast<T*>(ptr); }
+};
+
+struct PinnedBuffer {
+    void* ptr = nullptr;
+    size_t bytes = 0;
+    int ensure(size_t need) {
+        if (need <= bytes) return BYZ_OK;
+        if (ptr) BYZ_HIP(hipHostFree(ptr));
+        ptr = nullptr;
+        bytes = 0;
+        BYZ_HIP(hipHostMalloc(&ptr, need, hipHostMallocDefault));
+        bytes = need;
+        return BYZ_OK;
+    }
+    void release() {
+        if (ptr) (void)hipHostFree(ptr);
+        ptr = nullptr;
+        bytes = 0;
+    }
+};
+
+struct TimingSlot {
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
+    double total_ms = 0.0;
+    int64_t launches = 0;
+};
+
+}  // namespace byz
+
+struct byz_ctx {
+    int device = 0;
+    int num_cus = 256;
+    // workspaces
+    byz::Buffer gram_partials;   // split-K slabs of the Gram kernel
+    byz::Buffer gram;            // n x n fp64 Gram
+    byz::Buffer dist;            // n x n fp32 distances (when the caller does not pass one)
+    byz::Buffer colstat_partials;  // row-split partial column sums
+    byz::Buffer sorted_idx;      // n x n uint16: column index at every ascending rank
+    byz::Buffer rank_t;          // n x n uint16: rank_t[w][u] = rank of column w in row u
+    byz::Buffer row_total;       // n fp64: sum of a row's finite distances
+    byz::Buffer row_top;         // n fp64: sum of a row's largest `drop` distances
+    byz::Buffer scores;          // n fp32 Krum scores
+    byz::Buffer selection;       // theta int32
+    byz::Buffer small;           // misc device scalars (winner index, status words)
+    byz::Buffer stage_in;        // device copy of a host matrix
+    byz::Buffer stage_out;       // device result before download
+    byz::PinnedBuffer pinned;    // host bounce buffer for small results
+    // timing
+    bool timing = false;
+    byz::TimingSlot slots[BYZ_K_COUNT];
+};
+
+namespace byz {
+
+inline hipStream_t as_stream(void* s) { return static_cast<hipStream_t>(s); }
+
+// Brackets one kernel launch with events when timing is on (bench.py's roofline leg).
+struct KernelTimer {
+    byz_ctx* ctx;
+    int kernel;
+    hipStream_t stream;
+    hipEvent_t start = nullptr, stop = nullptr;
+    KernelTimer(byz_ctx* c, int k, hipStream_t s) : ctx(c), kernel(k), stream(s) {
+        if (ctx->timing) {
+            (void)hipEventCreate(&start);
+            (void)hipEventCreate(&stop);
+            (void)hipEventRecord(start, stream);
+        }
+    }
+    ~KernelTimer() {
+        if (ctx->timing && start) {
+            (void)hipEventRecord(stop, stream);
+            ctx->slots[kernel].pending.emplace_back(start, stop);
+        }
+    }
+};
+
+inline int check_launch(const char* what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        set_error("launch of %s failed: %s", what, hipGetErrorString(e));
+        return BYZ_E_HIP;
+    }
+    return BYZ_OK;
+}
+
+inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
+inline int64_t next_pow2(int64_t v) {
+    int64_t p = 1;
+    while (p < v) p <<= 1;
+    return p;
+}
+
+// ---- kernel launchers (one per .hip file) -------------------------------------------------------
+int launch_column_mean(byz_ctx* ctx, const float* G, int64_t n_rows, int64_t n_cols, int64_t ld,
+                       float* out, hipStream_t stream);
+int launch_column_drift(byz_ctx* ctx, const float* G, int64_t n_rows, int64_t n_cols, int64_t ld,
+                        float num_std, float* drift, float* mean, float* stdev, hipStream_t stream);
+int launch_broadcast_rows(byz_ctx* ctx, float* G, int64_t n_rows, int64_t n_cols, int64_t ld,
+                          const float* vec, hipStream_t stream);
+int launch_drift_axpy(byz_ctx* ctx, float* mean, const float* stdev, int64_t n, float num_std,
+                      hipStream_t stream);
+int launch_server_update(byz_ctx* ctx, float* w, float* v, const float* agg, int64_t n, float momentum,
+                         float lr, hipStream_t stream);
+int launch_copy_row(byz_ctx* ctx, const float* G, int64_t ld, int64_t n_rows, int64_t n_cols,
+                    const int32_t* index_dev, float* out, hipStream_t stream);
+
+int launch_gram(byz_ctx* ctx, const float* G, int64_t n_rows, int64_t n_cols, int64_t ld, double* gram,
+                hipStream_t stream);
+int launch_distances_from_gram(byz_ctx* ctx, const double* gram, int64_t n, float* dist,
+                               hipStream_t stream);
+
+int launch_row_sort(byz_ctx* ctx, const float* dist, int64_t n, int64_t prefix_len, int64_t drop_count,
+                    bool want_tables, hipStream_t stream);
+int launch_krum_argmin(byz_ctx* ctx, int64_t n, int32_t* winner_dev, hipStream_t stream);
+int launch_bulyan_loop(byz_ctx* ctx, const float* dist, int64_t n, int64_t theta, int64_t drop_count,
+                       int32_t* selection_dev, int32_t* status_dev, hipStream_t stream);
+
+int launch_trimmed_mean(byz_ctx* ctx, const float* G, int64_t n_rows, int64_t n_cols, int64_t ld,
+                        const int32_t* row_index, int64_t keep, float* out, hipStream_t stream);
+int64_t trimmed_mean_max_rows();
+int64_t select_max_rows();
+
+int launch_lane_selftest(byz_ctx* ctx, int32_t* out, int32_t* n_patterns, hipStream_t stream);
+
+}  // namespace byz

@@ -1,0 +1,461 @@
+// Median-window trimmed mean, reference defences.py:44-52, per parameter (column) over the client rows.
+//
+//   med  = np.median(column)                       fp32; even count -> (a + b) / 2
+//   good = sorted(column - med, key=abs)[:k]       stable: ties in |x - med| keep the lower row first
+//   out  = np.mean(good) + med
+//
+// This is the HBM-bound kernel of the path: 4 bytes read per (client, parameter), 4 bytes written per
+// parameter, and a sort per parameter that must hide under the load.
+//
+// Register-resident kernel (rows <= 1024), per workgroup of 8 waves:
+//   * tile = all rows x 32 consecutive parameters, loaded as 128-byte row segments (8 lanes x dwordx4)
+//     into LDS with a 36-float row stride (16-byte aligned for b128 traffic, and a b128 read of 16
+//     consecutive rows at one column offset touches 16 different 16-byte slots: conflict-free);
+//   * each wave takes 4 adjacent columns (one float4 per row): lane l reads rows l, l+64, ... with
+//     ds_read_b128, so a lane holds R = n_pad/64 values of each of its 4 columns in registers;
+//   * the 64*R values of a column are sorted by a bitonic network in the "flip" form (every
+//     compare-exchange puts the smaller value at the lower index).  With element index i = r + R*lane the
+//     low log2(R) index bits are register bits: those steps are plain v_min/v_max pairs.  Steps on lane
+//     bits fetch the partner through DPP (quad_perm / row_mirror / row_half_mirror / row_ror), ds_swizzle
+//     or ds_bpermute and keep min or max with one v_med3_f32 against a per-lane +/-inf;
+//   * the sorted columns go back to the wave's own 4 columns of the tile in rank order (skewed so the
+//     b128 stores do not collide), and the window is found from the sorted data:
+//       - the k kept values are the k nearest neighbours of the median, a contiguous rank window
+//         [lo, lo + k).  lo = number of ranks i in [0, n-k) whose value is farther from the median than
+//         rank i + k (counted with one ballot per 64 candidates);
+//       - a cross-side tie |x - med| == |y - med| at the window edge is the only place where the row
+//         order matters; it is detected exactly and resolved by rescanning the column in row order.
+// General kernel (rows up to 8192): same post-processing, the sort runs in LDS over a [rank][4] float4
+// array per workgroup.  It is the fallback for Bulyan's second stage at large theta.
+#include "common.hpp"
+
+#include <type_traits>
+
+namespace byz {
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
+
+constexpr int kTileCols = 32;
+constexpr int kStride = 36;        // floats per LDS row
+constexpr int kFastThreads = 512;  // 8 waves x 4 columns
+constexpr int kFastMaxRows = 1024;
+constexpr int kSkewRows = 64;
+constexpr int kGeneralMaxRows = 8192;
+
+// ---- cross-lane exchange ------------------------------------------------------------------------
+// value held by lane (lane ^ MASK); MASK is a compile-time constant after unrolling.
+__device__ __forceinline__ float lane_xor(float v, int mask, int lane) {
+    const int b = __float_as_int(v);
+    int r;
+    switch (mask) {
+        case 1: r = __builtin_amdgcn_update_dpp(0, b, 0xB1, 0xF, 0xF, true); break;   // quad_perm [1,0,3,2]
+        case 2: r = __builtin_amdgcn_update_dpp(0, b, 0x4E, 0xF, 0xF, true); break;   // quad_perm [2,3,0,1]
+        case 3: r = __builtin_amdgcn_update_dpp(0, b, 0x1B, 0xF, 0xF, true); break;   // quad_perm [3,2,1,0]
+        case 7: r = __builtin_amdgcn_update_dpp(0, b, 0x141, 0xF, 0xF, true); break;  // row_half_mirror
+        case 8: r = __builtin_amdgcn_update_dpp(0, b, 0x128, 0xF, 0xF, true); break;  // row_ror:8
+        case 15: r = __builtin_amdgcn_update_dpp(0, b, 0x140, 0xF, 0xF, true); break; // row_mirror
+        case 4: r = __builtin_amdgcn_ds_swizzle(b, 0x101F); break;                     // xor 4
+        case 16: r = __builtin_amdgcn_ds_swizzle(b, 0x401F); break;                    // xor 16
+        case 31: r = __builtin_amdgcn_ds_swizzle(b, 0x7C1F); break;                    // xor 31
+        default: r = __builtin_amdgcn_ds_bpermute((lane ^ mask) << 2, b); break;       // 32, 63
+    }
+    return __int_as_float(r);
+}
+
+__device__ __forceinline__ void cmp_swap(float& lo, float& hi) {
+    const float a = lo, b = hi;
+    lo = __builtin_fminf(a, b);
+    hi = __builtin_fmaxf(a, b);
+}
+
+// compile-time loops over powers of two (a `k <<= 1` loop is not reliably unrolled, and a register
+// array indexed by a runtime value would be demoted to scratch)
+template <int K, int KMAX, typename F>
+__device__ __forceinline__ void for_pow2_up(F&& f) {
+    if constexpr (K <= KMAX) {
+        f(std::integral_constant<int, K>{});
+        for_pow2_up<K * 2, KMAX>(f);
+    }
+}
+template <int J, typename F>
+__device__ __forceinline__ void for_pow2_down(F&& f) {
+    if constexpr (J > 0) {
+        f(std::integral_constant<int, J>{});
+        for_pow2_down<J / 2>(f);
+    }
+}
+
+// Sorts the 64*R values {x[r] of lane l} ascending in index i = r + R*l, for C independent columns.
+template <int R, int C>
+__device__ __forceinline__ void wave_bitonic_sort(float (&x)[C][R], int lane) {
+    const float pinf = __builtin_inff();
+    for_pow2_up<2, 64 * R>([&](auto kc) {
+        constexpr int k = decltype(kc)::value;
+        // flip: i <-> i ^ (k-1); the element whose bit (k/2) is clear keeps the minimum
+        if constexpr (k <= R) {
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const int p = r ^ (k - 1);
+                if (p > r) {
+#pragma unroll
+                    for (int c = 0; c < C; ++c) cmp_swap(x[c][r], x[c][p]);
+                }
+            }
+        } else {
+            constexpr int lane_mask = k / R - 1;
+            constexpr int lane_bit = k / (2 * R);
+            const float sel = (lane & lane_bit) ? pinf : -pinf;  // upper partner keeps the maximum
+#pragma unroll
+            for (int r = 0; r < (R + 1) / 2; ++r) {
+                const int p = R - 1 - r;
+#pragma unroll
+                for (int c = 0; c < C; ++c) {
+                    const float from_p = lane_xor(x[c][p], lane_mask, lane);
+                    if (p != r) {
+                        const float from_r = lane_xor(x[c][r], lane_mask, lane);
+                        x[c][p] = __builtin_amdgcn_fmed3f(x[c][p], from_r, sel);
+                    }
+                    x[c][r] = __builtin_amdgcn_fmed3f(x[c][r], from_p, sel);
+                }
+            }
+        }
+        // half-cleaners: i <-> i ^ j, j = k/4 ... 1
+        for_pow2_down<k / 4>([&](auto jc) {
+            constexpr int j = decltype(jc)::value;
+            if constexpr (j < R) {
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    if ((r & j) == 0) {
+#pragma unroll
+                        for (int c = 0; c < C; ++c) cmp_swap(x[c][r], x[c][r | j]);
+                    }
+                }
+            } else {
+                constexpr int s = j / R;
+                const float sel = (lane & s) ? pinf : -pinf;
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+#pragma unroll
+                    for (int c = 0; c < C; ++c) {
+                        const float other = lane_xor(x[c][r], s, lane);
+                        x[c][r] = __builtin_amdgcn_fmed3f(x[c][r], other, sel);
+                    }
+                }
+            }
+        });
+    });
+}
+
+// ---- post-processing on a sorted quad of columns -------------------------------------------------
+// `Sorted` exposes at(rank) -> float4 (the 4 columns' values at that rank).  One wave per call.
+struct WindowArgs {
+    const float* G;
+    int64_t ld;
+    const int32_t* row_index;
+    int n;      // rows
+    int keep;   // number of kept values, 0 <= keep <= n
+    int64_t col0;   // first of the 4 columns
+    int64_t n_cols;
+};
+
+__device__ __forceinline__ float quad_get(const f32x4& v, int c) { return c == 0 ? v.x : (c == 1 ? v.y : (c == 2 ? v.z : v.w)); }
+
+template <typename Sorted>
+__device__ __forceinline__ void window_mean(const Sorted& sorted, const WindowArgs& a, int lane, float* __restrict__ out) {
+    const int n = a.n, keep = a.keep;
+    f32x4 med;
+    if (n & 1) {
+        med = sorted.at((n - 1) >> 1);
+    } else {
+        const f32x4 lo = sorted.at((n >> 1) - 1), hi = sorted.at(n >> 1);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) med[c] = __fmul_rn(__fadd_rn(lo[c], hi[c]), 0.5f);
+    }
+    if (keep <= 0) {  // np.mean([]) -> nan
+        if (lane < 4 && a.col0 + lane < a.n_cols) out[a.col0 + lane] = __uint_as_float(0x7fc00000u);
+        return;
+    }
+    // lo[c] = how many of the lowest ranks fall outside the k nearest neighbours of the median
+    const int n_drop = n - keep;
+    int lo[4] = {0, 0, 0, 0};
+    for (int base = 0; base < n_drop; base += 64) {
+        const int i = base + lane;
+        const bool active = i < n_drop;
+        const f32x4 left = sorted.at(active ? i : 0), right = sorted.at(active ? i + keep : 0);
+        const int dl = abs(2 * i - (n - 1)), dr = abs(2 * (i + keep) - (n - 1));
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const float al = fabsf(__fsub_rn(left[c], med[c])), ar = fabsf(__fsub_rn(right[c], med[c]));
+            const bool farther = active && (al > ar || (al == ar && dl > dr));
+            lo[c] += __popcll(__ballot(farther));
+        }
+    }
+    // sum of the kept deviations
+    float sum[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    for (int base = 0; base < n; base += 64) {
+        const int i = base + lane;
+        const f32x4 v = sorted.at(i < n ? i : 0);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const bool in = i < n && static_cast<unsigned>(i - lo[c]) < static_cast<unsigned>(keep);
+            sum[c] += in ? __fsub_rn(v[c], med[c]) : 0.0f;
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+#pragma unroll
+        for (int m = 32; m > 0; m >>= 1) sum[c] += __shfl_xor(sum[c], m, 64);
+    }
+    // exact cross-side ties at the window edge: the reference's stable sort decides by row order
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const int first = lo[c], last = lo[c] + keep - 1;
+        const float m = med[c];
+        const float d_first = __fsub_rn(quad_get(sorted.at(first), c), m);
+        const float d_last = __fsub_rn(quad_get(sorted.at(last), c), m);
+        bool tie = false;
+        if (first > 0) {
+            const float d_out = __fsub_rn(quad_get(sorted.at(first - 1), c), m);
+            tie = tie || (fabsf(d_out) == fabsf(d_last) && d_out < 0.0f && d_last > 0.0f);
+        }
+        if (last + 1 < n) {
+            const float d_out = __fsub_rn(quad_get(sorted.at(last + 1), c), m);
+            tie = tie || (fabsf(d_out) == fabsf(d_first) && d_first < 0.0f && d_out > 0.0f);
+        }
+        if (tie && a.col0 + c < a.n_cols) {  // wave-uniform
+            const float edge = fmaxf(fabsf(d_first), fabsf(d_last));
+            float closer = 0.0f;
+            int n_closer = 0;
+            for (int base = 0; base < n; base += 64) {
+                const int i = base + lane;
+                const float d = i < n ? __fsub_rn(quad_get(sorted.at(i), c), m) : 0.0f;
+                const bool in = i < n && fabsf(d) < edge;
+                closer += in ? d : 0.0f;
+                n_closer += __popcll(__ballot(in));
+            }
+#pragma unroll
+            for (int mm = 32; mm > 0; mm >>= 1) closer += __shfl_xor(closer, mm, 64);
+            int want = keep - n_closer, taken = 0, n_pos = 0, n_neg = 0;
+            for (int base = 0; base < n && taken < want; base += 64) {
+                const int r = base + lane;
+                float d = 0.0f;
+                bool tied = false;
+                if (r < n) {
+                    const int64_t src = a.row_index ? a.row_index[r] : r;
+                    d = __fsub_rn(a.G[src * a.ld + a.col0 + c], m);
+                    tied = fabsf(d) == edge;
+                }
+                const unsigned long long mask = __ballot(tied);
+                const int before = __popcll(mask & ((1ull << lane) - 1ull));
+                const bool take = tied && (taken + before < want);
+                n_pos += __popcll(__ballot(take && d > 0.0f));
+                n_neg += __popcll(__ballot(take && d < 0.0f));
+                taken += __popcll(mask);
+            }
+            sum[c] = closer + static_cast<float>(n_pos - n_neg) * edge;
+        }
+    }
+    if (lane < 4 && a.col0 + lane < a.n_cols) {
+        const float s = lane == 0 ? sum[0] : (lane == 1 ? sum[1] : (lane == 2 ? sum[2] : sum[3]));
+        const float m = lane == 0 ? med.x : (lane == 1 ? med.y : (lane == 2 ? med.z : med.w));
+        out[a.col0 + lane] = __fadd_rn(__fdiv_rn(s, static_cast<float>(keep)), m);
+    }
+}
+
+// ---- register-resident kernel --------------------------------------------------------------------
+template <int R>
+struct SkewedTile {
+    const float* base;  // tile + 4 * quad
+    __device__ __forceinline__ static int row_of(int rank) { return R >= 4 ? rank + rank / R : rank; }
+    __device__ __forceinline__ f32x4 at(int rank) const {
+        return *reinterpret_cast<const f32x4*>(base + row_of(rank) * kStride);
+    }
+};
+
+template <int R>
+__global__ __launch_bounds__(kFastThreads) void trimmed_mean_regs_kernel(
+    const float* __restrict__ G, int n_rows, int64_t n_cols, int64_t ld, const int32_t* __restrict__ row_index,
+    int keep, float* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) float tile[];  // (n_rows + kSkewRows) x kStride
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t n_tiles = (n_cols + kTileCols - 1) / kTileCols;
+    const float pinf = __builtin_inff();
+
+    for (int64_t t = blockIdx.x; t < n_tiles; t += gridDim.x) {
+        const int64_t c_base = t * kTileCols;
+        // ---- stage the tile: 8 lanes per 128-byte row segment, 64 rows per pass
+        {
+            const int q = (tid & 7) * 4;
+            const int64_t c = c_base + q;
+            for (int r = tid >> 3; r < n_rows; r += kFastThreads / 8) {
+                const int64_t src = row_index ? row_index[r] : r;
+                const float* p = G + src * ld + c;
+                f32x4 v = {0.0f, 0.0f, 0.0f, 0.0f};
+                if (c + 4 <= n_cols) {
+                    v = *reinterpret_cast<const f32x4u*>(p);
+                } else {
+                    if (c + 0 < n_cols) v.x = p[0];
+                    if (c + 1 < n_cols) v.y = p[1];
+                    if (c + 2 < n_cols) v.z = p[2];
+                }
+                *reinterpret_cast<f32x4*>(tile + r * kStride + q) = v;
+            }
+        }
+        __syncthreads();
+        // ---- each wave sorts its 4 columns in registers
+        float x[4][R];
+        float* my = tile + 4 * wave;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int row = lane + 64 * r;
+            f32x4 v = {pinf, pinf, pinf, pinf};
+            if (row < n_rows) v = *reinterpret_cast<const f32x4*>(my + row * kStride);
+            x[0][r] = v.x; x[1][r] = v.y; x[2][r] = v.z; x[3][r] = v.w;
+        }
+        wave_bitonic_sort<R, 4>(x, lane);
+        // every lane has consumed its rows before any lane overwrites them (one wave, program order)
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int rank = r + R * lane;
+            if (rank < n_rows) {
+                const f32x4 v = {x[0][r], x[1][r], x[2][r], x[3][r]};
+                *reinterpret_cast<f32x4*>(my + SkewedTile<R>::row_of(rank) * kStride) = v;
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const SkewedTile<R> sorted{my};
+        const WindowArgs args{G, ld, row_index, n_rows, keep, c_base + 4 * wave, n_cols};
+        window_mean(sorted, args, lane, out);
+        __syncthreads();  // the tile is restaged by the next iteration
+    }
+}
+
+// ---- general kernel: LDS bitonic over [rank][4 columns] ------------------------------------------
+struct QuadArray {
+    const f32x4* base;
+    __device__ __forceinline__ f32x4 at(int rank) const { return base[rank]; }
+};
+
+__global__ __launch_bounds__(1024) void trimmed_mean_lds_kernel(const float* __restrict__ G, int n_rows, int n_pad,
+                                                                int64_t n_cols, int64_t ld,
+                                                                const int32_t* __restrict__ row_index, int keep,
+                                                                float* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) f32x4 quad[];  // n_pad entries
+    const int tid = threadIdx.x, nt = blockDim.x;
+    const int64_t n_quads = (n_cols + 3) / 4;
+    const float pinf = __builtin_inff();
+    for (int64_t qd = blockIdx.x; qd < n_quads; qd += gridDim.x) {
+        const int64_t c = qd * 4;
+        for (int r = tid; r < n_pad; r += nt) {
+            f32x4 v = {pinf, pinf, pinf, pinf};
+            if (r < n_rows) {
+                const int64_t src = row_index ? row_index[r] : r;
+                const float* p = G + src * ld + c;
+                if (c + 4 <= n_cols) {
+                    v = *reinterpret_cast<const f32x4u*>(p);
+                } else {
+                    v.x = p[0];
+                    v.y = c + 1 < n_cols ? p[1] : 0.0f;
+                    v.z = c + 2 < n_cols ? p[2] : 0.0f;
+                    v.w = 0.0f;
+                }
+            }
+            quad[r] = v;
+        }
+        __syncthreads();
+        for (int k = 2; k <= n_pad; k <<= 1) {
+            for (int j = k >> 1; j > 0; j >>= 1) {
+                for (int idx = tid; idx < (n_pad >> 1); idx += nt) {
+                    const int i = ((idx & ~(j - 1)) << 1) | (idx & (j - 1));
+                    const int p = i | j;
+                    const f32x4 a = quad[i], b = quad[p];
+                    const bool up = (i & k) == 0;
+                    f32x4 lo, hi;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        lo[e] = __builtin_fminf(a[e], b[e]);
+                        hi[e] = __builtin_fmaxf(a[e], b[e]);
+                    }
+                    quad[i] = up ? lo : hi;
+                    quad[p] = up ? hi : lo;
+                }
+                __syncthreads();
+            }
+        }
+        if (tid < 64) {
+            const QuadArray sorted{quad};
+            const WindowArgs args{G, ld, row_index, n_rows, keep, c, n_cols};
+            window_mean(sorted, args, tid, out);
+        }
+        __syncthreads();
+    }
+}
+
+__global__ void lane_selftest_kernel(int32_t* __restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const int masks[11] = {1, 2, 3, 4, 7, 8, 15, 16, 31, 32, 63};
+    const float me = static_cast<float>(lane);
+#pragma unroll
+    for (int p = 0; p < 11; ++p) out[p * 64 + lane] = static_cast<int32_t>(lane_xor(me, masks[p], lane));
+}
+
+}  // namespace
+
+int64_t trimmed_mean_max_rows() { return kGeneralMaxRows; }
+
+int launch_lane_selftest(byz_ctx* ctx, int32_t* out, int32_t* n_patterns, hipStream_t stream) {
+    KernelTimer t(ctx, BYZ_K_MISC, stream);
+    lane_selftest_kernel<<<1, 64, 0, stream>>>(out);
+    *n_patterns = 11;
+    return check_launch("lane_selftest_kernel");
+}
+
+int launch_trimmed_mean(byz_ctx* ctx, const float* G, int64_t n_rows, int64_t n_cols, int64_t ld,
+                        const int32_t* row_index, int64_t keep, float* out, hipStream_t stream) {
+    BYZ_REQUIRE(G && out && n_rows > 0 && n_cols > 0 && ld >= n_cols, "trimmed_mean: bad shape %lld x %lld ld %lld",
+                (long long)n_rows, (long long)n_cols, (long long)ld);
+    BYZ_REQUIRE(keep >= 0 && keep <= n_rows, "trimmed_mean: keep count %lld out of range", (long long)keep);
+    if (n_rows > kGeneralMaxRows) {
+        set_error("trimmed_mean supports at most %d rows, got %lld", kGeneralMaxRows, (long long)n_rows);
+        return BYZ_E_UNSUPPORTED;
+    }
+    KernelTimer t(ctx, BYZ_K_TRIMMED_MEAN, stream);
+    if (n_rows <= kFastMaxRows) {
+        const int64_t n_tiles = ceil_div(n_cols, kTileCols);
+        int64_t grid = n_tiles < static_cast<int64_t>(ctx->num_cus) * 4 ? n_tiles : static_cast<int64_t>(ctx->num_cus) * 4;
+        const size_t lds = static_cast<size_t>(n_rows + kSkewRows) * kStride * sizeof(float);
+        const int r = static_cast<int>(next_pow2(ceil_div(n_rows, 64)));
+#define BYZ_TM(R)                                                                                            \
+    do {                                                                                                     \
+        BYZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&trimmed_mean_regs_kernel<R>),            \
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));    \
+        trimmed_mean_regs_kernel<R><<<static_cast<unsigned>(grid), kFastThreads, lds, stream>>>(            \
+            G, (int)n_rows, n_cols, ld, row_index, (int)keep, out);                                          \
+    } while (0)
+        switch (r) {
+            case 1: BYZ_TM(1); break;
+            case 2: BYZ_TM(2); break;
+            case 4: BYZ_TM(4); break;
+            case 8: BYZ_TM(8); break;
+            default: BYZ_TM(16); break;
+        }
+#undef BYZ_TM
+        return check_launch("trimmed_mean_regs_kernel");
+    }
+    const int64_t n_pad = next_pow2(n_rows);
+    const int64_t n_quads = ceil_div(n_cols, 4);
+    const int64_t grid = n_quads < static_cast<int64_t>(ctx->num_cus) * 2 ? n_quads : static_cast<int64_t>(ctx->num_cus) * 2;
+    const size_t lds = static_cast<size_t>(n_pad) * sizeof(f32x4);
+    BYZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&trimmed_mean_lds_kernel),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
+    trimmed_mean_lds_kernel<<<static_cast<unsigned>(grid), 1024, lds, stream>>>(G, (int)n_rows, (int)n_pad, n_cols, ld,
+                                                                                row_index, (int)keep, out);
+    return check_launch("trimmed_mean_lds_kernel");
+}
+
+}  // namespace byz

@@ -1,0 +1,419 @@
+"""Host-side driver of libbyzagg: one `Engine` per GPU.
+
+The engine accepts either
+  * host matrices (C-contiguous np.float32, exactly what reference server.py:34-35 allocates): staged to
+    the device by the library, results come back as numpy -- this is the drop-in path; or
+  * device-resident matrices (torch CUDA tensors, or `DeviceBuffer`s allocated through the library):
+    nothing crosses PCIe, work is queued on the caller's current stream -- this is the path the large
+    configurations and bench.py use.
+There is no CPU implementation behind it: every method ends in a HIP kernel or raises.
+"""
+import ctypes
+import os
+
+import numpy as np
+
+from . import _native
+
+NAME_TO_ID = {'NoDefense': 0, 'Krum': 1, 'TrimmedMean': 2, 'Bulyan': 3}
+
+
+class EngineError(RuntimeError):
+    pass
+
+
+def _check(rc):
+    if rc == _native.OK:
+        return
+    msg = _native.last_error()
+    if rc == _native.E_PRECONDITION:
+        raise AssertionError(msg)            # the reference asserts (defences.py:25, 56)
+    if rc == _native.E_NO_WINNER:
+        raise KeyError(-1)                   # the reference pops key -1 from its dict (defences.py:65)
+    if rc == _native.E_INVALID:
+        raise ValueError(msg)
+    if rc == _native.E_UNSUPPORTED:
+        raise NotImplementedError(msg)
+    raise EngineError('libbyzagg error %d: %s' % (rc, msg))
+
+
+def _is_torch(x):
+    return type(x).__module__.split('.')[0] == 'torch'
+
+
+def _vp(x):
+    return ctypes.c_void_p(int(x)) if x else None
+
+
+class DeviceBuffer:
+    """Raw device memory owned through the C ABI (lets a host without torch keep data on the GPU)."""
+
+    def __init__(self, engine, shape, dtype):
+        self.engine = engine
+        self.shape = tuple(int(s) for s in shape)
+        self.dtype = np.dtype(dtype)
+        self.nbytes = int(np.prod(self.shape)) * self.dtype.itemsize
+        ptr = ctypes.c_void_p()
+        _check(engine.lib.byz_malloc(engine.ctx, max(self.nbytes, 4), ctypes.byref(ptr)))
+        self.ptr = ptr.value
+
+    def upload(self, array):
+        array = np.ascontiguousarray(array, dtype=self.dtype)
+        assert array.nbytes == self.nbytes
+        _check(self.engine.lib.byz_upload(self.engine.ctx, _vp(self.ptr), array.ctypes.data_as(ctypes.c_void_p),
+                                          self.nbytes, None))
+        _check(self.engine.lib.byz_stream_sync(self.engine.ctx, None))
+        return self
+
+    def numpy(self):
+        out = np.empty(self.shape, dtype=self.dtype)
+        _check(self.engine.lib.byz_download(self.engine.ctx, out.ctypes.data_as(ctypes.c_void_p), _vp(self.ptr),
+                                            self.nbytes, None))
+        return out
+
+    def free(self):
+        if self.ptr and self.engine.ctx:
+            self.engine.lib.byz_free(self.engine.ctx, _vp(self.ptr))
+        self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class Distances:
+    """What `_krum_create_distances` returns here: the N x N fp32 distance matrix, resident on the GPU.
+
+    The reference returns a dict of dicts (defences.py:16-21); `to_dict()` rebuilds that form, with the same
+    key order (1, 0, 2, ...), for code that wants to look inside.
+    """
+
+    def __init__(self, buffer, n):
+        self.buffer, self.n = buffer, n
+
+    @property
+    def ptr(self):
+        return self.buffer.ptr
+
+    def numpy(self):
+        return self.buffer.numpy()
+
+    def to_dict(self):
+        from collections import defaultdict
+        dense = self.numpy()
+        out = defaultdict(dict)
+        for i in range(self.n):
+            for j in range(i):
+                out[i][j] = out[j][i] = dense[i, j]
+        return out
+
+
+class _Matrix:
+    """Uniform view of a caller's matrix: device pointer, shape, leading dimension, stream."""
+
+    def __init__(self, ptr, rows, cols, ld, stream, keepalive, torch_like=None):
+        self.ptr, self.rows, self.cols, self.ld, self.stream = ptr, rows, cols, ld, stream
+        self.keepalive, self.torch_like = keepalive, torch_like
+
+
+class Engine:
+    def __init__(self, device=None):
+        self.lib = _native.load()
+        if device is None:
+            device = int(os.environ.get('BYZ_DEVICE', os.environ.get('LOCAL_RANK', '0')))
+        ctx = ctypes.c_void_p()
+        _check(self.lib.byz_ctx_create(int(device), ctypes.byref(ctx)))
+        self.ctx = ctx
+        self.device = int(device)
+
+    def close(self):
+        if getattr(self, 'ctx', None):
+            self.lib.byz_ctx_destroy(self.ctx)
+            self.ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- memory helpers -----------------------------------------------------------------------
+    def empty(self, shape, dtype=np.float32):
+        return DeviceBuffer(self, shape, dtype)
+
+    def to_device(self, array):
+        array = np.ascontiguousarray(array)
+        return DeviceBuffer(self, array.shape, array.dtype).upload(array)
+
+    def reserve(self, n_rows, n_cols):
+        _check(self.lib.byz_ctx_reserve(self.ctx, int(n_rows), int(n_cols)))
+
+    def synchronize(self, stream=None):
+        _check(self.lib.byz_stream_sync(self.ctx, _vp(stream)))
+
+    def _device_matrix(self, g):
+        """torch CUDA tensor / DeviceBuffer -> _Matrix; None for host arrays."""
+        if isinstance(g, DeviceBuffer):
+            assert g.dtype == np.float32 and len(g.shape) == 2
+            return _Matrix(g.ptr, g.shape[0], g.shape[1], g.shape[1], None, g)
+        if _is_torch(g):
+            import torch
+            if not g.is_cuda:
+                return None
+            if g.dtype != torch.float32 or g.dim() != 2 or g.stride(1) != 1:
+                raise ValueError('device matrices must be 2-D float32 with unit column stride')
+            stream = torch.cuda.current_stream(g.device).cuda_stream
+            return _Matrix(g.data_ptr(), g.shape[0], g.shape[1], g.stride(0), stream, g, torch_like=g)
+        return None
+
+    @staticmethod
+    def _host_matrix(g):
+        if _is_torch(g):
+            g = g.detach().cpu().numpy()
+        g = np.asarray(g)
+        if g.ndim != 2:
+            raise ValueError('expected a 2-D gradient matrix, got shape %r' % (g.shape,))
+        return np.ascontiguousarray(g, dtype=np.float32)
+
+    def _out_like(self, m, n, dtype=np.float32):
+        """Output vector for a device-resident input: torch tensor for torch input, DeviceBuffer otherwise."""
+        if m.torch_like is not None:
+            import torch
+            tdt = {np.dtype(np.float32): torch.float32, np.dtype(np.int32): torch.int32}[np.dtype(dtype)]
+            t = torch.empty(int(n), dtype=tdt, device=m.torch_like.device)
+            return t, t.data_ptr()
+        b = DeviceBuffer(self, (int(n),), dtype)
+        return b, b.ptr
+
+    # ---- defences.py -------------------------------------------------------------------------
+    def defend_host(self, name, g, users_count, corrupted_count, check_assert=True, want_aux=False):
+        """One call for a host matrix: upload, aggregate, download (the numpy drop-in path)."""
+        g = self._host_matrix(g)
+        n, d = g.shape
+        out = np.empty(d, dtype=np.float32)
+        theta = max(int(users_count) - 2 * int(corrupted_count), 1)
+        aux = np.full(max(theta, 1), -1, dtype=np.int32) if want_aux else None
+        _check(self.lib.byz_defend_host(self.ctx, NAME_TO_ID[name], g.ctypes.data_as(ctypes.c_void_p), n, d,
+                                        int(users_count), int(corrupted_count), int(bool(check_assert)),
+                                        out.ctypes.data_as(ctypes.c_void_p),
+                                        aux.ctypes.data_as(ctypes.c_void_p) if want_aux else None))
+        return (out, aux) if want_aux else out
+
+    def no_defense(self, g, users_count=None, corrupted_count=None):
+        m = self._device_matrix(g)
+        if m is None:
+            return self.defend_host('NoDefense', g, 0, 0)
+        out, ptr = self._out_like(m, m.cols)
+        _check(self.lib.byz_no_defense_dev(self.ctx, _vp(m.ptr), m.rows, m.cols, m.ld, _vp(ptr), _vp(m.stream)))
+        return out
+
+    def pairwise_distances(self, g):
+        m = self._device_matrix(g)
+        stage = None
+        if m is None:
+            stage = self.to_device(self._host_matrix(g))
+            m = self._device_matrix(stage)
+        dist = DeviceBuffer(self, (m.rows, m.rows), np.float32)
+        _check(self.lib.byz_pairwise_distances_dev(self.ctx, _vp(m.ptr), m.rows, m.cols, m.ld, _vp(dist.ptr),
+                                                   _vp(m.stream)))
+        self.synchronize(m.stream)
+        return Distances(dist, m.rows)
+
+    def gram(self, g):
+        """fp64 Gram matrix of a device-resident slice (the D-sharded multi-GPU path all-reduces these)."""
+        m = self._device_matrix(g)
+        if m is None:
+            raise ValueError('gram() takes a device-resident matrix')
+        if m.torch_like is not None:
+            import torch
+            out = torch.empty((m.rows, m.rows), dtype=torch.float64, device=m.torch_like.device)
+            ptr = out.data_ptr()
+        else:
+            out = DeviceBuffer(self, (m.rows, m.rows), np.float64)
+            ptr = out.ptr
+        _check(self.lib.byz_gram_dev(self.ctx, _vp(m.ptr), m.rows, m.cols, m.ld, _vp(ptr), _vp(m.stream)))
+        return out
+
+    def distances_from_gram(self, gram, n, stream=None):
+        ptr = gram.data_ptr() if _is_torch(gram) else gram.ptr
+        if _is_torch(gram):
+            import torch
+            stream = torch.cuda.current_stream(gram.device).cuda_stream
+        dist = DeviceBuffer(self, (n, n), np.float32)
+        _check(self.lib.byz_distances_from_gram_dev(self.ctx, _vp(ptr), int(n), _vp(dist.ptr), _vp(stream)))
+        self.synchronize(stream)
+        return Distances(dist, n)
+
+    def _as_distances(self, distances, n_expected=None):
+        if isinstance(distances, Distances):
+            return distances
+        if isinstance(distances, dict):
+            n = len(distances)
+            keys = list(distances.keys())
+            if keys != ([1, 0] + list(range(2, n)) if n >= 2 else []):
+                raise NotImplementedError('only complete distance dicts in creation order are supported')
+            dense = np.full((n, n), np.inf, dtype=np.float32)
+            for i, row in distances.items():
+                if len(row) != n - 1:
+                    raise NotImplementedError('distance dict with removed entries')
+                for j, v in row.items():
+                    dense[i, j] = v
+            distances = dense
+        dense = np.ascontiguousarray(distances, dtype=np.float32)
+        if dense.ndim != 2 or dense.shape[0] != dense.shape[1]:
+            raise ValueError('distances must be a square matrix')
+        return Distances(self.to_device(dense), dense.shape[0])
+
+    def krum_select(self, distances, users_count, corrupted_count):
+        """The selection loop of defences.py:27-37 on a distance matrix; returns the index (or -1)."""
+        d = self._as_distances(distances)
+        idx = ctypes.c_int32(-2)
+        _check(self.lib.byz_krum_select_dev(self.ctx, _vp(d.ptr), d.n, int(users_count), int(corrupted_count),
+                                            ctypes.byref(idx), None, None))
+        return int(idx.value)
+
+    def krum(self, g, users_count, corrupted_count, distances=None, return_index=False):
+        if not return_index:
+            # defences.py:24-25 (the message says +3, the check is +1)
+            assert users_count >= 2 * corrupted_count + 1, (
+                'users_count>=2*corrupted_count + 3', users_count, corrupted_count)
+        if distances is not None:
+            idx = self.krum_select(distances, users_count, corrupted_count)
+            if return_index:
+                return idx
+            return self._row(g, idx)
+        m = self._device_matrix(g)
+        if m is None:
+            if return_index:
+                _, aux = self.defend_host('Krum', g, users_count, corrupted_count, check_assert=False, want_aux=True)
+                return int(aux[0])
+            return self.defend_host('Krum', g, users_count, corrupted_count, check_assert=False)
+        idx = ctypes.c_int32(-2)
+        out, ptr = (None, None) if return_index else self._out_like(m, m.cols)
+        _check(self.lib.byz_krum_dev(self.ctx, _vp(m.ptr), m.rows, m.cols, m.ld, int(users_count),
+                                     int(corrupted_count), 0, _vp(ptr), ctypes.byref(idx), _vp(m.stream)))
+        return int(idx.value) if return_index else out
+
+    def _row(self, g, idx):
+        """Row `idx` of the caller's matrix, in the caller's own container type (negative idx as numpy)."""
+        if isinstance(g, DeviceBuffer):
+            return g.numpy()[idx]
+        return g[idx]
+
+    def trimmed_mean(self, g, users_count=None, corrupted_count=0, row_index=None):
+        m = self._device_matrix(g)
+        if m is None:
+            if row_index is not None:
+                g = self._host_matrix(g)[np.asarray(row_index)]
+            return self.defend_host('TrimmedMean', g, 0, corrupted_count)
+        n_rows, idx_ptr, keep = m.rows, None, None
+        if row_index is not None:
+            if _is_torch(row_index):
+                idx_ptr, n_rows, keep = row_index.data_ptr(), row_index.numel(), row_index
+            elif isinstance(row_index, DeviceBuffer):
+                idx_ptr, n_rows, keep = row_index.ptr, row_index.shape[0], row_index
+            else:
+                keep = self.to_device(np.asarray(row_index, dtype=np.int32))
+                idx_ptr, n_rows = keep.ptr, keep.shape[0]
+        out, ptr = self._out_like(m, m.cols)
+        _check(self.lib.byz_trimmed_mean_dev(self.ctx, _vp(m.ptr), int(n_rows), m.cols, m.ld, _vp(idx_ptr),
+                                             int(corrupted_count), _vp(ptr), _vp(m.stream)))
+        if not (_is_torch(row_index) or row_index is None):
+            self.synchronize(m.stream)  # the temporary index buffer must outlive the kernel
+        return out
+
+    def bulyan_select(self, distances, users_count, corrupted_count):
+        d = self._as_distances(distances)
+        theta = int(users_count) - 2 * int(corrupted_count)
+        sel = DeviceBuffer(self, (max(theta, 1),), np.int32)
+        _check(self.lib.byz_bulyan_select_dev(self.ctx, _vp(d.ptr), d.n, int(users_count), int(corrupted_count),
+                                              _vp(sel.ptr), None))
+        return sel.numpy()[:theta]
+
+    def bulyan(self, g, users_count, corrupted_count, return_selection=False):
+        assert users_count >= 4 * corrupted_count + 3  # defences.py:56
+        m = self._device_matrix(g)
+        if m is None:
+            if return_selection:
+                out, aux = self.defend_host('Bulyan', g, users_count, corrupted_count, want_aux=True)
+                return out, aux[:int(users_count) - 2 * int(corrupted_count)]
+            return self.defend_host('Bulyan', g, users_count, corrupted_count)
+        theta = int(users_count) - 2 * int(corrupted_count)
+        out, ptr = self._out_like(m, m.cols)
+        sel, sel_ptr = self._out_like(m, max(theta, 1), np.int32) if return_selection else (None, None)
+        _check(self.lib.byz_bulyan_dev(self.ctx, _vp(m.ptr), m.rows, m.cols, m.ld, int(users_count),
+                                       int(corrupted_count), _vp(ptr), _vp(sel_ptr), _vp(m.stream)))
+        return (out, sel) if return_selection else out
+
+    # ---- malicious.py ------------------------------------------------------------------------
+    def drift_attack(self, rows, num_std, write_back=False):
+        """(drift, mean, std) over the rows; device inputs may be overwritten in place (write_back)."""
+        m = self._device_matrix(rows)
+        if m is None:
+            g = self._host_matrix(rows)
+            n, d = g.shape
+            drift, mean, std = (np.empty(d, dtype=np.float32) for _ in range(3))
+            _check(self.lib.byz_drift_attack_host(self.ctx, g.ctypes.data_as(ctypes.c_void_p), n, d, float(num_std),
+                                                  drift.ctypes.data_as(ctypes.c_void_p),
+                                                  mean.ctypes.data_as(ctypes.c_void_p),
+                                                  std.ctypes.data_as(ctypes.c_void_p)))
+            return drift, mean, std
+        outs = [self._out_like(m, m.cols) for _ in range(3)]
+        _check(self.lib.byz_drift_attack_dev(self.ctx, _vp(m.ptr), m.rows, m.cols, m.ld, float(num_std),
+                                             _vp(outs[0][1]), _vp(outs[1][1]), _vp(outs[2][1]),
+                                             int(bool(write_back)), _vp(m.stream)))
+        return outs[0][0], outs[1][0], outs[2][0]
+
+    def drift_axpy_host(self, mean, std, num_std):
+        """DriftAttack._attack_grads on host vectors (malicious.py:34-36), computed on the device."""
+        mean_c = np.ascontiguousarray(mean, dtype=np.float32)
+        a, b = self.to_device(mean_c), self.to_device(np.ascontiguousarray(std, dtype=np.float32))
+        _check(self.lib.byz_drift_axpy_dev(self.ctx, _vp(a.ptr), _vp(b.ptr), mean_c.size, float(num_std), None))
+        return a.numpy()
+
+    # ---- server.py:89-90 ---------------------------------------------------------------------
+    def server_update(self, weights, velocity, agg, momentum, learning_rate):
+        """In-place fused momentum update on device-resident vectors (torch tensors or DeviceBuffers)."""
+        def ptr_of(x):
+            return x.data_ptr() if _is_torch(x) else x.ptr
+        n = weights.numel() if _is_torch(weights) else int(np.prod(weights.shape))
+        stream = None
+        if _is_torch(weights):
+            import torch
+            stream = torch.cuda.current_stream(weights.device).cuda_stream
+        _check(self.lib.byz_server_update_dev(self.ctx, _vp(ptr_of(weights)), _vp(ptr_of(velocity)), _vp(ptr_of(agg)),
+                                              int(n), float(momentum), float(learning_rate), _vp(stream)))
+
+    # ---- timing ------------------------------------------------------------------------------
+    def timing(self, on=True):
+        _check(self.lib.byz_timing_enable(self.ctx, int(bool(on))))
+        _check(self.lib.byz_timing_reset(self.ctx))
+
+    def timing_read(self):
+        out = {}
+        for k, name in enumerate(_native.KERNELS):
+            ms, calls = ctypes.c_double(0.0), ctypes.c_int64(0)
+            _check(self.lib.byz_timing_read(self.ctx, k, ctypes.byref(ms), ctypes.byref(calls)))
+            if calls.value:
+                out[name] = {'total_ms': ms.value, 'launches': calls.value}
+        return out
+
+    def lane_exchange_selftest(self):
+        buf = DeviceBuffer(self, (16 * 64,), np.int32)
+        n = ctypes.c_int32(0)
+        _check(self.lib.byz_selftest_lane_exchange_dev(self.ctx, _vp(buf.ptr), ctypes.byref(n), None))
+        self.synchronize()
+        return buf.numpy()[: n.value * 64].reshape(n.value, 64)
+
+
+_default = None
+
+
+def get_engine():
+    """Process-wide engine on BYZ_DEVICE / LOCAL_RANK (default GPU 0); created on first use."""
+    global _default
+    if _default is None:
+        _default = Engine()
+    return _default

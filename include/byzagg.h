@@ -1,0 +1,170 @@
+/*
+ * byzagg -- C ABI of the MI355X (gfx950) Byzantine-robust aggregation engine.
+ *
+ * This is the drop-in boundary for the hot path of shaneson0/attacking_federate_learning:
+ * what `defences.py` and `malicious.py` compute on the host with numpy, this library
+ * computes on one GPU with hand-written HIP kernels.  Plain C types only: pointers, sizes,
+ * a stream handle passed as `void*` (a `hipStream_t`, NULL = the default stream).  No torch
+ * types cross this line.  The reference is pure Python, so a maintainer binds these with
+ * ctypes; INTEGRATION.md shows the stub.
+ *
+ * Conventions
+ *   - G is the (n_rows x n_cols) fp32 gradient matrix, row-major, leading dimension `ld`
+ *     (elements).  It corresponds to `Server.users_grads` (reference server.py:34-35).
+ *   - "_dev" pointers are device pointers; "_host" entry points take host pointers and do the
+ *     staging copies themselves (pinned bounce buffers owned by the context).
+ *   - Every call is asynchronous on `stream` unless it has a host output, in which case it
+ *     returns after that output is valid.
+ *   - Return value: BYZ_OK (0) or a negative BYZ_E_* code; `byz_last_error()` has the text.
+ *     BYZ_E_PRECONDITION mirrors the reference's `assert`s (defences.py:25, 56): the Python
+ *     shim turns it into AssertionError.
+ *   - The context owns all workspaces (distance matrix, sort buffers, split-K slabs).  They
+ *     grow on demand outside the kernels; `byz_ctx_reserve` pre-sizes them so that no
+ *     allocation happens on the hot path.
+ *   - One call in flight per context (the reference is single-threaded and synchronous).
+ */
+#ifndef BYZAGG_H
+#define BYZAGG_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BYZ_ABI_VERSION 1
+
+enum {
+    BYZ_OK = 0,
+    BYZ_E_INVALID = -1,      /* bad argument (null pointer, negative size, ld < n_cols ...)   */
+    BYZ_E_PRECONDITION = -2, /* the reference would raise AssertionError                       */
+    BYZ_E_HIP = -3,          /* a HIP runtime call failed                                      */
+    BYZ_E_UNSUPPORTED = -4,  /* size beyond what this build supports (see byz_limits)          */
+    BYZ_E_NO_WINNER = -5     /* Krum found no score < 1e20 (reference: index -1 / KeyError)    */
+};
+
+typedef struct byz_ctx byz_ctx;
+
+/* ---- context -------------------------------------------------------------------------- */
+int byz_abi_version(void);
+const char* byz_last_error(void);                       /* thread-local text of the last failure */
+int byz_ctx_create(int device, byz_ctx** out);
+void byz_ctx_destroy(byz_ctx* ctx);
+int byz_ctx_reserve(byz_ctx* ctx, int64_t n_rows, int64_t n_cols);
+int byz_ctx_device(const byz_ctx* ctx);
+/* largest supported row count for the selection kernels (rows of G), and for trimmed_mean */
+int byz_limits(int64_t* max_rows_select, int64_t* max_rows_trimmed);
+
+/* ---- raw device memory, so that a host without torch can still drive the library ------- */
+int byz_malloc(byz_ctx* ctx, int64_t bytes, void** dev_ptr);
+int byz_free(byz_ctx* ctx, void* dev_ptr);
+int byz_upload(byz_ctx* ctx, void* dst_dev, const void* src_host, int64_t bytes, void* stream);
+int byz_download(byz_ctx* ctx, void* dst_host, const void* src_dev, int64_t bytes, void* stream);
+int byz_upload_2d(byz_ctx* ctx, void* dst_dev, int64_t dst_pitch_bytes, const void* src_host,
+                  int64_t src_pitch_bytes, int64_t width_bytes, int64_t rows, void* stream);
+int byz_stream_sync(byz_ctx* ctx, void* stream);
+
+/* ---- defences.no_defense (reference defences.py:13-14) --------------------------------- */
+/* out_dev[c] = mean over rows of G[:, c].                                                  */
+int byz_no_defense_dev(byz_ctx* ctx, const float* G_dev, int64_t n_rows, int64_t n_cols,
+                       int64_t ld, float* out_dev, void* stream);
+
+/* ---- defences._krum_create_distances (reference defences.py:16-21) --------------------- */
+/* dist_dev: (n_rows x n_rows) fp32, row-major, unsquared L2 distances, diagonal = +inf     */
+/* (the reference stores no self-distance).  Gram via fp32 MFMA, chunk partials in fp64.    */
+int byz_pairwise_distances_dev(byz_ctx* ctx, const float* G_dev, int64_t n_rows, int64_t n_cols,
+                               int64_t ld, float* dist_dev, void* stream);
+/* The two halves of the above, exposed for the D-sharded multi-GPU path: every rank computes */
+/* the Gram of its column slice in fp64, the host all-reduces it, then every rank converts.   */
+int byz_gram_dev(byz_ctx* ctx, const float* G_dev, int64_t n_rows, int64_t n_cols, int64_t ld,
+                 double* gram_dev, void* stream);
+int byz_distances_from_gram_dev(byz_ctx* ctx, const double* gram_dev, int64_t n_rows,
+                                float* dist_dev, void* stream);
+
+/* ---- defences.krum (reference defences.py:23-42) --------------------------------------- */
+/* Selection loop only: ascending sort of every row's distances, sequential fp32 sum of the */
+/* first (users_count - corrupted_count), candidates visited in order 1,0,2,3,... with a    */
+/* strict '<' against 1e20.  *index_host = winner or -1.  scores_dev (optional, n_rows).    */
+int byz_krum_select_dev(byz_ctx* ctx, const float* dist_dev, int64_t n_rows, int64_t users_count,
+                        int64_t corrupted_count, int32_t* index_host, float* scores_dev,
+                        void* stream);
+/* Whole function.  check_assert != 0 applies `users_count >= 2*corrupted_count + 1`        */
+/* (the reference skips it when return_index=True).  out_row_dev (optional) receives a copy */
+/* of the winning row (index -1 selects the last row, as numpy's G[-1] does).               */
+int byz_krum_dev(byz_ctx* ctx, const float* G_dev, int64_t n_rows, int64_t n_cols, int64_t ld,
+                 int64_t users_count, int64_t corrupted_count, int check_assert,
+                 float* out_row_dev, int32_t* index_host, void* stream);
+
+/* ---- defences.trimmed_mean (reference defences.py:44-52) ------------------------------- */
+/* Per column: fp32 median, keep the k = n_rows - corrupted_count - 1 values closest to it  */
+/* (ties in |x - med| by row order), out = mean(kept - med) + med.  row_index_dev (optional)*/
+/* selects and orders the rows: row r of the logical matrix is G[row_index[r]].  k follows  */
+/* Python slice semantics (k == 0 -> NaN, k < 0 -> drop from the far end).                  */
+int byz_trimmed_mean_dev(byz_ctx* ctx, const float* G_dev, int64_t n_rows, int64_t n_cols,
+                         int64_t ld, const int32_t* row_index_dev, int64_t corrupted_count,
+                         float* out_dev, void* stream);
+
+/* ---- defences.bulyan (reference defences.py:55-70) ------------------------------------- */
+/* Selection loop on a distance matrix: theta = users_count - 2*corrupted_count picks, each */
+/* the Krum winner among the rows still present, scores in fp64.            */
+/* selection_dev: theta int32 indices in selection order.                                   */
+int byz_bulyan_select_dev(byz_ctx* ctx, const float* dist_dev, int64_t n_rows, int64_t users_count,
+                          int64_t corrupted_count, int32_t* selection_dev, void* stream);
+/* Whole function (asserts users_count >= 4*corrupted_count + 3).  selection_dev optional.  */
+int byz_bulyan_dev(byz_ctx* ctx, const float* G_dev, int64_t n_rows, int64_t n_cols, int64_t ld,
+                   int64_t users_count, int64_t corrupted_count, float* out_dev,
+                   int32_t* selection_dev, void* stream);
+
+/* ---- malicious.Attack.attack / DriftAttack._attack_grads (malicious.py:10-36) ---------- */
+/* Column mean and population std over the n_rows rows of G (the malicious clients' honest  */
+/* gradients), drifted vector = mean - num_std * std.  Any output pointer may be NULL.      */
+/* write_back != 0 also overwrites every row of G with the drifted vector (what             */
+/* collect_gradients would copy in, server.py:81-83).                                       */
+int byz_drift_attack_dev(byz_ctx* ctx, float* G_dev, int64_t n_rows, int64_t n_cols, int64_t ld,
+                         float num_std, float* drift_dev, float* mean_dev, float* std_dev,
+                         int write_back, void* stream);
+/* The hook alone (malicious.py:34-36): mean[:] -= num_std * std[:], in place on the device. */
+int byz_drift_axpy_dev(byz_ctx* ctx, float* mean_dev, const float* std_dev, int64_t n,
+                       float num_std, void* stream);
+
+/* ---- next row after the path: Server.defend's update (server.py:89-90) ----------------- */
+/* velocity = momentum*velocity - lr*agg ; weights += velocity, fused, in place.            */
+int byz_server_update_dev(byz_ctx* ctx, float* weights_dev, float* velocity_dev,
+                          const float* agg_dev, int64_t n, float momentum, float learning_rate,
+                          void* stream);
+
+/* ---- host-pointer convenience (what the numpy drop-in uses) ---------------------------- */
+/* G_host is the reference's C-contiguous np.float32 users_grads.  name: 0 NoDefense, 1 Krum, */
+/* 2 TrimmedMean, 3 Bulyan (the keys of defences.defend, defences.py:73-75).  out_host: n_cols */
+/* floats.  aux_host (optional): Krum -> 1 int32 (index), Bulyan -> theta int32 (selection).  */
+int byz_defend_host(byz_ctx* ctx, int name, const float* G_host, int64_t n_rows, int64_t n_cols,
+                    int64_t users_count, int64_t corrupted_count, int check_assert,
+                    float* out_host, int32_t* aux_host);
+int byz_pairwise_distances_host(byz_ctx* ctx, const float* G_host, int64_t n_rows, int64_t n_cols,
+                                float* dist_host);
+int byz_krum_select_host(byz_ctx* ctx, const float* dist_host, int64_t n_rows, int64_t users_count,
+                         int64_t corrupted_count, int32_t* index_host);
+int byz_drift_attack_host(byz_ctx* ctx, const float* rows_host, int64_t n_rows, int64_t n_cols,
+                          float num_std, float* drift_host, float* mean_host, float* std_host);
+
+/* ---- per-kernel timing (bench.py's roofline leg) --------------------------------------- */
+/* When enabled, every kernel launch is bracketed by HIP events on its own stream.          */
+enum {
+    BYZ_K_COLUMN_STATS = 0, BYZ_K_GRAM = 1, BYZ_K_GRAM_REDUCE = 2, BYZ_K_DISTANCES = 3,
+    BYZ_K_ROW_SORT = 4, BYZ_K_KRUM_ARGMIN = 5, BYZ_K_BULYAN_LOOP = 6, BYZ_K_TRIMMED_MEAN = 7,
+    BYZ_K_MISC = 8, BYZ_K_COUNT = 9
+};
+int byz_timing_enable(byz_ctx* ctx, int on);
+int byz_timing_reset(byz_ctx* ctx);
+int byz_timing_read(byz_ctx* ctx, int kernel, double* total_ms, int64_t* launches);
+const char* byz_kernel_name(int kernel);
+
+/* ---- self-test of the cross-lane exchange primitives (tests only) ----------------------- */
+/* out_dev: 64 * n_patterns int32; entry [p*64 + lane] = source lane observed by `lane`.     */
+int byz_selftest_lane_exchange_dev(byz_ctx* ctx, int32_t* out_dev, int32_t* n_patterns_host,
+                                   void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BYZAGG_H */

@@ -1,0 +1,97 @@
+"""CPU checks of the boundary: the shared library exports what include/byzagg.h declares, the drop-in modules
+expose the reference's names and signatures, and the product refuses to run without its HIP path."""
+import inspect
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, 'include', 'byzagg.h')).read()
+    text = re.sub(r'/\*.*?\*/', '', text, flags=re.S)
+    return sorted(set(re.findall(r'\b(byz_[a-z0-9_]+)\s*\(', text)))
+
+
+def test_library_exports_every_declared_symbol():
+    from attacking_federate_learning_amd import _native, build_native
+    build_native.build()
+    lib = _native.load()
+    names = declared_symbols()
+    assert len(names) >= 30
+    for name in names:
+        assert hasattr(lib, name), name
+    assert sorted(_native.EXPORTED_SYMBOLS) == names       # the ctypes table covers the whole header
+    assert lib.byz_abi_version() == 1
+    assert lib.byz_kernel_name(1) == b'gram_tile'
+
+
+def test_limits_are_reported_without_a_gpu():
+    import ctypes
+    from attacking_federate_learning_amd import _native
+    lib = _native.load()
+    a, b = ctypes.c_int64(), ctypes.c_int64()
+    assert lib.byz_limits(ctypes.byref(a), ctypes.byref(b)) == 0
+    assert a.value >= 10000 and b.value >= 5200     # config 5: N = 10000 selection, theta = 5200 second stage
+
+
+def test_no_cpu_fallback():
+    """Without a GPU the product path fails loudly instead of computing somewhere else."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip('a GPU is present')
+    from attacking_federate_learning_amd import defences, malicious
+    g = np.zeros((5, 8), dtype=np.float32)
+    for name in ('NoDefense', 'Krum', 'TrimmedMean', 'Bulyan'):
+        with pytest.raises(RuntimeError):
+            defences.defend[name](g, 5, 0)
+
+    class U:
+        grads, original_params, learning_rate = g[0], None, None
+    with pytest.raises(RuntimeError):
+        malicious.DriftAttack(1.5).attack([U()])
+
+
+def test_product_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, 'attacking_federate_learning_amd')
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith(('.py', '.hip', '.hpp', '.h')):
+                src = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r'^\s*(from|import)\s+oracle\b', src, flags=re.M), f
+                assert 'oracle/' not in src or f == 'sharded.py' or 'tests/' in src, f
+
+
+def test_drop_in_surface_matches_the_reference(reference_modules):
+    from attacking_federate_learning_amd import defences, malicious
+    ref_d, ref_m = reference_modules['defences'], reference_modules['malicious']
+    for name in ('no_defense', '_krum_create_distances', 'krum', 'trimmed_mean', 'bulyan'):
+        assert str(inspect.signature(getattr(defences, name))) == str(inspect.signature(getattr(ref_d, name))), name
+    assert list(defences.defend) == list(ref_d.defend)
+    for attr in ('NoDefense', 'Krum', 'TrimmedMean', 'Bulyan'):
+        assert getattr(defences.DefenseTypes, attr) == getattr(ref_d.DefenseTypes, attr)
+    for cls in ('Attack', 'DriftAttack'):
+        for meth in ('__init__', 'attack'):
+            assert str(inspect.signature(getattr(getattr(malicious, cls), meth))) == \
+                str(inspect.signature(getattr(getattr(ref_m, cls), meth)))
+    assert str(inspect.signature(malicious.DriftAttack._attack_grads)) == \
+        str(inspect.signature(ref_m.DriftAttack._attack_grads))
+    assert issubclass(malicious.DriftAttack, malicious.Attack)
+    att = malicious.Attack(1.5)
+    assert (att.num_std, att.grads_mean, att.grads_stdev) == (1.5, None, None)
+
+
+def test_dropin_shims_resolve():
+    import importlib.util
+    for name in ('defences', 'malicious'):
+        path = os.path.join(ROOT, 'attacking_federate_learning_amd', 'dropin', name + '.py')
+        spec = importlib.util.spec_from_file_location('shim_' + name, path)
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+        if name == 'defences':
+            assert callable(mod.defend['Krum']) and mod.DefenseTypes.Bulyan == 'Bulyan'
+        else:
+            assert issubclass(mod.DriftAttack, mod.Attack)

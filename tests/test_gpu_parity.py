@@ -1,0 +1,335 @@
+"""Parity of the HIP path against the CPU oracle and the reference's golden vectors (needs an MI355X).
+
+Everything goes through the C ABI (libbyzagg.so) via the drop-in modules or the Engine.
+Tolerances: indices bit-exact; aggregated fp32 vectors |d| <= 1e-5 + 1e-5*|ref| (BASELINE.json north_star).
+"""
+import warnings
+
+import numpy as np
+import pytest
+
+from oracle import faithful, ideal
+
+pytestmark = pytest.mark.gpu
+
+RTOL = ATOL = 1e-5
+
+
+@pytest.fixture(scope='module')
+def eng():
+    from attacking_federate_learning_amd.engine import get_engine
+    return get_engine()
+
+
+@pytest.fixture(scope='module')
+def defences():
+    from attacking_federate_learning_amd import defences
+    return defences
+
+
+def close(a, b, rtol=RTOL, atol=ATOL):
+    return np.allclose(np.asarray(a), np.asarray(b), rtol=rtol, atol=atol, equal_nan=True)
+
+
+def gaussian(seed, n, d):
+    return np.random.default_rng(seed).standard_normal((n, d)).astype(np.float32)
+
+
+def scaled(seed, n, d):
+    rng = np.random.default_rng(seed)
+    g = rng.standard_normal((n, d)).astype(np.float32)
+    return g * (1.0 + 0.5 * rng.permutation(n) / n).astype(np.float32)[:, None]
+
+
+# ---- primitives -------------------------------------------------------------------------------------
+def test_lane_exchange_patterns(eng):
+    got = eng.lane_exchange_selftest()
+    masks = [1, 2, 3, 4, 7, 8, 15, 16, 31, 32, 63]
+    assert got.shape == (len(masks), 64)
+    for row, m in zip(got, masks):
+        assert row.tolist() == [lane ^ m for lane in range(64)], 'lane_xor(%d)' % m
+
+
+# ---- golden vectors minted from the reference -------------------------------------------------------
+def test_golden_no_defense(defences, golden):
+    c = golden['nodef_7x130']
+    assert close(defences.no_defense(c['G'], 7, 1), c['out'])
+
+
+@pytest.mark.parametrize('case', ['krum_iid_10x257', 'krum_scaled_33x1000', 'krum_attacked_12x300',
+                                  'krum_allsame_6x64', 'krum_f0_5x40'])
+def test_golden_krum(defences, eng, golden, case):
+    c = golden[case]
+    g, f, n = c['G'], int(c['f']), len(c['G'])
+    # selection on the reference's own distance matrix: bit-exact scores -> identical index
+    assert eng.krum_select(c['dist'], n, f) == int(c['index'])
+    # end to end (Gram distances)
+    assert defences.krum(g, n, f, return_index=True) == int(c['index'])
+    assert np.array_equal(defences.krum(g, n, f), c['out'])
+    dist = defences._krum_create_distances(g).numpy()
+    off = ~np.eye(n, dtype=bool)
+    assert np.all(np.isinf(np.diag(dist)))
+    assert np.allclose(dist[off], c['dist'][off], rtol=2e-6, atol=1e-6)
+    assert np.array_equal(dist, dist.T)
+
+
+def test_golden_krum_all_nan(defences, golden):
+    c = golden['krum_allnan_4x8']
+    assert defences.krum(c['G'], 4, int(c['f']), return_index=True) == -1
+
+
+@pytest.mark.parametrize('case', ['tm_odd_11x97', 'tm_even_10x97', 'tm_100x64', 'tm_attacked_20x50',
+                                  'tm_c0_9x33', 'tm_edge_ties_c1', 'tm_edge_ties_c2', 'tm_edge_ties_c3',
+                                  'tm_edge_ties_c4', 'tm_kzero_6x20', 'tm_kneg_6x20'])
+def test_golden_trimmed_mean(defences, golden, case):
+    c = golden[case]
+    got = defences.trimmed_mean(c['G'], len(c['G']), int(c['c']))
+    assert got.dtype == np.float32 and got.shape == c['out'].shape
+    assert close(got, c['out']), (got, c['out'])
+
+
+@pytest.mark.parametrize('case', ['bulyan_iid_11x200', 'bulyan_boundary_15x120', 'bulyan_scaled_40x500',
+                                  'bulyan_attacked_23x150', 'bulyan_f0_6x30'])
+def test_golden_bulyan(defences, eng, golden, case):
+    c = golden[case]
+    g, f, n = c['G'], int(c['f']), len(c['G'])
+    out, sel = eng.bulyan(g, n, f, return_selection=True)
+    assert sel.tolist() == c['selection'].tolist()
+    assert close(out, c['out'])
+    assert close(defences.bulyan(g, n, f), c['out'])
+
+
+@pytest.mark.parametrize('case', ['attack_5x300_z1.5', 'attack_24x100_z0.5', 'attack_3x64_z0'])
+def test_golden_attack(golden, case):
+    from attacking_federate_learning_amd import malicious
+
+    class User:
+        def __init__(self, grads):
+            self.grads, self.original_params, self.learning_rate = grads, None, None
+
+    c = golden[case]
+    users = [User(r.copy()) for r in c['G']]
+    att = malicious.DriftAttack(float(c['z']))
+    att.attack(users)
+    assert close(att.grads_stdev, c['stored_stdev'], atol=1e-6)
+    assert close(att.grads_mean, c['stored_mean'])
+    assert close(users[0].grads, c['user0'])
+    assert all(u.grads is users[0].grads for u in users) == bool(c['aliased'])
+
+
+def test_assertions_like_the_reference(defences):
+    g = gaussian(1, 6, 10)
+    with pytest.raises(AssertionError):
+        defences.krum(g, 6, 3)
+    with pytest.raises(AssertionError):
+        defences.bulyan(g, 6, 3)
+    assert isinstance(defences.krum(g, 6, 3, return_index=True), int)   # the assert is skipped (defences.py:24)
+    assert set(defences.defend) == {'NoDefense', 'Krum', 'TrimmedMean', 'Bulyan'}
+
+
+# ---- seeded random inputs against the oracle --------------------------------------------------------
+@pytest.mark.parametrize('n,d', [(2, 1), (3, 7), (10, 79510), (100, 21840), (100, 79510), (129, 4097),
+                                 (300, 20000), (1000, 3001)])
+def test_distances_vs_fp64(eng, n, d):
+    g = gaussian(1000 + n, n, d)
+    got = eng.pairwise_distances(g).numpy()
+    want = ideal.distance_matrix(g)
+    off = ~np.eye(n, dtype=bool)
+    rel = np.abs(got[off] - want[off]) / want[off]
+    assert rel.max() < 1e-6, rel.max()          # the reference's own sdot noise is 5e-8 .. 4e-7
+    assert np.array_equal(got, got.T) and np.all(np.isinf(np.diag(got)))
+
+
+def test_identical_rows_have_zero_distance_and_tie_exactly(eng):
+    g = gaussian(7, 50, 33333)
+    g[:12] = g[3]
+    dist = eng.pairwise_distances(g).numpy()
+    assert np.all(dist[:12, :12][~np.eye(12, dtype=bool)] == 0.0)
+    assert all(np.array_equal(dist[0, 12:], dist[i, 12:]) for i in range(12))
+    # every copy has the same score; the reference's visit order 1, 0, 2, ... decides
+    idx = eng.krum_select(dist, 50, 12)
+    want = faithful.krum_pick(dist, faithful.visit_order(50), 50, 12)
+    assert idx == want
+
+
+@pytest.mark.parametrize('n,f', [(2, 0), (5, 1), (64, 15), (100, 24), (128, 31), (333, 80), (1000, 240)])
+def test_krum_selection_is_bit_exact_given_distances(eng, n, f):
+    rng = np.random.default_rng(2000 + n)
+    pts = rng.standard_normal((n, 24)).astype(np.float32)
+    dist = np.sqrt(((pts[:, None, :] - pts[None, :, :]) ** 2).sum(-1)).astype(np.float32)
+    np.fill_diagonal(dist, np.inf)
+    want = faithful.krum_pick(dist, faithful.visit_order(n), n, f)
+    assert eng.krum_select(dist, n, f) == want
+
+
+@pytest.mark.parametrize('n,d,f', [(100, 79510, 24), (100, 21840, 24), (256, 10000, 60)])
+def test_krum_end_to_end_margin_protocol(eng, n, d, f):
+    g = scaled(3000 + n, n, d)
+    idx = eng.krum(g, n, f, return_index=True)
+    want, margin, scores = ideal.krum_index(ideal.distance_matrix(g), n, f, with_margin=True)
+    tau = 16 * np.finfo(np.float32).eps
+    if margin > tau:
+        assert idx == want
+    else:
+        assert scores[idx] <= scores[want] * (1 + tau)
+    assert np.array_equal(eng.krum(g, n, f), g[idx])
+
+
+@pytest.mark.parametrize('n', [1, 2, 3, 10, 63, 64, 65, 100, 127, 128, 129, 500, 1000, 1024])
+@pytest.mark.parametrize('d', [1, 33, 1000])
+def test_trimmed_mean_register_kernel(eng, n, d):
+    g = gaussian(4000 + n * 7 + d, n, d)
+    c = n // 5
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        want = ideal.trimmed_mean(g, c)
+    assert close(eng.trimmed_mean(g, n, c), want)
+
+
+@pytest.mark.parametrize('n,c', [(7, 2), (8, 1), (40, 9), (100, 20), (257, 64)])
+def test_trimmed_mean_heavy_ties_match_the_reference_rule(eng, n, c):
+    # half-integer data: many exact +a / -a ties around the median, the stable row order decides
+    g = (np.round(gaussian(5000 + n, n, 300) * 2) / 2).astype(np.float32)
+    want = faithful.trimmed_mean(g, n, c)
+    assert close(eng.trimmed_mean(g, n, c), want)
+
+
+@pytest.mark.parametrize('n,d', [(1025, 64), (1500, 130), (2080, 257), (4096, 36)])
+def test_trimmed_mean_general_kernel(eng, n, d):
+    g = gaussian(6000 + n, n, d)
+    c = n // 4
+    assert close(eng.trimmed_mean(g, n, c), ideal.trimmed_mean(g, c))
+
+
+def test_trimmed_mean_row_index_orders_the_rows(eng):
+    g = (np.round(gaussian(61, 60, 200)) ).astype(np.float32)   # integers: ties everywhere
+    order = np.random.default_rng(3).permutation(60)[:41].astype(np.int32)
+    want = faithful.trimmed_mean(g[order], 41, 10)
+    gd = eng.to_device(g)
+    got = eng.trimmed_mean(gd, 60, 10, row_index=order).numpy()
+    assert close(got, want)
+
+
+@pytest.mark.parametrize('n,d,f', [(11, 50, 2), (40, 3000, 9), (100, 20000, 24), (301, 5000, 74),
+                                   (1000, 2000, 240)])
+def test_bulyan_vs_fp64_oracle(eng, n, d, f):
+    g = scaled(7000 + n, n, d)
+    out, sel = eng.bulyan(g, n, f, return_selection=True)
+    dist = ideal.distance_matrix(g)
+    want_sel, margins = ideal.bulyan_selection(dist, n, f, with_margins=True)
+    tau = 16 * np.finfo(np.float32).eps
+    sel = sel.tolist()
+    assert len(sel) == n - 2 * f and len(set(sel)) == len(sel)
+    first_noisy = int(np.argmax(margins <= tau)) if np.any(margins <= tau) else len(sel)
+    assert sel[:first_noisy] == want_sel[:first_noisy]
+    if first_noisy == len(sel):
+        assert close(out, ideal.trimmed_mean(g[want_sel], 2 * f))
+    # whatever was picked, the second stage must be the reference's trimmed mean of exactly those rows
+    assert close(out, ideal.trimmed_mean(g[sel], 2 * f))
+
+
+def test_bulyan_selection_matches_fp64_given_the_same_distances(eng):
+    rng = np.random.default_rng(77)
+    pts = rng.standard_normal((200, 16)).astype(np.float32)
+    dist = np.sqrt(((pts[:, None, :] - pts[None, :, :]) ** 2).sum(-1)).astype(np.float32)
+    np.fill_diagonal(dist, np.inf)
+    for f in (0, 1, 20, 49):
+        assert eng.bulyan_select(dist, 200, f).tolist() == ideal.bulyan_selection(dist, 200, f)
+
+
+def test_bulyan_under_the_drift_attack_keeps_exact_ties(eng):
+    n, d, f = 43, 4000, 10
+    g = scaled(81, n, d)
+    g[:f] = faithful.drift_vector(g[:f].copy(), 1.5)
+    out, sel = eng.bulyan(g, n, f, return_selection=True)
+    want_out, want_sel = faithful.bulyan(g, n, f, return_selection=True)
+    assert sel.tolist() == want_sel
+    assert close(out, want_out)
+
+
+@pytest.mark.parametrize('m,d,z', [(1, 10, 1.5), (24, 79510, 1.5), (240, 5000, 0.7), (5, 1 << 20, 1.5)])
+def test_drift_attack_statistics(eng, m, d, z):
+    g = gaussian(8000 + m, m, d) * 2 + 0.5
+    drift, mean, std = eng.drift_attack(g, z)
+    want_mean, want_std = faithful.attack_statistics(g)
+    assert close(mean, want_mean) and close(std, want_std, atol=1e-6)
+    assert close(drift, faithful.drift_vector(g, z))
+
+
+def test_no_defense_sizes(eng):
+    for n, d in [(1, 1), (10, 79510), (100, 21840), (1000, 4096), (7, 1 << 20)]:
+        g = gaussian(9000 + n, n, d)
+        assert close(eng.no_defense(g), np.mean(g, axis=0))
+
+
+def test_server_update_is_bit_exact(eng):
+    rng = np.random.default_rng(5)
+    w, v, a = (rng.standard_normal(100003).astype(np.float32) for _ in range(3))
+    wd, vd, ad = eng.to_device(w), eng.to_device(v), eng.to_device(a)
+    eng.server_update(wd, vd, ad, 0.9, 0.1)
+    eng.synchronize()
+    v2 = np.float32(0.9) * v - np.float32(0.1) * a      # server.py:89
+    assert np.array_equal(vd.numpy(), v2) and np.array_equal(wd.numpy(), w + v2)
+
+
+# ---- device-resident (torch) inputs: zero-copy path -------------------------------------------------
+def test_torch_device_tensors(eng):
+    torch = pytest.importorskip('torch')
+    g = scaled(99, 64, 5000)
+    gt = torch.from_numpy(g).cuda()
+    assert close(eng.no_defense(gt).cpu().numpy(), np.mean(g, axis=0))
+    assert close(eng.trimmed_mean(gt, 64, 12).cpu().numpy(), ideal.trimmed_mean(g, 12))
+    idx = eng.krum(gt, 64, 15, return_index=True)
+    assert idx == ideal.krum_index(ideal.distance_matrix(g), 64, 15)
+    assert torch.equal(eng.krum(gt, 64, 15), gt[idx])
+    out, sel = eng.bulyan(gt, 64, 15, return_selection=True)
+    assert sel.cpu().tolist() == ideal.bulyan_selection(ideal.distance_matrix(g), 64, 15)
+    assert close(out.cpu().numpy(), ideal.trimmed_mean(g[sel.cpu().numpy()], 30))
+    # a strided view: leading dimension != width
+    wide = torch.from_numpy(scaled(98, 32, 600)).cuda()
+    view = wide[:, 100:357]
+    assert close(eng.trimmed_mean(view, 32, 6).cpu().numpy(), ideal.trimmed_mean(view.cpu().numpy(), 6))
+    drift, mean, std = eng.drift_attack(gt[:15].clone(), 1.5, write_back=False)
+    assert close(drift.cpu().numpy(), faithful.drift_vector(g[:15].copy(), 1.5))
+
+
+# ---- full BASELINE sizes: size-independent properties -----------------------------------------------
+def test_config3_trimmed_mean_properties(eng):
+    """N=1000, D=1e6, trim 20%: spot-check columns against the oracle, plus invariances of the rule."""
+    torch = pytest.importorskip('torch')
+    n, d, c = 1000, 1_000_000, 200
+    gen = torch.Generator(device='cuda').manual_seed(1236)
+    g = torch.randn((n, d), generator=gen, device='cuda', dtype=torch.float32)
+    out = eng.trimmed_mean(g, n, c)
+    cols = np.random.default_rng(0).choice(d, 256, replace=False)
+    sub = g[:, torch.from_numpy(cols).cuda()].cpu().numpy()
+    assert close(out.cpu().numpy()[cols], ideal.trimmed_mean(sub, c))
+    # permuting the clients cannot change a continuous-data result beyond summation order
+    perm = torch.randperm(n, device='cuda', generator=gen)
+    gp = g[perm].contiguous()
+    out_p = eng.trimmed_mean(gp, n, c)
+    differs = torch.nonzero(~torch.isclose(out, out_p, rtol=1e-5, atol=1e-5)).flatten()
+    # ... except where |x - med| ties exactly across the median at the window edge: there the reference's
+    # stable sort makes the row order matter (about 2^-23 per column for continuous data).  Every such
+    # column must agree with the oracle in BOTH row orders.
+    assert differs.numel() <= 8, differs.numel()
+    if differs.numel():
+        a, b = g[:, differs].cpu().numpy(), gp[:, differs].cpu().numpy()
+        assert close(out[differs].cpu().numpy(), faithful.trimmed_mean(a, n, c))
+        assert close(out_p[differs].cpu().numpy(), faithful.trimmed_mean(b, n, c))
+    # the result lies between the kept window's extremes, hence inside the column's range
+    assert torch.all(out <= g.max(dim=0).values) and torch.all(out >= g.min(dim=0).values)
+    # translation equivariance on exactly representable shifts
+    out_s = eng.trimmed_mean(g + 4.0, n, c)
+    assert torch.allclose(out_s, out + 4.0, rtol=1e-5, atol=2e-5)
+
+
+def test_config2_krum_full_size_linearity(eng):
+    torch = pytest.importorskip('torch')
+    n, d, f = 100, 79510, 24
+    g = torch.from_numpy(scaled(1235, n, d)).cuda()
+    idx = eng.krum(g, n, f, return_index=True)
+    # distances are homogeneous of degree 1: scaling all gradients by 2 cannot change the winner
+    assert eng.krum(g * 2.0, n, f, return_index=True) == idx
+    # and a common offset cancels in every difference
+    assert eng.krum(g + 0.25, n, f, return_index=True) == idx

@@ -1,0 +1,139 @@
+"""The N>1 orchestration (attacking_federate_learning_amd.sharded) on CPU: world_size 2 over gloo.
+
+The per-rank kernels are replaced by a numpy stand-in built on the oracle (TEST ONLY: the package itself has
+no CPU implementation); what is under test is the sharding plan, the exchange step and the replicated
+selection -- sharded results must equal the unsharded oracle's.
+"""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from oracle import faithful, ideal
+
+
+class OracleKernels:
+    """numpy stand-in for HipKernels (same method names); tensors are CPU torch tensors."""
+
+    def gram(self, g_local):
+        g = g_local.numpy().astype(np.float64)
+        return torch.from_numpy(g @ g.T)
+
+    def distances_from_gram(self, gram):
+        c = gram.numpy()
+        sq = np.diag(c)
+        d2 = np.maximum(sq[:, None] + sq[None, :] - 2 * c, 0.0)
+        d2 = np.minimum(d2, d2.T)
+        d = np.sqrt(d2).astype(np.float32)
+        np.fill_diagonal(d, np.inf)
+        return d
+
+    def krum_select(self, d, users_count, corrupted_count):
+        return faithful.krum_pick(d, faithful.visit_order(len(d)), users_count, corrupted_count)
+
+    def bulyan_select(self, d, users_count, corrupted_count):
+        return ideal.bulyan_selection(d, users_count, corrupted_count)
+
+    def trimmed_mean(self, g_local, corrupted_count, row_index=None):
+        g = g_local.numpy()
+        if row_index is not None:
+            g = g[np.asarray(row_index)]
+        return torch.from_numpy(faithful.trimmed_mean(g, len(g), corrupted_count))
+
+    def no_defense(self, g_local):
+        return torch.from_numpy(np.mean(g_local.numpy(), axis=0))
+
+    def drift(self, rows_local, num_std, write_back=False):
+        rows = rows_local.numpy()
+        mean, std = faithful.attack_statistics(rows)
+        vec = mean - np.float32(num_std) * std
+        if write_back:
+            rows_local[:] = torch.from_numpy(vec)
+        return torch.from_numpy(vec), torch.from_numpy(mean), torch.from_numpy(std)
+
+    def row(self, g_local, index):
+        return g_local[index].clone()
+
+
+def make_matrix(n, d, f, seed=5):
+    rng = np.random.default_rng(seed)
+    g = rng.standard_normal((n, d)).astype(np.float32)
+    g *= (1.0 + 0.5 * rng.permutation(n) / n).astype(np.float32)[:, None]
+    return g
+
+
+def worker(rank, world, port, n, d, f, results):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        from attacking_federate_learning_amd.sharded import ShardedAggregator
+        agg = ShardedAggregator(OracleKernels())
+        g = make_matrix(n, d, f)
+        # start client-sharded (uneven on purpose), convert with the exchange step
+        rows_per_rank = [n // world + (1 if r < n % world else 0) for r in range(world)]
+        start = sum(rows_per_rank[:rank])
+        mine = torch.from_numpy(g[start:start + rows_per_rank[rank]].copy())
+        g_local = agg.reshard_clients_to_columns(mine, rows_per_rank)
+        lo, hi = agg.column_slices(d)[rank]
+        assert np.array_equal(g_local.numpy(), g[:, lo:hi])
+        out = {}
+        # attack first (in place on the local slice), then the defences on the attacked matrix
+        drift, _, _ = agg.drift_attack(g_local, f, 1.5, write_back=True, gather=True)
+        out['drift'] = drift.numpy()
+        out['attacked_slice'] = g_local.numpy().copy()
+        out['krum_index'] = agg.krum(g_local, n, f, return_index=True)
+        out['krum'] = agg.krum(g_local, n, f, gather=True).numpy()
+        out['tm'] = agg.trimmed_mean(g_local, n, f, gather=True).numpy()
+        out['nodef'] = agg.no_defense(g_local, gather=True).numpy()
+        b, sel = agg.bulyan(g_local, n, f, gather=True, return_selection=True)
+        out['bulyan'], out['selection'] = b.numpy(), np.asarray(sel)
+        results[rank] = out
+    finally:
+        dist.destroy_process_group()
+
+
+def free_port():
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        return s.getsockname()[1]
+
+
+@pytest.mark.parametrize('n,d,f', [(23, 157, 5), (12, 64, 2)])
+def test_two_ranks_equal_the_unsharded_oracle(n, d, f):
+    world = 2
+    with mp.Manager() as manager:
+        results = manager.dict()
+        mp.spawn(worker, args=(world, free_port(), n, d, f, results), nprocs=world, join=True)
+        results = dict(results)
+    g = make_matrix(n, d, f)
+    g[:f] = faithful.drift_vector(g[:f].copy(), 1.5)
+    want_bulyan, want_sel = faithful.bulyan(g, n, f, return_selection=True)
+    for rank in range(world):
+        r = results[rank]
+        assert np.allclose(r['drift'], g[0], rtol=1e-6, atol=1e-6)
+        assert r['krum_index'] == faithful.krum(g, n, f, return_index=True)
+        assert np.array_equal(r['krum'], g[r['krum_index']])
+        assert np.array_equal(r['tm'], faithful.trimmed_mean(g, n, f))
+        assert np.array_equal(r['nodef'], faithful.no_defense(g, n, f))
+        assert r['selection'].tolist() == want_sel
+        assert np.array_equal(r['bulyan'], want_bulyan)
+
+
+def test_column_slices_cover_everything():
+    from attacking_federate_learning_amd.sharded import ShardedAggregator
+
+    class Fake(ShardedAggregator):
+        def __init__(self, world):
+            self.world, self.rank = world, 0
+
+    for world in (1, 2, 3, 8):
+        for d in (1, 7, 8, 79510):
+            b = Fake(world).column_slices(d)
+            assert b[0][0] == 0 and b[-1][1] == d
+            assert all(b[i][1] == b[i + 1][0] for i in range(world - 1))
+            sizes = [hi - lo for lo, hi in b]
+            assert max(sizes) - min(sizes) <= 1
