@@ -1,0 +1,407 @@
+#!/usr/bin/env python3
+"""Contract bench: `python bench.py --gpus N --steps K --warmup W` -> ONE JSON line on rank 0.
+
+Metric (BASELINE.json): aggregation rounds/sec at N clients x D params on 1/2/4/8 MI355X.
+
+A "step" is one aggregation round of the hot path on device-resident synthetic gradients.  The default
+workload is BASELINE.json configs[3] -- Bulyan, N=4000 clients x D=10,000,000 params, f=960 -- the smallest
+of the two configurations the metric's "1/2/4/8 GPUs" are quoted on, and one that fits a single 288 GB
+MI355X whole (160 GB), so the same total problem is timed at every GPU count (`"scaling": "strong"`).
+With `--gpus N` the D columns are sharded N ways (one process per GPU, torch.distributed/RCCL): every rank
+runs the MFMA Gram kernel on its column slice, ONE all-reduce of the N x N fp64 Gram is the path's only
+exchange step, the selection loop runs replicated, the median-window mean runs on the local columns and the
+D-vector is all-gathered (attacking_federate_learning_amd/sharded.py; DESIGN.md section "Multi-GPU").
+
+Other workloads (`--workload`): c2 (Krum N=100, D=79,510 and 21,840), c3 (trimmed_mean N=1000, D=1e6,
+trim 200), c5s (attack + Krum + Bulyan, N=10000, one D-slice of 8's worth), attack.  At --gpus 1 the c2/c3
+numbers ride along in the JSON line under "other_workloads" (they take < 1 s).
+
+Added objects: "roofline" for the dominant kernel (live HIP-event timing around every launch of that kernel on
+the stream it is launched on, via the library's byz_timing_* entry points) and "cpu_baseline" (the numpy
+oracle -- a port of the reference's defences.py -- timed on this box's host cores on a bounded sample).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+PEAK_HBM = 8.0e12        # B/s, spec (MI355X_MICROARCH.md chip table; 6.29e12 measured copy)
+PEAK_MFMA_F32 = 157.3e12  # flop/s, dense fp32-input MFMA (same table)
+MAL_PROP = 0.24           # reference main.py:106
+
+
+def parse_args():
+    p = argparse.ArgumentParser()
+    p.add_argument('--gpus', type=int, default=1)
+    p.add_argument('--steps', type=int, default=3)
+    p.add_argument('--warmup', type=int, default=1)
+    p.add_argument('--workload', default='c4', choices=['c4', 'c3', 'c2', 'c5s', 'attack'])
+    p.add_argument('--clients', type=int, default=None, help='override N')
+    p.add_argument('--params', type=int, default=None, help='override total D')
+    p.add_argument('--no-cpu-baseline', action='store_true')
+    p.add_argument('--no-extras', action='store_true')
+    p.add_argument('--cpu-seconds', type=float, default=20.0, help='budget of the cpu_baseline leg')
+    return p.parse_args()
+
+
+# ---- synthetic inputs -----------------------------------------------------------------------------
+def make_matrix(torch, n, d, seed, device):
+    """'scaled' family of SURVEY.md 8(d): G[i,:] = s_i * N(0,1), s_i = 1 + 0.5*pi(i)/N: well-separated Krum
+    scores.  Generated on the device in row blocks (no second copy of a 160 GB matrix)."""
+    gen = torch.Generator(device=device).manual_seed(seed)
+    g = torch.empty((n, d), dtype=torch.float32, device=device)
+    perm = torch.from_numpy(np.random.default_rng(seed).permutation(n)).to(device)
+    scale = (1.0 + 0.5 * perm.to(torch.float32) / n)
+    rows_per = max(1, (1 << 28) // max(d, 1))
+    for r in range(0, n, rows_per):
+        blk = g[r:r + rows_per]
+        blk.normal_(generator=gen)
+        blk.mul_(scale[r:r + rows_per, None])
+    return g
+
+
+def column_bounds(d_total, world):
+    base, extra = divmod(d_total, world)
+    out, start = [], 0
+    for r in range(world):
+        stop = start + base + (1 if r < extra else 0)
+        out.append((start, stop))
+        start = stop
+    return out
+
+
+# ---- workloads ------------------------------------------------------------------------------------
+class Workload:
+    name = ''
+    defence = ''
+
+    def describe(self):
+        raise NotImplementedError
+
+
+class BulyanSharded(Workload):
+    """configs[3] (and the Bulyan half of configs[4]): column-sharded Bulyan through ShardedAggregator."""
+
+    def __init__(self, torch, agg, eng, n, d_total, device, seed, with_attack=False):
+        self.torch, self.agg, self.eng = torch, agg, eng
+        self.n, self.d_total = n, d_total
+        self.f = int(n * MAL_PROP)
+        lo, hi = column_bounds(d_total, agg.world)[agg.rank]
+        self.d_local = hi - lo
+        self.g = make_matrix(torch, n, self.d_local, seed + 17 * agg.rank, device)
+        self.with_attack = with_attack
+        self.name = 'c5s' if with_attack else 'c4'
+        self.defence = 'attack+Krum+Bulyan' if with_attack else 'Bulyan'
+        self.last = None
+
+    def step(self):
+        if self.with_attack:
+            # rows 0..m-1 are the malicious clients (reference main.py:28); per column, no exchange
+            self.agg.drift_attack(self.g, self.f, 1.5, write_back=True)
+            dist_m = self.agg.global_distances(self.g)
+            idx = self.agg.kernels.krum_select(dist_m, self.n, self.f)
+            sel = np.asarray(self.agg.kernels.bulyan_select(dist_m, self.n, self.f), dtype=np.int32)
+            out = self.agg.kernels.trimmed_mean(self.g, 2 * self.f, row_index=sel)
+            self.last = (self.agg._maybe_gather(out, True), sel, idx)
+        else:
+            out, sel = self.agg.bulyan(self.g, self.n, self.f, gather=True, return_selection=True)
+            self.last = (out, sel)
+
+    def dominant(self):
+        # the Gram: N^2 * D_local flops per launch (half Gram, 2 flop per MAC) -- SURVEY.md 8(d)
+        return {'kernel': 'gram_tile', 'bound': 'mfma', 'work': float(self.n) ** 2 * self.d_local,
+                'peak': PEAK_MFMA_F32, 'unit': 'TFLOP/s', 'scale': 1e12}
+
+    def config(self):
+        return {'workload': '%s: %s N=%d D=%d f=%d theta=%d (BASELINE configs[%d]), columns sharded %d-way'
+                            % (self.name, self.defence, self.n, self.d_total, self.f, self.n - 2 * self.f,
+                               4 if self.with_attack else 3, self.agg.world),
+                'clients': self.n, 'params': self.d_total, 'corrupted': self.f,
+                'params_per_gpu': self.d_local, 'input_family': 'scaled'}
+
+
+class TrimmedMeanC3(Workload):
+    name, defence = 'c3', 'TrimmedMean'
+
+    def __init__(self, torch, eng, n, d, device, seed):
+        self.eng, self.n, self.d, self.c = eng, n, d, n // 5
+        self.g = make_matrix(torch, n, d, seed, device)
+
+    def step(self):
+        self.last = self.eng.trimmed_mean(self.g, self.n, self.c)
+
+    def dominant(self):
+        return {'kernel': 'trimmed_mean', 'bound': 'hbm', 'work': 4.0 * self.n * self.d + 4.0 * self.d,
+                'peak': PEAK_HBM, 'unit': 'GB/s', 'scale': 1e9}
+
+    def config(self):
+        return {'workload': 'c3: TrimmedMean N=%d D=%d trim=%d (BASELINE configs[2])' % (self.n, self.d, self.c),
+                'clients': self.n, 'params': self.d, 'corrupted': self.c}
+
+
+class KrumC2(Workload):
+    name, defence = 'c2', 'Krum'
+
+    def __init__(self, torch, eng, n, d, device, seed):
+        self.eng, self.n, self.d, self.f = eng, n, d, int(n * MAL_PROP)
+        self.g = make_matrix(torch, n, d, seed, device)
+
+    def step(self):
+        self.last = self.eng.krum(self.g, self.n, self.f)
+
+    def dominant(self):
+        return {'kernel': 'gram_tile', 'bound': 'hbm', 'work': 4.0 * self.n * self.d + 4.0 * self.n * self.n,
+                'peak': PEAK_HBM, 'unit': 'GB/s', 'scale': 1e9}
+
+    def config(self):
+        return {'workload': 'c2: Krum N=%d D=%d f=%d (BASELINE configs[1])' % (self.n, self.d, self.f),
+                'clients': self.n, 'params': self.d, 'corrupted': self.f}
+
+
+class AttackOnly(Workload):
+    name, defence = 'attack', 'DriftAttack'
+
+    def __init__(self, torch, eng, m, d, device, seed):
+        self.eng, self.m, self.d = eng, m, d
+        self.g = make_matrix(torch, m, d, seed, device)
+
+    def step(self):
+        self.last = self.eng.drift_attack(self.g, 1.5, write_back=False)
+
+    def dominant(self):
+        return {'kernel': 'column_stats', 'bound': 'hbm', 'work': 4.0 * self.m * self.d + 4.0 * self.d,
+                'peak': PEAK_HBM, 'unit': 'GB/s', 'scale': 1e9}
+
+    def config(self):
+        return {'workload': 'attack: A Little Is Enough over m=%d malicious rows, D=%d' % (self.m, self.d),
+                'clients': self.m, 'params': self.d}
+
+
+# ---- timing ---------------------------------------------------------------------------------------
+def timed_steps(torch, dist, wl, eng, steps, warmup, world):
+    for _ in range(warmup):
+        wl.step()
+    eng.timing(True)      # HIP events around every kernel launch, on the launch stream
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        wl.step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    per_kernel = eng.timing_read()
+    eng.timing(False)
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device='cuda')
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    return elapsed, per_kernel
+
+
+def roofline_of(wl, per_kernel, traffic_table):
+    dom = wl.dominant()
+    k = per_kernel.get(dom['kernel'])
+    if not k:
+        return None
+    avg_s = k['total_ms'] / k['launches'] / 1e3
+    achieved = dom['work'] / avg_s
+    traffic = None
+    if traffic_table:
+        rec = traffic_table.get('%s/%s' % (wl.name, dom['kernel']))
+        if rec:
+            traffic = rec.get('hbm_bytes_per_launch')
+    return {'kernel': dom['kernel'], 'bound': dom['bound'], 'achieved': achieved / dom['scale'],
+            'peak': dom['peak'] / dom['scale'], 'unit': dom['unit'], 'frac': achieved / dom['peak'],
+            'traffic': traffic, 'avg_launch_ms': avg_s * 1e3, 'launches': k['launches'],
+            'algorithmic_work_per_launch': dom['work']}
+
+
+def kernel_table(per_kernel, steps):
+    return {name: {'ms_per_step': round(v['total_ms'] / steps, 4), 'launches_per_step': v['launches'] / steps}
+            for name, v in per_kernel.items()}
+
+
+def load_traffic_table():
+    """HBM bytes per launch from the committed rocprofv3 --pmc passes (profiles/*traffic*.json), doubled on the
+    read side as MI355X_MICROARCH.md section HBM prescribes for gfx950.  None when no pass has been recorded."""
+    path = os.path.join(ROOT, 'profiles', 'hbm_traffic.json')
+    try:
+        with open(path) as fh:
+            return json.load(fh)
+    except (OSError, ValueError):
+        return None
+
+
+# ---- CPU baseline (oracle = numpy port of the reference; checker/baseline only, never the product) --------
+def cpu_baseline(wl, budget_s):
+    from oracle import faithful
+    try:
+        from threadpoolctl import threadpool_limits
+    except ImportError:
+        threadpool_limits = None
+    rng = np.random.default_rng(5)
+    t_budget = max(budget_s, 3.0)
+
+    def run():
+        if isinstance(wl, BulyanSharded):
+            n, d, f = wl.n, wl.d_total, wl.f
+            theta = n - 2 * f
+            # (i) distance pairs at the true D (defences.py:20): sqrt(sdot) of the fp32 difference
+            rows = [rng.standard_normal(d).astype(np.float32) for _ in range(4)]
+            t0, pairs = time.perf_counter(), 0
+            while time.perf_counter() - t0 < 0.35 * t_budget:
+                for i in range(4):
+                    for j in range(i):
+                        np.linalg.norm(rows[i] - rows[j])
+                        pairs += 1
+            t_pair = (time.perf_counter() - t0) / pairs
+            # (ii) one Krum pick over n live rows (defences.py:32-37): n sorts of n-1 + sequential sums
+            pts = rng.standard_normal((n, 8)).astype(np.float32)
+            dist = np.sqrt(((pts[:, None, :] - pts[None, :, :]) ** 2).sum(-1)).astype(np.float32)
+            np.fill_diagonal(dist, np.inf)
+            t0 = time.perf_counter()
+            faithful.krum_pick(dist, faithful.visit_order(n), n, f)
+            t_pick = time.perf_counter() - t0
+            # (iii) trimmed_mean per column over theta rows (defences.py:48-51)
+            sample_cols = 400
+            sub = rng.standard_normal((theta, sample_cols)).astype(np.float32)
+            t0 = time.perf_counter()
+            faithful.trimmed_mean(sub, theta, 2 * f)
+            t_col = (time.perf_counter() - t0) / sample_cols
+            # picks shrink: pick t scores n - t rows of n - t - 1 distances
+            pick_total = sum(t_pick * ((n - t) / n) ** 2 for t in range(theta))
+            total = t_pair * n * (n - 1) / 2 + pick_total + t_col * d
+            extra = 0.0
+            if wl.with_attack:
+                extra = t_pick   # the Krum pass; the attack statistics are negligible beside the distances
+            return 1.0 / (total + extra), (
+                'extrapolated from: %d distance pairs at D=%d (%.1f ms/pair x N(N-1)/2), one Krum pick at N=%d '
+                '(%.2f s, x theta picks with the (n_t/N)^2 shrink), trimmed_mean over %d columns at theta=%d rows '
+                '(%.0f us/column x D)' % (pairs, d, t_pair * 1e3, n, t_pick, sample_cols, theta, t_col * 1e6))
+        if isinstance(wl, TrimmedMeanC3):
+            cols = 0
+            sub = rng.standard_normal((wl.n, 200)).astype(np.float32)
+            t0 = time.perf_counter()
+            while time.perf_counter() - t0 < t_budget:
+                faithful.trimmed_mean(sub, wl.n, wl.c)
+                cols += sub.shape[1]
+            t_col = (time.perf_counter() - t0) / cols
+            return 1.0 / (t_col * wl.d), 'extrapolated from %d columns at N=%d (%.0f us/column x D)' % (
+                cols, wl.n, t_col * 1e6)
+        if isinstance(wl, KrumC2):
+            g = rng.standard_normal((wl.n, wl.d)).astype(np.float32)
+            t0, rounds = time.perf_counter(), 0
+            while time.perf_counter() - t0 < t_budget or rounds == 0:
+                faithful.krum(g, wl.n, wl.f)
+                rounds += 1
+            return rounds / (time.perf_counter() - t0), 'full rounds: %d in the budget' % rounds
+        if isinstance(wl, AttackOnly):
+            m = min(wl.m, 64)
+            g = rng.standard_normal((m, min(wl.d, 1 << 20))).astype(np.float32)
+            t0, rounds = time.perf_counter(), 0
+            while time.perf_counter() - t0 < 0.5 * t_budget or rounds == 0:
+                faithful.drift_vector(g, 1.5)
+                rounds += 1
+            per = (time.perf_counter() - t0) / rounds
+            per *= (wl.m / m) * (wl.d / g.shape[1])
+            return 1.0 / per, 'extrapolated linearly from m=%d, D=%d' % (m, g.shape[1])
+        return None, 'n/a'
+
+    if threadpool_limits is not None:
+        with threadpool_limits(limits=1):
+            value, sample = run()
+    else:
+        value, sample = run()
+    return {'value': value, 'unit': 'rounds/s', 'cores': 1, 'kind': 'port', 'sample': sample,
+            'host_cores_available': os.cpu_count()}
+
+
+# ---- main -----------------------------------------------------------------------------------------
+def main():
+    args = parse_args()
+    import torch
+    import torch.distributed as dist
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if world != args.gpus and world > 1:
+        raise SystemExit('--gpus %d but WORLD_SIZE=%d' % (args.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs an MI355X: the aggregation path has no CPU implementation')
+    torch.cuda.set_device(local_rank)
+    device = torch.device('cuda', local_rank)
+    os.environ.setdefault('BYZ_DEVICE', str(local_rank))
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', device_id=device)
+
+    from attacking_federate_learning_amd.engine import Engine
+    from attacking_federate_learning_amd.sharded import HipKernels, ShardedAggregator
+    eng = Engine(local_rank)
+    agg = ShardedAggregator(HipKernels(eng))
+    traffic = load_traffic_table()
+
+    if args.workload in ('c4', 'c5s'):
+        n = args.clients or (4000 if args.workload == 'c4' else 10000)
+        # c5s: the slice of configs[4] one GPU of eight would hold (25M/8 columns) -- 125 GB
+        d_total = args.params or (10_000_000 if args.workload == 'c4' else 3_125_000 * world)
+        wl = BulyanSharded(torch, agg, eng, n, d_total, device, 1237, with_attack=args.workload == 'c5s')
+    elif args.workload == 'c3':
+        wl = TrimmedMeanC3(torch, eng, args.clients or 1000, args.params or 1_000_000, device, 1236)
+    elif args.workload == 'c2':
+        wl = KrumC2(torch, eng, args.clients or 100, args.params or 79510, device, 1235)
+    else:
+        wl = AttackOnly(torch, eng, args.clients or 2400, args.params or 4_000_000, device, 1238)
+
+    elapsed, per_kernel = timed_steps(torch, dist, wl, eng, args.steps, args.warmup, world)
+    ms_per_step = elapsed / args.steps * 1e3
+    line = {
+        'metric': 'aggregation rounds/sec at N clients x D params (%s)' % wl.defence,
+        'value': args.steps / elapsed, 'unit': 'rounds/s', 'n_gpus': args.gpus, 'steps': args.steps,
+        'warmup': args.warmup, 'ms_per_step': ms_per_step, 'higher_is_better': True,
+        'scaling': 'strong', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+        'config': wl.config(),
+        'roofline': roofline_of(wl, per_kernel, traffic),
+        'kernels': kernel_table(per_kernel, args.steps),
+    }
+
+    if rank == 0 and world == 1:
+        if not args.no_cpu_baseline:
+            line['cpu_baseline'] = cpu_baseline(wl, args.cpu_seconds)
+        if not args.no_extras and args.workload == 'c4':
+            del wl.g
+            wl.g = None
+            torch.cuda.empty_cache()
+            extras = {}
+            for make in (lambda: TrimmedMeanC3(torch, eng, 1000, 1_000_000, device, 1236),
+                         lambda: KrumC2(torch, eng, 100, 79510, device, 1235),
+                         lambda: KrumC2(torch, eng, 100, 21840, device, 1234),
+                         lambda: AttackOnly(torch, eng, 2400, 1_000_000, device, 1238)):
+                w2 = make()
+                k2 = 20
+                e2, pk2 = timed_steps(torch, dist, w2, eng, k2, 3, 1)
+                key = '%s_D%d' % (w2.name, w2.d)
+                extras[key] = {'config': w2.config(), 'value': k2 / e2, 'unit': 'rounds/s',
+                               'ms_per_step': e2 / k2 * 1e3, 'roofline': roofline_of(w2, pk2, traffic),
+                               'kernels': kernel_table(pk2, k2)}
+                del w2
+                torch.cuda.empty_cache()
+            line['other_workloads'] = extras
+    if rank == 0:
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()
