@@ -319,9 +319,15 @@ def test_config3_trimmed_mean_properties(eng):
         assert close(out_p[differs].cpu().numpy(), faithful.trimmed_mean(b, n, c))
     # the result lies between the kept window's extremes, hence inside the column's range
     assert torch.all(out <= g.max(dim=0).values) and torch.all(out >= g.min(dim=0).values)
-    # translation equivariance on exactly representable shifts
-    out_s = eng.trimmed_mean(g + 4.0, n, c)
-    assert torch.allclose(out_s, out + 4.0, rtol=1e-5, atol=2e-5)
+    # translation equivariance: g + 4 rounds every value to a multiple of 2^-21, which may flip a near-tie
+    # at a window edge (a 2a/k jump); such columns are rare and each must still agree with the oracle
+    gs = g + 4.0
+    out_s = eng.trimmed_mean(gs, n, c)
+    moved = torch.nonzero(~torch.isclose(out_s, out + 4.0, rtol=1e-5, atol=2e-5)).flatten()
+    assert moved.numel() <= d // 1000, moved.numel()
+    if moved.numel():
+        pick = moved[:64]
+        assert close(out_s[pick].cpu().numpy(), ideal.trimmed_mean(gs[:, pick].cpu().numpy(), c))
 
 
 def test_config2_krum_full_size_linearity(eng):
