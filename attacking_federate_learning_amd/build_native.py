@@ -17,11 +17,16 @@ BUILD = os.path.join(HERE, 'csrc', 'build')
 LIB = os.path.join(HERE, 'libbyzagg.so')
 ARCH = 'gfx950'
 
-SOURCES = ['api.hip', 'column_stats.hip', 'gram.hip', 'select.hip', 'trimmed_mean.hip']
+SOURCES = ['api.hip', 'column_stats.hip', 'gram.hip', 'select.hip', 'trimmed_mean.hip', 'median_window.hip']
 # The sorting network only orders finite values and +/-inf padding; NaN inputs are unspecified in the
 # reference as well.  Without this flag every v_min/v_max is preceded by a
 # canonicalising v_max (sNaN quieting), +30% VALU work in the hot kernel.
-EXTRA_FLAGS = {'trimmed_mean.hip': ['-fno-honor-nans']}
+EXTRA_FLAGS = {'trimmed_mean.hip': ['-fno-honor-nans'],
+               # median_window.hip keeps its tile in registers: every loop over the register array must be
+               # fully unrolled (a dynamic index would demote the array to scratch), and the staging loop of
+               # the larger instantiations exceeds LLVM's default budget for `#pragma unroll`.  NaN semantics
+               # stay on in this file: the padding rows are NaNs.
+               'median_window.hip': ['-mllvm', '-pragma-unroll-threshold=1000000']}
 COMMON_FLAGS = ['--offload-arch=' + ARCH, '-O3', '-std=c++17', '-fPIC', '-Wall', '-Wno-unused-function',
                 '-Wno-nan-infinity-disabled']
 
@@ -41,7 +46,7 @@ def _stale(target, deps):
 
 
 def _headers():
-    return [os.path.join(CSRC, 'common.hpp'), os.path.join(HERE, '..', 'include', 'byzagg.h'), __file__]
+    return [os.path.join(CSRC, 'common.hpp'), os.path.join(CSRC, 'lane_exchange.hpp'), os.path.join(HERE, '..', 'include', 'byzagg.h'), __file__]
 
 
 def _compile(src, force):

@@ -29,7 +29,7 @@
 // array per workgroup.  It is the fallback for Bulyan's second stage at large theta.
 #include "common.hpp"
 
-#include <type_traits>
+#include "lane_exchange.hpp"
 
 namespace byz {
 namespace {
@@ -37,116 +37,9 @@ namespace {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
 
-constexpr int kTileCols = 32;
-constexpr int kStride = 36;        // floats per LDS row
-constexpr int kFastThreads = 512;  // 8 waves x 4 columns
-constexpr int kFastMaxRows = 1024;
-constexpr int kSkewRows = 64;
 constexpr int kGeneralMaxRows = 8192;
 
-// ---- cross-lane exchange ------------------------------------------------------------------------
-// value held by lane (lane ^ MASK); MASK is a compile-time constant after unrolling.
-__device__ __forceinline__ float lane_xor(float v, int mask, int lane) {
-    const int b = __float_as_int(v);
-    int r;
-    switch (mask) {
-        case 1: r = __builtin_amdgcn_update_dpp(0, b, 0xB1, 0xF, 0xF, true); break;   // quad_perm [1,0,3,2]
-        case 2: r = __builtin_amdgcn_update_dpp(0, b, 0x4E, 0xF, 0xF, true); break;   // quad_perm [2,3,0,1]
-        case 3: r = __builtin_amdgcn_update_dpp(0, b, 0x1B, 0xF, 0xF, true); break;   // quad_perm [3,2,1,0]
-        case 7: r = __builtin_amdgcn_update_dpp(0, b, 0x141, 0xF, 0xF, true); break;  // row_half_mirror
-        case 8: r = __builtin_amdgcn_update_dpp(0, b, 0x128, 0xF, 0xF, true); break;  // row_ror:8
-        case 15: r = __builtin_amdgcn_update_dpp(0, b, 0x140, 0xF, 0xF, true); break; // row_mirror
-        case 4: r = __builtin_amdgcn_ds_swizzle(b, 0x101F); break;                     // xor 4
-        case 16: r = __builtin_amdgcn_ds_swizzle(b, 0x401F); break;                    // xor 16
-        case 31: r = __builtin_amdgcn_ds_swizzle(b, 0x7C1F); break;                    // xor 31
-        default: r = __builtin_amdgcn_ds_bpermute((lane ^ mask) << 2, b); break;       // 32, 63
-    }
-    return __int_as_float(r);
-}
-
-__device__ __forceinline__ void cmp_swap(float& lo, float& hi) {
-    const float a = lo, b = hi;
-    lo = __builtin_fminf(a, b);
-    hi = __builtin_fmaxf(a, b);
-}
-
-// compile-time loops over powers of two (a `k <<= 1` loop is not reliably unrolled, and a register
-// array indexed by a runtime value would be demoted to scratch)
-template <int K, int KMAX, typename F>
-__device__ __forceinline__ void for_pow2_up(F&& f) {
-    if constexpr (K <= KMAX) {
-        f(std::integral_constant<int, K>{});
-        for_pow2_up<K * 2, KMAX>(f);
-    }
-}
-template <int J, typename F>
-__device__ __forceinline__ void for_pow2_down(F&& f) {
-    if constexpr (J > 0) {
-        f(std::integral_constant<int, J>{});
-        for_pow2_down<J / 2>(f);
-    }
-}
-
-// Sorts the 64*R values {x[r] of lane l} ascending in index i = r + R*l, for C independent columns.
-template <int R, int C>
-__device__ __forceinline__ void wave_bitonic_sort(float (&x)[C][R], int lane) {
-    const float pinf = __builtin_inff();
-    for_pow2_up<2, 64 * R>([&](auto kc) {
-        constexpr int k = decltype(kc)::value;
-        // flip: i <-> i ^ (k-1); the element whose bit (k/2) is clear keeps the minimum
-        if constexpr (k <= R) {
-#pragma unroll
-            for (int r = 0; r < R; ++r) {
-                const int p = r ^ (k - 1);
-                if (p > r) {
-#pragma unroll
-                    for (int c = 0; c < C; ++c) cmp_swap(x[c][r], x[c][p]);
-                }
-            }
-        } else {
-            constexpr int lane_mask = k / R - 1;
-            constexpr int lane_bit = k / (2 * R);
-            const float sel = (lane & lane_bit) ? pinf : -pinf;  // upper partner keeps the maximum
-#pragma unroll
-            for (int r = 0; r < (R + 1) / 2; ++r) {
-                const int p = R - 1 - r;
-#pragma unroll
-                for (int c = 0; c < C; ++c) {
-                    const float from_p = lane_xor(x[c][p], lane_mask, lane);
-                    if (p != r) {
-                        const float from_r = lane_xor(x[c][r], lane_mask, lane);
-                        x[c][p] = __builtin_amdgcn_fmed3f(x[c][p], from_r, sel);
-                    }
-                    x[c][r] = __builtin_amdgcn_fmed3f(x[c][r], from_p, sel);
-                }
-            }
-        }
-        // half-cleaners: i <-> i ^ j, j = k/4 ... 1
-        for_pow2_down<k / 4>([&](auto jc) {
-            constexpr int j = decltype(jc)::value;
-            if constexpr (j < R) {
-#pragma unroll
-                for (int r = 0; r < R; ++r) {
-                    if ((r & j) == 0) {
-#pragma unroll
-                        for (int c = 0; c < C; ++c) cmp_swap(x[c][r], x[c][r | j]);
-                    }
-                }
-            } else {
-                constexpr int s = j / R;
-                const float sel = (lane & s) ? pinf : -pinf;
-#pragma unroll
-                for (int r = 0; r < R; ++r) {
-#pragma unroll
-                    for (int c = 0; c < C; ++c) {
-                        const float other = lane_xor(x[c][r], s, lane);
-                        x[c][r] = __builtin_amdgcn_fmed3f(x[c][r], other, sel);
-                    }
-                }
-            }
-        });
-    });
-}
+using namespace lanes;
 
 // ---- post-processing on a sorted quad of columns -------------------------------------------------
 // `Sorted` exposes at(rank) -> float4 (the 4 columns' values at that rank).  One wave per call.
@@ -264,77 +157,6 @@ __device__ __forceinline__ void window_mean(const Sorted& sorted, const WindowAr
     }
 }
 
-// ---- register-resident kernel --------------------------------------------------------------------
-template <int R>
-struct SkewedTile {
-    const float* base;  // tile + 4 * quad
-    __device__ __forceinline__ static int row_of(int rank) { return R >= 4 ? rank + rank / R : rank; }
-    __device__ __forceinline__ f32x4 at(int rank) const {
-        return *reinterpret_cast<const f32x4*>(base + row_of(rank) * kStride);
-    }
-};
-
-template <int R>
-__global__ __launch_bounds__(kFastThreads) void trimmed_mean_regs_kernel(
-    const float* __restrict__ G, int n_rows, int64_t n_cols, int64_t ld, const int32_t* __restrict__ row_index,
-    int keep, float* __restrict__ out) {
-    extern __shared__ __attribute__((aligned(16))) float tile[];  // (n_rows + kSkewRows) x kStride
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int64_t n_tiles = (n_cols + kTileCols - 1) / kTileCols;
-    const float pinf = __builtin_inff();
-
-    for (int64_t t = blockIdx.x; t < n_tiles; t += gridDim.x) {
-        const int64_t c_base = t * kTileCols;
-        // ---- stage the tile: 8 lanes per 128-byte row segment, 64 rows per pass
-        {
-            const int q = (tid & 7) * 4;
-            const int64_t c = c_base + q;
-            for (int r = tid >> 3; r < n_rows; r += kFastThreads / 8) {
-                const int64_t src = row_index ? row_index[r] : r;
-                const float* p = G + src * ld + c;
-                f32x4 v = {0.0f, 0.0f, 0.0f, 0.0f};
-                if (c + 4 <= n_cols) {
-                    v = *reinterpret_cast<const f32x4u*>(p);
-                } else {
-                    if (c + 0 < n_cols) v.x = p[0];
-                    if (c + 1 < n_cols) v.y = p[1];
-                    if (c + 2 < n_cols) v.z = p[2];
-                }
-                *reinterpret_cast<f32x4*>(tile + r * kStride + q) = v;
-            }
-        }
-        __syncthreads();
-        // ---- each wave sorts its 4 columns in registers
-        float x[4][R];
-        float* my = tile + 4 * wave;
-#pragma unroll
-        for (int r = 0; r < R; ++r) {
-            const int row = lane + 64 * r;
-            f32x4 v = {pinf, pinf, pinf, pinf};
-            if (row < n_rows) v = *reinterpret_cast<const f32x4*>(my + row * kStride);
-            x[0][r] = v.x; x[1][r] = v.y; x[2][r] = v.z; x[3][r] = v.w;
-        }
-        wave_bitonic_sort<R, 4>(x, lane);
-        // every lane has consumed its rows before any lane overwrites them (one wave, program order)
-        __builtin_amdgcn_wave_barrier();
-#pragma unroll
-        for (int r = 0; r < R; ++r) {
-            const int rank = r + R * lane;
-            if (rank < n_rows) {
-                const f32x4 v = {x[0][r], x[1][r], x[2][r], x[3][r]};
-                *reinterpret_cast<f32x4*>(my + SkewedTile<R>::row_of(rank) * kStride) = v;
-            }
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        const SkewedTile<R> sorted{my};
-        const WindowArgs args{G, ld, row_index, n_rows, keep, c_base + 4 * wave, n_cols};
-        window_mean(sorted, args, lane, out);
-        __syncthreads();  // the tile is restaged by the next iteration
-    }
-}
-
 // ---- general kernel: LDS bitonic over [rank][4 columns] ------------------------------------------
 struct QuadArray {
     const f32x4* base;
@@ -415,37 +237,11 @@ int launch_lane_selftest(byz_ctx* ctx, int32_t* out, int32_t* n_patterns, hipStr
     return check_launch("lane_selftest_kernel");
 }
 
-int launch_trimmed_mean(byz_ctx* ctx, const float* G, int64_t n_rows, int64_t n_cols, int64_t ld,
-                        const int32_t* row_index, int64_t keep, float* out, hipStream_t stream) {
-    BYZ_REQUIRE(G && out && n_rows > 0 && n_cols > 0 && ld >= n_cols, "trimmed_mean: bad shape %lld x %lld ld %lld",
-                (long long)n_rows, (long long)n_cols, (long long)ld);
-    BYZ_REQUIRE(keep >= 0 && keep <= n_rows, "trimmed_mean: keep count %lld out of range", (long long)keep);
+int launch_trimmed_mean_sorted(byz_ctx* ctx, const float* G, int64_t n_rows, int64_t n_cols, int64_t ld,
+                               const int32_t* row_index, int64_t keep, float* out, hipStream_t stream) {
     if (n_rows > kGeneralMaxRows) {
         set_error("trimmed_mean supports at most %d rows, got %lld", kGeneralMaxRows, (long long)n_rows);
         return BYZ_E_UNSUPPORTED;
-    }
-    KernelTimer t(ctx, BYZ_K_TRIMMED_MEAN, stream);
-    if (n_rows <= kFastMaxRows) {
-        const int64_t n_tiles = ceil_div(n_cols, kTileCols);
-        int64_t grid = n_tiles < static_cast<int64_t>(ctx->num_cus) * 4 ? n_tiles : static_cast<int64_t>(ctx->num_cus) * 4;
-        const size_t lds = static_cast<size_t>(n_rows + kSkewRows) * kStride * sizeof(float);
-        const int r = static_cast<int>(next_pow2(ceil_div(n_rows, 64)));
-#define BYZ_TM(R)                                                                                            \
-    do {                                                                                                     \
-        BYZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&trimmed_mean_regs_kernel<R>),            \
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));    \
-        trimmed_mean_regs_kernel<R><<<static_cast<unsigned>(grid), kFastThreads, lds, stream>>>(            \
-            G, (int)n_rows, n_cols, ld, row_index, (int)keep, out);                                          \
-    } while (0)
-        switch (r) {
-            case 1: BYZ_TM(1); break;
-            case 2: BYZ_TM(2); break;
-            case 4: BYZ_TM(4); break;
-            case 8: BYZ_TM(8); break;
-            default: BYZ_TM(16); break;
-        }
-#undef BYZ_TM
-        return check_launch("trimmed_mean_regs_kernel");
     }
     const int64_t n_pad = next_pow2(n_rows);
     const int64_t n_quads = ceil_div(n_cols, 4);
