@@ -135,6 +135,7 @@ void byz_ctx_destroy(byz_ctx* ctx) {
     byz_timing_reset(ctx);
     ctx->gram_partials.release();
     ctx->gram.release();
+    ctx->tile_order.release();
     ctx->dist.release();
     ctx->colstat_partials.release();
     ctx->sorted_idx.release();

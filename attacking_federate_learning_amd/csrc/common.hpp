@@ -96,6 +96,9 @@ struct byz_ctx {
     // workspaces
     byz::Buffer gram_partials;   // split-K slabs of the Gram kernel
     byz::Buffer gram;            // n x n fp64 Gram
+    byz::Buffer tile_order;      // (ti, tj) of every lower-triangle tile, in XCD-friendly order
+    std::vector<int32_t> tile_order_host;
+    int64_t tile_order_T = -1;
     byz::Buffer dist;            // n x n fp32 distances (when the caller does not pass one)
     byz::Buffer colstat_partials;  // row-split partial column sums
     byz::Buffer sorted_idx;      // n x n uint16: column index at every ascending rank

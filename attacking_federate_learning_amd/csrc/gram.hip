@@ -43,29 +43,13 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
 
-__device__ __forceinline__ void tile_coords(int t, int& ti, int& tj) {
-    // t = ti*(ti+1)/2 + tj, 0 <= tj <= ti
-    int r = static_cast<int>((sqrtf(8.0f * static_cast<float>(t) + 1.0f) - 1.0f) * 0.5f);
-    while ((r + 1) * (r + 2) / 2 <= t) ++r;
-    while (r * (r + 1) / 2 > t) --r;
-    ti = r;
-    tj = t - r * (r + 1) / 2;
-}
-
-// 4 consecutive floats of one row, zero-filled outside [0, n_rows) x [k_lo, k_hi)
-__device__ __forceinline__ f32x4 load_row_segment(const float* __restrict__ G, int64_t ld, int64_t n_rows,
-                                                  int64_t row, int64_t k, int64_t k_hi) {
+// 4 consecutive floats starting at column k, zero-filled from k_hi on
+__device__ __forceinline__ f32x4 load_tail(const float* __restrict__ p, int64_t k, int64_t k_hi) {
     f32x4 v = {0.0f, 0.0f, 0.0f, 0.0f};
-    if (row < n_rows) {
-        const float* p = G + row * ld + k;
-        if (k + 4 <= k_hi) {
-            v = *reinterpret_cast<const f32x4u*>(p);
-        } else {
-            if (k + 0 < k_hi) v.x = p[0];
-            if (k + 1 < k_hi) v.y = p[1];
-            if (k + 2 < k_hi) v.z = p[2];
-        }
-    }
+    if (k + 0 < k_hi) v.x = p[0];
+    if (k + 1 < k_hi) v.y = p[1];
+    if (k + 2 < k_hi) v.z = p[2];
+    if (k + 3 < k_hi) v.w = p[3];
     return v;
 }
 
@@ -73,13 +57,33 @@ template <typename PartialT>
 __global__ __launch_bounds__(THREADS, 2) void gram_tile_kernel(const float* __restrict__ G, int64_t n_rows,
                                                                int64_t n_cols, int64_t ld,
                                                                int64_t stages_per_split,
-                                                               PartialT* __restrict__ partial, int n_tiles) {
+                                                               PartialT* __restrict__ partial, int n_tiles,
+                                                               const int2* __restrict__ tile_order, int per_xcd, int n_splits) {
     __shared__ __attribute__((aligned(16))) float lds[2 * 2 * TILE_FLOATS];  // [2 buffers][A | B][TM][LDS_STRIDE]
 
-    const int tile = blockIdx.x;
-    const int split = blockIdx.y;
-    int ti, tj;
-    tile_coords(tile, ti, tj);
+    // Workgroup -> (tile, K split).  Workgroups are dealt to the 8 XCDs round-robin (observed; only speed
+    // depends on it), each XCD with its own L2.  With many tiles, XCD x works through its own contiguous
+    // share of the tile list, split by split, and the list is ordered in 8 x 8 super-blocks of the tile
+    // triangle: the ~64 workgroups an XCD runs at a time then share 8 + 8 operand row blocks instead of
+    // streaming 128.
+    int split, t_list;
+    if (per_xcd > 0) {
+        const int xcd = blockIdx.x & 7;
+        const int seq = blockIdx.x >> 3;
+        // XCD x owns tiles [first, first + mine): shares differ by at most one tile
+        const int base = n_tiles >> 3, rem = n_tiles & 7;
+        const int mine = base + (xcd < rem ? 1 : 0);
+        const int first = xcd * base + (xcd < rem ? xcd : rem);
+        split = seq / mine;
+        if (split >= n_splits) return;
+        t_list = first + (seq - split * mine);
+    } else {  // few tiles: plain tile-fastest order, every XCD busy
+        split = blockIdx.x / n_tiles;
+        t_list = blockIdx.x - split * n_tiles;
+    }
+    const int2 tt = tile_order[t_list];
+    const int ti = tt.x, tj = tt.y;
+    const int tile = ti * (ti + 1) / 2 + tj;
     const bool diagonal = (ti == tj);
 
     const int tid = threadIdx.x;
@@ -91,20 +95,46 @@ __global__ __launch_bounds__(THREADS, 2) void gram_tile_kernel(const float* __re
     int64_t k_end = k_begin + stages_per_split * BK;
     if (k_end > n_cols) k_end = n_cols;
     const int n_stages = k_begin < k_end ? static_cast<int>((k_end - k_begin + BK - 1) / BK) : 0;
+    const int n_full = k_begin < k_end ? static_cast<int>((k_end - k_begin) / BK) : 0;   // stages without a ragged K tail
 
-    // staging assignment: 8 lanes cover one 128-byte row segment, 32 rows per pass, 4 passes per operand
+    // staging assignment: 8 lanes cover one 128-byte row segment, 32 rows per pass, 4 passes per operand.
+    // Rows past the matrix are clamped to the last row: the duplicates land in Gram entries nobody reads,
+    // and the main loop carries no per-load branch (a branch around a load makes hipcc drain vmcnt).
     const int ld_kq = (tid & 7) * 4;
     const int ld_row = tid >> 3;
-    const int64_t a_row0 = static_cast<int64_t>(ti) * TM;
-    const int64_t b_row0 = static_cast<int64_t>(tj) * TM;
+    const float* a_ptr[4];
+    const float* b_ptr[4];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        int64_t ra_ = static_cast<int64_t>(ti) * TM + ld_row + 32 * p;
+        int64_t rb_ = static_cast<int64_t>(tj) * TM + ld_row + 32 * p;
+        if (ra_ > n_rows - 1) ra_ = n_rows - 1;
+        if (rb_ > n_rows - 1) rb_ = n_rows - 1;
+        a_ptr[p] = G + ra_ * ld + ld_kq;
+        b_ptr[p] = G + rb_ * ld + ld_kq;
+    }
 
     f32x4 ra[4], rb[4];
-    auto fetch = [&](int stage) {
-        const int64_t k = k_begin + static_cast<int64_t>(stage) * BK + ld_kq;
+    // the main loop only ever issues unconditional 16-byte loads; the ragged K tail has its own code
+    auto fetch_full = [&](int stage) {
+        const int64_t k = k_begin + static_cast<int64_t>(stage) * BK;
 #pragma unroll
-        for (int p = 0; p < 4; ++p) {
-            ra[p] = load_row_segment(G, ld, n_rows, a_row0 + ld_row + 32 * p, k, k_end);
-            if (!diagonal) rb[p] = load_row_segment(G, ld, n_rows, b_row0 + ld_row + 32 * p, k, k_end);
+        for (int p = 0; p < 4; ++p) ra[p] = *reinterpret_cast<const f32x4u*>(a_ptr[p] + k);
+        if (!diagonal) {
+#pragma unroll
+            for (int p = 0; p < 4; ++p) rb[p] = *reinterpret_cast<const f32x4u*>(b_ptr[p] + k);
+        }
+    };
+    auto fetch_any = [&](int stage) {
+        if (stage < n_full) {
+            fetch_full(stage);
+        } else {  // the one ragged stage of the last split: zero-fill past k_end
+            const int64_t k = k_begin + static_cast<int64_t>(stage) * BK;
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                ra[p] = load_tail(a_ptr[p] + k, k + ld_kq, k_end);
+                if (!diagonal) rb[p] = load_tail(b_ptr[p] + k, k + ld_kq, k_end);
+            }
         }
     };
     auto stash = [&](int buf) {
@@ -135,13 +165,7 @@ __global__ __launch_bounds__(THREADS, 2) void gram_tile_kernel(const float* __re
     const int frag_k = (lane >> 5) * 4;
     constexpr int kFlushStages = kFlushK / BK;
 
-    if (n_stages > 0) {
-        fetch(0);
-        stash(0);
-    }
-    __syncthreads();
-    for (int s = 0; s < n_stages; ++s) {
-        if (s + 1 < n_stages) fetch(s + 1);
+    auto compute = [&](int s) {
         const float* A = lds + (s & 1) * 2 * TILE_FLOATS;
         const float* B = diagonal ? A : A + TILE_FLOATS;
 #pragma unroll
@@ -161,8 +185,8 @@ __global__ __launch_bounds__(THREADS, 2) void gram_tile_kernel(const float* __re
                     for (int n = 0; n < 2; ++n)
                         acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m][t], b[n][t], acc[m][n], 0, 0, 0);
         }
-        if (s + 1 < n_stages) stash((s + 1) & 1);
-        __syncthreads();
+    };
+    auto flush = [&](int s) {
         if constexpr (kWide) if ((s + 1) % kFlushStages == 0) {
 #pragma unroll
             for (int m = 0; m < 2; ++m)
@@ -174,6 +198,27 @@ __global__ __launch_bounds__(THREADS, 2) void gram_tile_kernel(const float* __re
                         acc[m][n][e] = 0.0f;
                     }
         }
+    };
+
+    if (n_stages > 0) {
+        fetch_any(0);
+        stash(0);
+    }
+    __syncthreads();
+    int s = 0;
+    for (; s + 1 < n_full; ++s) {   // steady state: the next stage is a full one
+        fetch_full(s + 1);
+        compute(s);
+        stash((s + 1) & 1);
+        __syncthreads();
+        flush(s);
+    }
+    for (; s < n_stages; ++s) {     // at most two stages: the last full one and the ragged tail
+        if (s + 1 < n_stages) fetch_any(s + 1);
+        compute(s);
+        if (s + 1 < n_stages) stash((s + 1) & 1);
+        __syncthreads();
+        flush(s);
     }
 
     PartialT* out = partial + (static_cast<int64_t>(split) * n_tiles + tile) * (TM * TM);
@@ -243,11 +288,31 @@ int launch_gram(byz_ctx* ctx, const float* G, int64_t n_rows, int64_t n_cols, in
         return BYZ_E_UNSUPPORTED;
     }
     const int64_t stages = ceil_div(n_cols, BK);
-    // split-K: aim at ~3 workgroups per CU in total, but keep at least 16 stages (512 columns) per slab so
-    // that slab traffic stays a small fraction of the matrix traffic
-    int64_t splits = ceil_div(static_cast<int64_t>(ctx->num_cus) * 3, n_tiles);
+    // split-K.  Two workgroups fit a CU (LDS), so the chip runs `slots` workgroups at a time; the grid is
+    // n_tiles * splits of them, all of equal length.  Pick the split count whose last round of workgroups
+    // is (nearly) full -- 528 tiles x 2 splits would leave the chip one third idle, 528 x 31 does not --
+    // while keeping at least `min_stages` K stages (512 columns) per slab so that slab traffic stays a small
+    // fraction of the matrix traffic.
+    const int64_t slots = static_cast<int64_t>(ctx->num_cus) * 2;
     const int64_t min_stages = env_int("BYZ_GRAM_MIN_STAGES", 16);
-    if (splits > ceil_div(stages, min_stages)) splits = ceil_div(stages, min_stages);
+    int64_t max_splits = stages / min_stages;
+    if (max_splits < 1) max_splits = 1;
+    if (max_splits > 4096) max_splits = 4096;
+    int64_t splits = 1;
+    {
+        double best = -1.0;
+        const int64_t want = ceil_div(slots * 3, n_tiles);   // at least ~3 rounds when K allows it
+        for (int64_t s = 1; s <= max_splits; ++s) {
+            const int64_t wgs = n_tiles * s;
+            const double eff = static_cast<double>(wgs) / static_cast<double>(ceil_div(wgs, slots) * slots);
+            // prefer fuller last rounds; among equals the fewer slabs; below `want` only if nothing else fits
+            const double score = eff - (s < want ? 0.05 : 0.0) - 1e-4 * static_cast<double>(s > want ? s - want : 0);
+            if (score > best) {
+                best = score;
+                splits = s;
+            }
+        }
+    }
     const int forced = env_int("BYZ_GRAM_SPLITS", 0);
     if (forced > 0) splits = forced;
     if (splits < 1) splits = 1;
@@ -258,14 +323,40 @@ int launch_gram(byz_ctx* ctx, const float* G, int64_t n_rows, int64_t n_cols, in
     const bool wide = stages_per_split * BK > kFlushK;
     const size_t slab = static_cast<size_t>(TM) * TM * (wide ? sizeof(double) : sizeof(float));
     BYZ_TRY(ctx->gram_partials.ensure(static_cast<size_t>(splits) * n_tiles * slab));
-    const size_t lds_bytes = 0;  // static LDS: 2 buffers x (A|B) x 128 x 36 floats = 73,728 B -> 2 workgroups per CU
+    // tile list in 8 x 8 super-block order (see the kernel); rebuilt only when the tile count changes
+    if (ctx->tile_order_T != T) {
+        ctx->tile_order_host.clear();
+        const int64_t S = ceil_div(T, 8);
+        for (int64_t I = 0; I < S; ++I)
+            for (int64_t J = 0; J <= I; ++J)
+                for (int64_t ti = I * 8; ti < I * 8 + 8 && ti < T; ++ti)
+                    for (int64_t tj = J * 8; tj < J * 8 + 8 && tj <= ti; ++tj) {
+                        ctx->tile_order_host.push_back(static_cast<int32_t>(ti));
+                        ctx->tile_order_host.push_back(static_cast<int32_t>(tj));
+                    }
+        BYZ_TRY(ctx->tile_order.ensure(ctx->tile_order_host.size() * sizeof(int32_t)));
+        BYZ_HIP(hipMemcpyAsync(ctx->tile_order.ptr, ctx->tile_order_host.data(),
+                               ctx->tile_order_host.size() * sizeof(int32_t), hipMemcpyHostToDevice, stream));
+        BYZ_HIP(hipStreamSynchronize(stream));   // the host vector is pageable; once per matrix height
+        ctx->tile_order_T = T;
+    }
+    // XCD-partitioned order only when every XCD gets enough tiles for its shares to be even (<= 3% apart)
+    const bool partitioned = n_tiles >= 256;
+    const int64_t per_xcd = partitioned ? ceil_div(n_tiles, 8) : 0;
+    const int64_t grid_wgs = partitioned ? 8 * per_xcd * splits : n_tiles * splits;
+    if (grid_wgs > 0x7fffffff) {
+        set_error("gram: grid too large");
+        return BYZ_E_UNSUPPORTED;
+    }
     {
         KernelTimer t(ctx, BYZ_K_GRAM, stream);
-        dim3 grid(static_cast<unsigned>(n_tiles), static_cast<unsigned>(splits));
+        const int2* order = ctx->tile_order.as<int2>();
         if (wide)
-            gram_tile_kernel<double><<<grid, THREADS, lds_bytes, stream>>>(G, n_rows, n_cols, ld, stages_per_split, ctx->gram_partials.as<double>(), (int)n_tiles);
+            gram_tile_kernel<double><<<static_cast<unsigned>(grid_wgs), THREADS, 0, stream>>>(
+                G, n_rows, n_cols, ld, stages_per_split, ctx->gram_partials.as<double>(), (int)n_tiles, order, (int)per_xcd, (int)splits);
         else
-            gram_tile_kernel<float><<<grid, THREADS, lds_bytes, stream>>>(G, n_rows, n_cols, ld, stages_per_split, ctx->gram_partials.as<float>(), (int)n_tiles);
+            gram_tile_kernel<float><<<static_cast<unsigned>(grid_wgs), THREADS, 0, stream>>>(
+                G, n_rows, n_cols, ld, stages_per_split, ctx->gram_partials.as<float>(), (int)n_tiles, order, (int)per_xcd, (int)splits);
         BYZ_TRY(check_launch("gram_tile_kernel"));
     }
     {
