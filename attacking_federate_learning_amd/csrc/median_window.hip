@@ -6,16 +6,25 @@
 //
 // The reference sorts every column; nothing in the result needs the full order.  Only three order
 // statistics matter: the median (one or two middle ranks) and t = the k-th smallest |x - med|.  Given t,
-//     sum(good) = sum of d over {|d| < t}  +  (k - #{|d| < t}) tied values of magnitude exactly t,
-// and the row order only matters when +t and -t both occur and not all of them are kept.
+//     sum(good) = sum of d over {|d| <= t}                          when exactly k values satisfy |d| <= t,
+// and otherwise (ties at t beyond the k-th) the tied values are taken in row order, which only matters when
+// +t and -t both occur.
 //
-// An order statistic of R values held in registers costs ONE v_cmp per value per probe:
-// count(T) = #{x <= T} is a ballot + s_bcnt1 per register, accumulated on the scalar unit.  Probes bisect
-// the value range (arithmetic midpoints, falling back to midpoints of the order-preserving integer keys so
-// that at most 12 + 32 probes are ever made) until at most 64 candidates remain inside the bracket; those
-// are compacted into one value per lane (ballot + mbcnt scatter through a 256-byte LDS strip) and sorted
-// by a 64-lane bitonic network.  About 35 VALU operations per matrix element in total, against ~200 for a
-// bitonic sort of 1024 values: the kernel sits near the HBM time instead of 6x above it.
+// An order statistic of R values held in registers is found by counting probes: count(T) = #{x <= T}.
+//   * One probe costs 2.5 VALU operations per value: d = T - x, the sign bit of d, a three-input add.  On
+//     gfx950 a VOPC compare issues at half rate and the ballot/s_bcnt1/s_add form is bound by the scalar
+//     unit (scripts/ubench/count_rate.hip: 10.4 cycles per 64 values, against 6.3 for the arithmetic form).
+//   * Probes are chosen by safeguarded interpolation on the counts (the bracket ends carry their counts, so
+//     the empirical CDF is known at both), aiming alternately just above and just below the wanted rank so
+//     that two probes sandwich it; when a probe fails to shrink the candidate set by 15%, the next threshold
+//     is a data value from inside the bracket (a quickselect step: it splits by rank, so outliers of 1e30
+//     or heavy tails cannot stall the search); after 12 arithmetic probes the midpoint of the
+//     order-preserving integer keys takes over, which bounds the worst case at 12 + 32 probes.
+//     scripts/proto/probe_policy.py: 4.4 + 8.8 probes for N(0,1) at n = 1000, k = 799 (plain bisection
+//     7.9 + 6.8); 4.7 + 3.5 at n = 2080, k = 159 (9.1 + 9.1); 7.6 + 9.5 with +-1e30 outliers (20 + 25).
+//   * When at most 16 candidates remain inside the bracket they are compacted into the column's 16-lane
+//     segment of one register; one 16-lane bitonic network (DPP only) then sorts the candidates of the
+//     wave's four columns at once.
 //
 // Data movement (gfx950): one workgroup = 8 waves = one tile of 32 consecutive columns x all rows.
 //   * global loads are 128-byte row segments (8 lanes x dwordx4), 4 in flight per thread, software
@@ -25,8 +34,10 @@
 //     RPL = ceil(R/64) values of each of its 4 columns in registers.  The tile lives in the register file
 //     (512 KB per CU), which is what lets R reach 2560 rows; LDS (160 KB) could not hold it;
 //   * after staging, a wave never synchronises with another wave again: its 4 columns are entirely its own.
-// Rows past R are padded with quiet NaNs: they fail every ordered comparison, so no counting pass, min/max
-// or sum ever sees them.  A NaN in the data itself makes np.median, and with it the reference's result, NaN.
+// Rows past R are padded with +inf: T - inf has its sign bit set for every finite probe, so the padding is
+// never counted, and |inf - med| is never inside a window.  A NaN in the data makes np.median, and with it
+// the reference's result, NaN: a cheap per-thread x*0 accumulation flags non-finite input, and only a
+// flagged tile pays for the exact per-column NaN test.
 //
 // Algorithmic traffic: 4 bytes read per (row, column), 4 bytes written per column.  Bound: HBM.
 #include "common.hpp"
@@ -46,7 +57,10 @@ constexpr int kStride = 36;               // floats per LDS row: 16-byte aligned
 constexpr int kThreads = 512;             // 8 waves x 4 columns
 constexpr int kWaves = kThreads / 64;
 constexpr int kMaxRpl = 40;               // 2560 rows
-constexpr int kArithProbes = 12;          // value-space bisection steps before switching to key space
+constexpr int kArithProbes = 12;          // value-space probes before switching to key-space midpoints
+constexpr int kCand = 16;                 // candidates per column handed to the sorting network
+constexpr float kAimOffset = 0.35f * kCand;   // ranks by which a probe aims past the wanted rank
+constexpr float kStallRatio = 0.85f;
 
 __device__ __forceinline__ uint32_t fkey(float v) {  // order-preserving map float -> uint32
     const uint32_t b = __float_as_uint(v);
@@ -60,25 +74,12 @@ __device__ __forceinline__ bool finite_f(float v) { return (__float_as_uint(v) &
 template <bool ABS>
 __device__ __forceinline__ float mag(float v) { return ABS ? __builtin_fabsf(v) : v; }
 
-// number of values <= T (NaN padding never counts).  GS registers per uniform guard.
-template <int RPL, bool ABS>
-__device__ __forceinline__ int count_le(const float (&v)[RPL], int groups, float T) {
-    constexpr int GS = RPL >= 4 ? 4 : RPL;
-    int c = 0;
-#pragma unroll
-    for (int g = 0; g < RPL / GS; ++g) {
-        if (g < groups) {
-#pragma unroll
-            for (int jj = 0; jj < GS; ++jj) c += __popcll(__ballot(mag<ABS>(v[g * GS + jj]) <= T));
-        }
-    }
-    return c;
-}
-
-// wave-uniform values are moved to the scalar file explicitly: the bisection control flow is scalar code
+// wave-uniform values are moved to the scalar file explicitly: the probe control flow is scalar code
 __device__ __forceinline__ float uniform(float v) {
     return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v)));
 }
+__device__ __forceinline__ int uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
+
 __device__ __forceinline__ float wave_max(float v) {
 #pragma unroll
     for (int m = 32; m > 0; m >>= 1) v = __builtin_fmaxf(v, __shfl_xor(v, m, 64));
@@ -94,112 +95,249 @@ __device__ __forceinline__ float wave_sum(float v) {
     for (int m = 32; m > 0; m >>= 1) v += __shfl_xor(v, m, 64);
     return uniform(v);
 }
+// integer wave sum: four DPP butterfly steps inside each 16-lane row, then four v_readlane
+__device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v) {
+    int x = static_cast<int>(v);
+    x += __builtin_amdgcn_update_dpp(0, x, 0xB1, 0xF, 0xF, true);    // quad_perm [1,0,3,2]
+    x += __builtin_amdgcn_update_dpp(0, x, 0x4E, 0xF, 0xF, true);    // quad_perm [2,3,0,1]
+    x += __builtin_amdgcn_update_dpp(0, x, 0x141, 0xF, 0xF, true);   // row_half_mirror
+    x += __builtin_amdgcn_update_dpp(0, x, 0x140, 0xF, 0xF, true);   // row_mirror
+    return static_cast<uint32_t>(__builtin_amdgcn_readlane(x, 0) + __builtin_amdgcn_readlane(x, 16) +
+                                 __builtin_amdgcn_readlane(x, 32) + __builtin_amdgcn_readlane(x, 48));
+}
 
-struct Pair {
-    float a, b;
+// ascending sort inside every 16-lane segment (10 compare-exchange stages; lane masks <= 15)
+__device__ __forceinline__ float segment16_sort(float v, int lane) {
+    const float pinf = __builtin_inff();
+    for_pow2_up<2, 16>([&](auto kc) {
+        constexpr int k = decltype(kc)::value;
+        {
+            const float sel = (lane & (k / 2)) ? pinf : -pinf;   // the upper partner keeps the maximum
+            v = __builtin_amdgcn_fmed3f(v, lane_xor(v, k - 1, lane), sel);
+        }
+        for_pow2_down<k / 4>([&](auto jc) {
+            constexpr int j = decltype(jc)::value;
+            const float sel = (lane & j) ? pinf : -pinf;
+            v = __builtin_amdgcn_fmed3f(v, lane_xor(v, j, lane), sel);
+        });
+    });
+    return v;
+}
+
+// Bracket of one selection for one column; the fields the caller fills in and reads back are wave-uniform.
+struct Bracket {
+    float lo, hi;      // count(lo) = c_lo <= r < c_hi = count(hi)   (count(T) = #{mag(x) <= T})
+    int c_lo, c_hi;
+    float a, b;        // results: rank r and rank r + 1
 };
 
-// The r-th smallest (0-based) of mag(v), and with WANT_NEXT also the (r+1)-th.
-// Requires on entry: count(lo) == 0, count(hi) == c_hi > r (+1 with WANT_NEXT).
-template <int RPL, bool ABS, bool WANT_NEXT>
-__device__ __forceinline__ Pair select_rank(const float (&v)[RPL], int groups, int r, float lo, float hi, int c_hi,
-                                            int lane, float* strip) {
+template <typename T>
+__device__ __forceinline__ T by_column(int col, T v0, T v1, T v2, T v3) {
+    return col == 0 ? v0 : (col == 1 ? v1 : (col == 2 ? v2 : v3));
+}
+__device__ __forceinline__ float lane_value(float v, int src) {   // src is wave-uniform
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src));
+}
+
+// Ranks r (and r + 1 with want_next) of mag(x[c]) for the wave's four columns at once.
+// On entry q[c].lo / hi / c_lo / c_hi describe a valid bracket.  slots = 64 * registers in use.
+//
+// The probe bookkeeping of the four columns runs as ONE vector instruction stream: lane l carries the
+// bracket of column l & 3, so choosing the four next probes and absorbing the four counts costs one pass
+// of ~100 vector instructions, not four scalar ones with their branches.  Only the counting passes, the
+// compaction and the rare pivot search are per column.
+template <int RPL, bool ABS>
+__device__ __forceinline__ void select4(const float (&x)[4][RPL], int groups, int slots, int r, bool want_next,
+                                        Bracket (&q)[4], int lane, float* strip) {
     constexpr int GS = RPL >= 4 ? 4 : RPL;
-    const int r_hi = WANT_NEXT ? r + 1 : r;
-    int c_lo = 0;
-    for (int it = 0; c_hi - c_lo > 64; ++it) {
-        const uint32_t klo = fkey(lo), khi = fkey(hi);
-        if (khi - klo <= 1u) return Pair{hi, hi};  // no float strictly inside: every candidate equals hi
-        float T = 0.5f * lo + 0.5f * hi;
-        const bool arith = it < kArithProbes && finite_f(lo) && finite_f(hi) && T > lo && T < hi;
-        if (!arith) T = from_fkey(klo + ((khi - klo) >> 1));
-        const int c = count_le<RPL, ABS>(v, groups, T);
-        if (c <= r) {
-            lo = T;
-            c_lo = c;
-        } else if (c > r_hi) {
-            hi = T;
-            c_hi = c;
-        } else {
-            // WANT_NEXT and c == r + 1: T separates the two wanted ranks
-            float below = -__builtin_inff(), above = __builtin_inff();
+    const int col = lane & 3;
+    const float pinf = __builtin_inff();
+    const int r_hi = want_next ? r + 1 : r;
+    const float want = static_cast<float>(r) + (want_next ? 1.0f : 0.5f);
+    // per-lane state of column `col`
+    float lo = by_column(col, q[0].lo, q[1].lo, q[2].lo, q[3].lo);
+    float hi = by_column(col, q[0].hi, q[1].hi, q[2].hi, q[3].hi);
+    int c_lo = by_column(col, q[0].c_lo, q[1].c_lo, q[2].c_lo, q[3].c_lo);
+    int c_hi = by_column(col, q[0].c_hi, q[1].c_hi, q[2].c_hi, q[3].c_hi);
+    int state = (c_hi - c_lo <= kCand) ? 1 : 0;   // 0 probing, 1 <= kCand candidates, 2 resolved, 3 split at T
+    int last = 0, stalled = 0, probes = 0;
+    float T = hi, res_a = 0.0f, res_b = 0.0f;
+
+    for (int guard = 0; guard < 64; ++guard) {
+        if ((__ballot(state == 0) & 0xFull) == 0ull) break;
+        // ---- next probe of every probing column
+        {
+            const bool active = state == 0;
+            const uint32_t klo = fkey(lo), khi = fkey(hi);
+            const bool adjacent = khi - klo <= 1u;       // no float strictly inside: every candidate equals hi
+            const float cand = static_cast<float>(c_hi - c_lo);
+            const float aim = want + (last > 0 ? -kAimOffset : kAimOffset);
+            float f = (aim - static_cast<float>(c_lo)) * __builtin_amdgcn_rcpf(cand);
+            f = __builtin_fminf(__builtin_fmaxf(f, 0.02f), 0.98f);
+            f = stalled ? 0.5f : f;
+            const float Ta = __builtin_fmaf(f, hi - lo, lo);
+            const bool arith = probes < kArithProbes && finite_f(lo) && finite_f(hi) && Ta > lo && Ta < hi;
+            const float Tk = from_fkey(klo + ((khi - klo) >> 1));
+            if (active) T = (arith ? Ta : Tk) + 0.0f;   // -0.0 would count +0.0 as greater; a split column keeps its T
+            if (active && adjacent) {
+                state = 2;
+                res_a = hi;
+                res_b = hi;
+            }
+            // quickselect step for a stalled column: a data value from inside the bracket, looked for in the
+            // column's first registers only (rare path, per column)
+            const unsigned pivots = static_cast<unsigned>(__ballot(state == 0 && stalled && arith) & 0xFull);
+            if (pivots) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    if ((pivots >> c) & 1u) {
+                        const float lo_c = lane_value(lo, c), hi_c = lane_value(hi, c);
+                        bool have = false;
+                        float pv = 0.0f;
+#pragma unroll
+                        for (int jj = 0; jj < GS; ++jj) {
+                            if (!have) {
+                                const float a = mag<ABS>(x[c][jj]);
+                                const unsigned long long m = __ballot(a > lo_c && a <= hi_c);
+                                if (m) {
+                                    pv = lane_value(a, __builtin_ctzll(m));
+                                    if (!(pv < hi_c)) pv = from_fkey(fkey(pv) - 1u);   // stay strictly inside
+                                    have = pv > lo_c;
+                                }
+                            }
+                        }
+                        if (have && col == c) T = pv + 0.0f;
+                    }
+                }
+            }
+            probes += (state == 0) ? 1 : 0;
+        }
+        // ---- counting pass: for each column still probing, the values greater than its probe
+        uint32_t neg[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            if (__builtin_amdgcn_readlane(state, c) == 0) {
+                const float Tc = lane_value(T, c);
+                uint32_t n0 = 0u;
+#pragma unroll
+                for (int g = 0; g < RPL / GS; ++g) {
+                    if (g < groups) {
+#pragma unroll
+                        for (int jj = 0; jj < GS; ++jj)
+                            n0 += __float_as_uint(Tc - mag<ABS>(x[c][g * GS + jj])) >> 31;
+                    }
+                }
+                neg[c] = n0;
+            }
+        }
+        // per-lane counts are at most 40: two columns share one register through the reduction
+        const uint32_t s01 = wave_sum_u32(neg[0] | (neg[1] << 16));
+        const uint32_t s23 = wave_sum_u32(neg[2] | (neg[3] << 16));
+        // ---- absorb the counts
+        {
+            const uint32_t packed = (lane & 2) ? s23 : s01;
+            const int greater = static_cast<int>((lane & 1) ? (packed >> 16) : (packed & 0xffffu));
+            const int c = slots - greater;
+            const bool active = state == 0;
+            const int before = c_hi - c_lo;
+            const bool to_lo = active && c <= r;
+            const bool to_hi = active && c > r_hi;
+            lo = to_lo ? T : lo;
+            c_lo = to_lo ? c : c_lo;
+            hi = to_hi ? T : hi;
+            c_hi = to_hi ? c : c_hi;
+            last = to_lo ? -1 : (to_hi ? 1 : last);
+            const int after = c_hi - c_lo;
+            stalled = static_cast<float>(after) > kStallRatio * static_cast<float>(before) ? 1 : 0;
+            if (active) state = (!to_lo && !to_hi) ? 3 : (after <= kCand ? 1 : 0);   // 3: T separates ranks r, r + 1
+        }
+    }
+    // ---- a probe that fell exactly between ranks r and r + 1: the neighbours on both sides
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        if (__builtin_amdgcn_readlane(state, c) == 3) {
+            const float Tc = lane_value(T, c);
+            float below = -pinf, above = pinf;
 #pragma unroll
             for (int g = 0; g < RPL / GS; ++g) {
                 if (g < groups) {
 #pragma unroll
                     for (int jj = 0; jj < GS; ++jj) {
-                        const float a = mag<ABS>(v[g * GS + jj]);
-                        below = (a <= T) ? __builtin_fmaxf(below, a) : below;
-                        above = (a > T) ? __builtin_fminf(above, a) : above;
+                        const float a = mag<ABS>(x[c][g * GS + jj]);
+                        below = (a <= Tc) ? __builtin_fmaxf(below, a) : below;
+                        above = (a > Tc) ? __builtin_fminf(above, a) : above;   // +inf padding loses every min
                     }
                 }
             }
-            return Pair{wave_max(below), wave_min(above)};
+            const float wa = wave_max(below), wb = wave_min(above);
+            if (col == c) {
+                res_a = wa;
+                res_b = wb;
+                state = 2;
+            }
         }
     }
-    // at most 64 candidates in (lo, hi]: one per lane, sorted across the wave
-    int n_cand = 0;
+    // ---- compaction: the candidates of column c go to lanes 16 c .. 16 c + 15 of the strip
+    int valid[4] = {0, 0, 0, 0};
+    const unsigned to_sort = static_cast<unsigned>(__ballot(state == 1) & 0xFull);
 #pragma unroll
-    for (int g = 0; g < RPL / GS; ++g) {
-        if (g < groups) {
+    for (int c = 0; c < 4; ++c) {
+        if ((to_sort >> c) & 1u) {
+            const float lo_next = uniform(from_fkey(fkey(lane_value(lo, c)) + 1u)), hi_c = lane_value(hi, c);
+            int n_cand = 0;
 #pragma unroll
-            for (int jj = 0; jj < GS; ++jj) {
-                const float a = mag<ABS>(v[g * GS + jj]);
-                const bool in = !(a <= lo) && a <= hi;   // lo may be NaN when the minimum is -inf
-                const unsigned long long m = __ballot(in);
-                if (m) {  // uniform
-                    const int pos = n_cand + __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(m >> 32),
-                                                                        __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(m), 0));
-                    if (in) strip[pos] = a;
-                    n_cand += __popcll(m);
+            for (int g = 0; g < RPL / GS; ++g) {
+                if (g < groups) {
+#pragma unroll
+                    for (int jj = 0; jj < GS; ++jj) {
+                        const float a = mag<ABS>(x[c][g * GS + jj]);
+                        const bool in = __builtin_amdgcn_fmed3f(a, lo_next, hi_c) == a;   // lo < a <= hi
+                        const unsigned long long m = __ballot(in);
+                        if (m) {  // uniform
+                            const int pos = n_cand + __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(m >> 32),
+                                                                                __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(m), 0));
+                            if (in && pos < kCand) strip[c * kCand + pos] = a;
+                            n_cand += __popcll(m);
+                        }
+                    }
+                }
+            }
+            valid[c] = n_cand < kCand ? n_cand : kCand;
+        }
+    }
+    if (to_sort) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const int seg = lane >> 4;
+        const int n_valid = by_column(seg, valid[0], valid[1], valid[2], valid[3]);
+        float s = (lane & 15) < n_valid ? strip[lane] : pinf;
+        s = segment16_sort(s, lane);
+        __builtin_amdgcn_wave_barrier();   // the strip is reused by the next selection
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            if ((to_sort >> c) & 1u) {
+                const int i = c * kCand + (r - __builtin_amdgcn_readlane(c_lo, c));
+                const float sa = lane_value(s, i & 63), sb = lane_value(s, (i + 1) & 63);
+                if (col == c) {
+                    res_a = sa;
+                    res_b = want_next ? sb : sa;
                 }
             }
         }
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    float s[1][1];
-    s[0][0] = lane < n_cand ? strip[lane] : __builtin_inff();
-    wave_bitonic_sort<1, 1>(s, lane);
-    __builtin_amdgcn_wave_barrier();  // the strip is reused by the next selection
-    const int i = r - c_lo;
-    Pair out;
-    out.a = uniform(__shfl(s[0][0], i, 64));
-    out.b = WANT_NEXT ? uniform(__shfl(s[0][0], i + 1, 64)) : out.a;
-    return out;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        q[c].a = lane_value(res_a, c);
+        q[c].b = lane_value(res_b, c);
+    }
 }
 
-// One column: everything after the values sit in registers.  Returns the reference's out[i].
+// Ties at exactly t beyond the keep-th value (rare with continuous data, normal when many clients submit the
+// same vector): the reference's stable sort keeps the lowest rows.  v holds the deviations.
 template <int RPL>
-__device__ __forceinline__ float median_window_column(float (&v)[RPL], int groups, int n, int keep, float mn, float mx,
-                                                      int lane, float* strip) {
+__device__ __forceinline__ float tied_window_sum(const float (&v)[RPL], int groups, int keep, float t) {
     constexpr int GS = RPL >= 4 ? 4 : RPL;
-    // ---- median (defences.py:49)
-    float med;
-    {
-        // lo: the float just below the minimum (count 0); hi: the maximum (count n)
-        const float lo = from_fkey(fkey(mn) - 1u);
-        if (n & 1) {
-            med = select_rank<RPL, false, false>(v, groups, (n - 1) >> 1, lo, mx, n, lane, strip).a;
-        } else {
-            const Pair p = select_rank<RPL, false, true>(v, groups, (n >> 1) - 1, lo, mx, n, lane, strip);
-            med = __fmul_rn(__fadd_rn(p.a, p.b), 0.5f);
-        }
-    }
-    // ---- deviations in place (defences.py:50: column - med); rounding is monotone, so the largest
-    // |deviation| belongs to one of the extremes
-#pragma unroll
-    for (int g = 0; g < RPL / GS; ++g) {
-        if (g < groups) {
-#pragma unroll
-            for (int jj = 0; jj < GS; ++jj) v[g * GS + jj] = __fsub_rn(v[g * GS + jj], med);
-        }
-    }
-    const float max_dev = __builtin_fmaxf(__builtin_fabsf(__fsub_rn(mn, med)), __builtin_fabsf(__fsub_rn(mx, med)));
-    // ---- t = the keep-th smallest |deviation|
-    const float t = select_rank<RPL, true, false>(v, groups, keep - 1, -__uint_as_float(1u), max_dev, n, lane, strip).a;
-    // ---- everything strictly closer than t is kept; of the ties at exactly t, the first `need` in row order
     float acc = 0.0f;
     int n_closer = 0, n_pos = 0, n_neg = 0;
 #pragma unroll
@@ -227,7 +365,6 @@ __device__ __forceinline__ float median_window_column(float (&v)[RPL], int group
     } else if (n_pos == 0) {
         sum -= static_cast<float>(need) * t;
     } else {
-        // +t and -t both present and only some are kept: the reference's stable sort keeps the lowest rows
         int taken = 0, pos_taken = 0, neg_taken = 0;
 #pragma unroll
         for (int g = 0; g < RPL / GS; ++g) {
@@ -248,33 +385,38 @@ __device__ __forceinline__ float median_window_column(float (&v)[RPL], int group
         }
         sum += static_cast<float>(pos_taken - neg_taken) * t;
     }
-    // defences.py:51: np.mean(good) + med
-    return __fadd_rn(__fdiv_rn(sum, static_cast<float>(keep)), med);
+    return sum;
 }
 
 template <int RPL>
-__global__ __launch_bounds__(kThreads, (RPL <= 16 ? 4 : 2)) void median_window_kernel(const float* __restrict__ G, int n_rows,
-                                                                 int64_t n_cols, int64_t ld,
-                                                                 const int32_t* __restrict__ row_index, int keep,
-                                                                 float* __restrict__ out) {
+__global__ __launch_bounds__(kThreads, (RPL <= 16 ? 4 : 2)) void median_window_kernel(
+    const float* __restrict__ G, int n_rows, int64_t n_cols, int64_t ld, const int32_t* __restrict__ row_index,
+    int keep, float* __restrict__ out) {
     constexpr int JC = RPL >= 4 ? 4 : RPL;   // registers (64-row groups) per transit chunk == guard group
     constexpr int NCH = RPL / JC;
-    __shared__ __attribute__((aligned(16))) float transit[64 * JC * kStride + kWaves * 64];
+    constexpr int GS = JC;
+    __shared__ __attribute__((aligned(16))) float transit[64 * JC * kStride + kWaves * 64 + 16];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     float* strip = transit + 64 * JC * kStride + wave * 64;
+    int* nonfinite = reinterpret_cast<int*>(transit + 64 * JC * kStride + kWaves * 64);   // one flag per column quad
     const int64_t c_base = static_cast<int64_t>(blockIdx.x) * kCols;
+    const float pinf = __builtin_inff();
     const float qnan = __uint_as_float(0x7fc00000u);
     const int chunks = (n_rows + 64 * JC - 1) / (64 * JC);   // == guard groups in use
+    const int slots = chunks * 64 * JC;
+
+    if (tid < 8) nonfinite[tid] = 0;
 
     // ---- stage: global (128-byte row segments) -> LDS transit -> registers (4 columns x RPL rows per lane)
     const int ld_q = (tid & 7) * 4, ld_r = tid >> 3;
     const int64_t ld_c = c_base + ld_q;
     f32x4 tmp[JC];
+    float poison = 0.0f;   // x * 0 accumulates to NaN as soon as one loaded value is NaN or +-inf
     auto fetch = [&](int ch) {
 #pragma unroll
         for (int p = 0; p < JC; ++p) {
             const int row = ch * 64 * JC + 64 * p + ld_r;
-            f32x4 val = {qnan, qnan, qnan, qnan};
+            f32x4 val = {pinf, pinf, pinf, pinf};
             if (row < n_rows) {
                 const int64_t src = row_index ? row_index[row] : row;
                 const float* ptr = G + src * ld + ld_c;
@@ -290,52 +432,166 @@ __global__ __launch_bounds__(kThreads, (RPL <= 16 ? 4 : 2)) void median_window_k
             tmp[p] = val;
         }
     };
+    auto stash = [&](int ch) {
+#pragma unroll
+        for (int p = 0; p < JC; ++p) {
+            const f32x4 val = tmp[p];
+            if (ch * 64 * JC + 64 * p + ld_r < n_rows)
+                poison = __builtin_fmaf(val.x + val.y, 0.0f, __builtin_fmaf(val.z + val.w, 0.0f, poison));
+            *reinterpret_cast<f32x4*>(transit + (64 * p + ld_r) * kStride + ld_q) = val;
+        }
+    };
     float x[4][RPL];
     float mn[4], mx[4];
-    int n_nan[4] = {0, 0, 0, 0};
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
-        mn[c] = __builtin_inff();
-        mx[c] = -__builtin_inff();
+        mn[c] = pinf;
+        mx[c] = -pinf;
     }
     fetch(0);
 #pragma unroll
     for (int ch = 0; ch < NCH; ++ch) {
         if (ch < chunks) {
-#pragma unroll
-            for (int p = 0; p < JC; ++p)
-                *reinterpret_cast<f32x4*>(transit + (64 * p + ld_r) * kStride + ld_q) = tmp[p];
+            stash(ch);
             if (ch + 1 < chunks) fetch(ch + 1);
             __syncthreads();
+            const bool last_chunk = ch == chunks - 1;   // uniform: only this chunk can hold padding rows
 #pragma unroll
             for (int jj = 0; jj < JC; ++jj) {
                 const f32x4 val = *reinterpret_cast<const f32x4*>(transit + (64 * jj + lane) * kStride + 4 * wave);
+                const bool real = !last_chunk || (ch * 64 * JC + 64 * jj + lane < n_rows);
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
                     const float e = val[c];
                     x[c][ch * JC + jj] = e;
-                    mn[c] = __builtin_fminf(mn[c], e);   // minnum / maxnum: NaN padding is ignored
-                    mx[c] = __builtin_fmaxf(mx[c], e);
-                    n_nan[c] += __popcll(__ballot(e != e));
+                    mn[c] = __builtin_fminf(mn[c], e);                 // +inf padding never wins a minimum
+                    mx[c] = __builtin_fmaxf(mx[c], real ? e : -pinf);  // and is masked out of the maximum
                 }
             }
             __syncthreads();
         }
     }
-    const int pad_slots = chunks * 64 * JC - n_rows;
+    if (poison != poison) nonfinite[tid & 7] = 1;
+    __syncthreads();
+    const bool suspicious = uniform(nonfinite[wave]) != 0;   // an LDS load is per-lane to the compiler: make it scalar
 
-    // ---- per column: selection by counting, no further workgroup synchronisation
+    Bracket q[4];
+    bool dead[4];       // the column's result is NaN
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        dead[c] = keep <= 0;   // np.mean([]) is nan
+        if (suspicious) {
+            int n_nan = 0;
+#pragma unroll
+            for (int g = 0; g < RPL / GS; ++g) {
+                if (g < chunks) {
+#pragma unroll
+                    for (int jj = 0; jj < GS; ++jj) {
+                        const float e = x[c][g * GS + jj];
+                        n_nan += __popcll(__ballot(e != e));
+                    }
+                }
+            }
+            dead[c] = dead[c] || n_nan > 0;   // a NaN in the column makes np.median nan
+        }
+    }
+
+    // ---- median (defences.py:49)
+    float med[4], lo_x[4], hi_x[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        lo_x[c] = wave_min(mn[c]);
+        hi_x[c] = wave_max(mx[c]);
+        q[c].hi = hi_x[c];
+        q[c].c_hi = n_rows;
+        q[c].c_lo = 0;
+        q[c].lo = uniform(from_fkey(fkey(lo_x[c]) - 1u));   // the float just below the minimum
+        q[c].a = q[c].b = 0.0f;
+        if (!(lo_x[c] > -pinf) || dead[c]) {   // -inf in the data (or nothing to do): bracket by key space alone
+            q[c].lo = -pinf;
+            q[c].c_lo = 0;
+            if (!dead[c]) {
+                int c_inf = 0;
+#pragma unroll
+                for (int g = 0; g < RPL / GS; ++g)
+                    if (g < chunks)
+#pragma unroll
+                        for (int jj = 0; jj < GS; ++jj) c_inf += __popcll(__ballot(x[c][g * GS + jj] == -pinf));
+                q[c].c_lo = c_inf;
+            }
+        }
+    }
+    const bool even = (n_rows & 1) == 0;
+    const int r_med = even ? (n_rows >> 1) - 1 : (n_rows - 1) >> 1;
+    bool run_med[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        // more -inf than the median rank: the median is -inf and every deviation is NaN or +inf
+        run_med[c] = !dead[c] && q[c].c_lo <= r_med;
+        if (!run_med[c]) {
+            dead[c] = true;
+            q[c].lo = 0.0f;   // harmless bracket: the column is ignored
+            q[c].hi = 0.0f;
+            q[c].c_lo = 0;
+            q[c].c_hi = 0;
+        }
+    }
+    select4<RPL, false>(x, chunks, slots, r_med, even, q, lane, strip);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) med[c] = uniform(even ? __fmul_rn(__fadd_rn(q[c].a, q[c].b), 0.5f) : q[c].a);
+
+    // ---- deviations in place (defences.py:50: column - med); rounding is monotone, so the largest
+    // |deviation| belongs to one of the extremes.  Padding stays +inf.
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+#pragma unroll
+        for (int g = 0; g < RPL / GS; ++g) {
+            if (g < chunks) {
+#pragma unroll
+                for (int jj = 0; jj < GS; ++jj) x[c][g * GS + jj] = __fsub_rn(x[c][g * GS + jj], med[c]);
+            }
+        }
+        const float max_dev = uniform(__builtin_fmaxf(__builtin_fabsf(__fsub_rn(lo_x[c], med[c])),
+                                                      __builtin_fabsf(__fsub_rn(hi_x[c], med[c]))));
+        dead[c] = dead[c] || !(max_dev == max_dev);   // inf - inf
+        q[c].lo = -__uint_as_float(1u);               // below every |d|
+        q[c].c_lo = 0;
+        q[c].hi = max_dev;
+        q[c].c_hi = n_rows;
+        if (dead[c]) {
+            q[c].lo = 0.0f;
+            q[c].hi = 0.0f;
+            q[c].c_hi = 0;
+        }
+    }
+    // ---- t = the keep-th smallest |deviation|
+    select4<RPL, true>(x, chunks, slots, keep - 1, false, q, lane, strip);
+
+    // ---- window sum: everything with |d| <= t, when that is exactly `keep` values
     float result[4];
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
-        const float lo = wave_min(mn[c]), hi = wave_max(mx[c]);
-        float r;
-        if (keep <= 0 || n_nan[c] > pad_slots) {
-            r = qnan;   // np.mean([]) is nan; a NaN in the column makes np.median nan
-        } else {
-            r = median_window_column<RPL>(x[c], chunks, n_rows, keep, lo, hi, lane, strip);
+        const float t = q[c].a;
+        float acc = 0.0f;
+        int n_in = 0;
+        if (!dead[c]) {
+#pragma unroll
+            for (int g = 0; g < RPL / GS; ++g) {
+                if (g < chunks) {
+#pragma unroll
+                    for (int jj = 0; jj < GS; ++jj) {
+                        const float d = x[c][g * GS + jj];
+                        const bool in = __builtin_fabsf(d) <= t;
+                        acc += in ? d : 0.0f;
+                        n_in += __popcll(__ballot(in));
+                    }
+                }
+            }
         }
-        result[c] = r;
+        float sum = wave_sum(acc);
+        if (!dead[c] && n_in != keep) sum = tied_window_sum<RPL>(x[c], chunks, keep, t);
+        // defences.py:51: np.mean(good) + med
+        result[c] = dead[c] ? qnan : __fadd_rn(__fdiv_rn(sum, static_cast<float>(keep)), med[c]);
     }
     if (lane < 4) {
         const int64_t col = c_base + 4 * wave + lane;
