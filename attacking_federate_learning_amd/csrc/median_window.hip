@@ -52,9 +52,9 @@ using namespace lanes;
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
 
-constexpr int kCols = 32;                 // columns per tile
-constexpr int kStride = 36;               // floats per LDS row: 16-byte aligned, b128 column reads conflict-free
-constexpr int kThreads = 512;             // 8 waves x 4 columns
+constexpr int kCols = 16;                 // columns per tile
+constexpr int kStride = 20;               // floats per LDS row: 16-byte aligned, b128 column reads conflict-free
+constexpr int kThreads = 256;             // 4 waves x 4 columns
 constexpr int kWaves = kThreads / 64;
 constexpr int kMaxRpl = 40;               // 2560 rows
 constexpr int kArithProbes = 12;          // value-space probes before switching to key-space midpoints
@@ -405,10 +405,11 @@ __global__ __launch_bounds__(kThreads, (RPL <= 16 ? 4 : 2)) void median_window_k
     const int chunks = (n_rows + 64 * JC - 1) / (64 * JC);   // == guard groups in use
     const int slots = chunks * 64 * JC;
 
-    if (tid < 8) nonfinite[tid] = 0;
+    if (tid < kWaves) nonfinite[tid] = 0;
 
     // ---- stage: global (128-byte row segments) -> LDS transit -> registers (4 columns x RPL rows per lane)
-    const int ld_q = (tid & 7) * 4, ld_r = tid >> 3;
+    constexpr int QUADS = kCols / 4;
+    const int ld_q = (tid % QUADS) * 4, ld_r = tid / QUADS;
     const int64_t ld_c = c_base + ld_q;
     f32x4 tmp[JC];
     float poison = 0.0f;   // x * 0 accumulates to NaN as soon as one loaded value is NaN or +-inf
@@ -471,7 +472,7 @@ __global__ __launch_bounds__(kThreads, (RPL <= 16 ? 4 : 2)) void median_window_k
             __syncthreads();
         }
     }
-    if (poison != poison) nonfinite[tid & 7] = 1;
+    if (poison != poison) nonfinite[tid % QUADS] = 1;
     __syncthreads();
     const bool suspicious = uniform(nonfinite[wave]) != 0;   // an LDS load is per-lane to the compiler: make it scalar
 
