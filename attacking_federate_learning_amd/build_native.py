@@ -26,7 +26,8 @@ EXTRA_FLAGS = {'trimmed_mean.hip': ['-fno-honor-nans'],
                # fully unrolled (a dynamic index would demote the array to scratch), and the staging loop of
                # the larger instantiations exceeds LLVM's default budget for `#pragma unroll`.  NaN semantics
                # stay on in this file: the padding rows are NaNs.
-               'median_window.hip': ['-mllvm', '-pragma-unroll-threshold=1000000']}
+               'median_window.hip': ['-mllvm', '-pragma-unroll-threshold=1000000'],
+               'gram.hip': ['-mllvm', '-pragma-unroll-threshold=1000000']}
 COMMON_FLAGS = ['--offload-arch=' + ARCH, '-O3', '-std=c++17', '-fPIC', '-Wall', '-Wno-unused-function',
                 '-Wno-nan-infinity-disabled']
 

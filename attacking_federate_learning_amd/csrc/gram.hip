@@ -37,6 +37,7 @@ constexpr int BK = 32;               // floats of K per stage
 constexpr int LDS_STRIDE = BK + 4;   // 36 floats = 144 B: 16-byte aligned, conflict-free b128 reads
 constexpr int THREADS = 256;
 constexpr int kFlushK = 2048;        // longest fp32 accumulation chain
+constexpr int kLevel1 = 8;           // level-0 chains per level-1 fp32 sum
 constexpr int TILE_FLOATS = TM * LDS_STRIDE;
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -53,13 +54,23 @@ __device__ __forceinline__ f32x4 load_tail(const float* __restrict__ p, int64_t 
     return v;
 }
 
-template <typename PartialT>
+// float offset of (row, 16-byte chunk 0..7) inside one operand tile.
+//   register-staged layout: rows padded to 36 floats (conflict-free ds_read_b128);
+//   LDS-DMA layout: rows of exactly 32 floats, because `global_load_lds` writes wave-uniform base + 16 * lane and
+//   cannot pad; the bank conflicts are removed by an XOR swizzle of the chunk index instead, applied to the
+//   SOURCE address of the DMA and to every read (the same involution on both sides).
+template <bool DMA>
+__device__ __forceinline__ int tile_off(int row, int chunk) {
+    return DMA ? row * 32 + ((chunk ^ ((row >> 1) & 7)) << 2) : row * LDS_STRIDE + (chunk << 2);
+}
+
+template <typename PartialT, bool DMA>
 __global__ __launch_bounds__(THREADS, 2) void gram_tile_kernel(const float* __restrict__ G, int64_t n_rows,
                                                                int64_t n_cols, int64_t ld,
                                                                int64_t stages_per_split,
                                                                PartialT* __restrict__ partial, int n_tiles,
                                                                const int2* __restrict__ tile_order, int per_xcd, int n_splits) {
-    __shared__ __attribute__((aligned(16))) float lds[2 * 2 * TILE_FLOATS];  // [2 buffers][A | B][TM][LDS_STRIDE]
+    __shared__ __attribute__((aligned(16))) float lds[2 * 2 * TILE_FLOATS];  // [2 buffers][A | B][TM][row]
 
     // Workgroup -> (tile, K split).  Workgroups are dealt to the 8 XCDs round-robin (observed; only speed
     // depends on it), each XCD with its own L2.  With many tiles, XCD x works through its own contiguous
@@ -88,7 +99,7 @@ __global__ __launch_bounds__(THREADS, 2) void gram_tile_kernel(const float* __re
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int wave = tid >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave >> 1, wc = wave & 1;
 
     const int64_t k_begin = static_cast<int64_t>(split) * stages_per_split * BK;
@@ -97,59 +108,87 @@ __global__ __launch_bounds__(THREADS, 2) void gram_tile_kernel(const float* __re
     const int n_stages = k_begin < k_end ? static_cast<int>((k_end - k_begin + BK - 1) / BK) : 0;
     const int n_full = k_begin < k_end ? static_cast<int>((k_end - k_begin) / BK) : 0;   // stages without a ragged K tail
 
-    // staging assignment: 8 lanes cover one 128-byte row segment, 32 rows per pass, 4 passes per operand.
-    // Rows past the matrix are clamped to the last row: the duplicates land in Gram entries nobody reads,
-    // and the main loop carries no per-load branch (a branch around a load makes hipcc drain vmcnt).
-    const int ld_kq = (tid & 7) * 4;
+    // Rows past the matrix are clamped to the last row: the duplicates land in Gram entries nobody reads, and
+    // the main loop carries no per-load branch (a branch around a load makes hipcc drain vmcnt).
+    auto row_ptr = [&](int tile_row0, int local_row) {
+        int64_t r = static_cast<int64_t>(tile_row0) * TM + local_row;
+        if (r > n_rows - 1) r = n_rows - 1;
+        return G + r * ld;
+    };
+    // register staging (the whole loop without DMA, the ragged K tail with it): 8 lanes cover one 128-byte
+    // row segment, 32 rows per pass, 4 passes per operand
+    const int ld_chunk = tid & 7;
     const int ld_row = tid >> 3;
-    const float* a_ptr[4];
-    const float* b_ptr[4];
+    // LDS-DMA staging: wave w moves rows 32w .. 32w+31 of each operand, 8 rows (1 KiB) per instruction;
+    // lane l lands at LDS position (row l >> 3, chunk slot l & 7), which holds chunk (l & 7) ^ swizzle(row)
+    const float* src_a[4];
+    const float* src_b[4];
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
-        int64_t ra_ = static_cast<int64_t>(ti) * TM + ld_row + 32 * p;
-        int64_t rb_ = static_cast<int64_t>(tj) * TM + ld_row + 32 * p;
-        if (ra_ > n_rows - 1) ra_ = n_rows - 1;
-        if (rb_ > n_rows - 1) rb_ = n_rows - 1;
-        a_ptr[p] = G + ra_ * ld + ld_kq;
-        b_ptr[p] = G + rb_ * ld + ld_kq;
+        if constexpr (DMA) {
+            const int r = 32 * wave + 8 * p + (lane >> 3);
+            const int chunk = (lane & 7) ^ ((r >> 1) & 7);
+            src_a[p] = row_ptr(ti, r) + 4 * chunk;
+            src_b[p] = row_ptr(tj, r) + 4 * chunk;
+        } else {
+            src_a[p] = row_ptr(ti, ld_row + 32 * p) + 4 * ld_chunk;
+            src_b[p] = row_ptr(tj, ld_row + 32 * p) + 4 * ld_chunk;
+        }
     }
 
     f32x4 ra[4], rb[4];
-    // the main loop only ever issues unconditional 16-byte loads; the ragged K tail has its own code
-    auto fetch_full = [&](int stage) {
+    auto fetch_full = [&](int stage) __attribute__((always_inline)) {   // register path, full stage
         const int64_t k = k_begin + static_cast<int64_t>(stage) * BK;
 #pragma unroll
-        for (int p = 0; p < 4; ++p) ra[p] = *reinterpret_cast<const f32x4u*>(a_ptr[p] + k);
+        for (int p = 0; p < 4; ++p) ra[p] = *reinterpret_cast<const f32x4u*>(src_a[p] + k);
         if (!diagonal) {
 #pragma unroll
-            for (int p = 0; p < 4; ++p) rb[p] = *reinterpret_cast<const f32x4u*>(b_ptr[p] + k);
+            for (int p = 0; p < 4; ++p) rb[p] = *reinterpret_cast<const f32x4u*>(src_b[p] + k);
         }
     };
-    auto fetch_any = [&](int stage) {
-        if (stage < n_full) {
-            fetch_full(stage);
-        } else {  // the one ragged stage of the last split: zero-fill past k_end
-            const int64_t k = k_begin + static_cast<int64_t>(stage) * BK;
+    auto fetch_tail = [&](int stage) __attribute__((always_inline)) {   // the one ragged stage: zero-fill past k_end
+        const int64_t k = k_begin + static_cast<int64_t>(stage) * BK + 4 * ld_chunk;
 #pragma unroll
-            for (int p = 0; p < 4; ++p) {
-                ra[p] = load_tail(a_ptr[p] + k, k + ld_kq, k_end);
-                if (!diagonal) rb[p] = load_tail(b_ptr[p] + k, k + ld_kq, k_end);
-            }
+        for (int p = 0; p < 4; ++p) {
+            ra[p] = load_tail(row_ptr(ti, ld_row + 32 * p) + k, k, k_end);
+            if (!diagonal) rb[p] = load_tail(row_ptr(tj, ld_row + 32 * p) + k, k, k_end);
         }
     };
-    auto stash = [&](int buf) {
+    auto stash = [&](int buf) __attribute__((always_inline)) {
         float* A = lds + buf * 2 * TILE_FLOATS;
         float* B = A + TILE_FLOATS;
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
-            *reinterpret_cast<f32x4*>(A + (ld_row + 32 * p) * LDS_STRIDE + ld_kq) = ra[p];
-            if (!diagonal) *reinterpret_cast<f32x4*>(B + (ld_row + 32 * p) * LDS_STRIDE + ld_kq) = rb[p];
+            *reinterpret_cast<f32x4*>(A + tile_off<DMA>(ld_row + 32 * p, ld_chunk)) = ra[p];
+            if (!diagonal) *reinterpret_cast<f32x4*>(B + tile_off<DMA>(ld_row + 32 * p, ld_chunk)) = rb[p];
+        }
+    };
+    auto dma = [&](int stage, int buf) __attribute__((always_inline)) {
+        if constexpr (DMA) {
+            const int64_t k = k_begin + static_cast<int64_t>(stage) * BK;
+            float* A = lds + buf * 2 * TILE_FLOATS + (32 * wave) * 32;
+            float* B = A + TILE_FLOATS;
+#pragma unroll
+            for (int p = 0; p < 4; ++p)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src_a[p] + k),
+                                                 (__attribute__((address_space(3))) void*)(A + p * 8 * 32), 16, 0, 0);
+            if (!diagonal) {
+#pragma unroll
+                for (int p = 0; p < 4; ++p)
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src_b[p] + k),
+                                                     (__attribute__((address_space(3))) void*)(B + p * 8 * 32), 16, 0, 0);
+            }
         }
     };
 
     f32x16 acc[2][2];
     constexpr bool kWide = sizeof(PartialT) == 8;
-    double wide[kWide ? 64 : 1];
+    // Long K ranges (kWide): three accumulation levels, so that no fp32 chain is long and no fp64 lives in
+    // registers (128 VGPRs of fp64 sums used to push the kernel to 256 VGPRs with spills):
+    //   level 0  `acc`   MFMA chain of at most kFlushK = 2048 products,
+    //   level 1  `acc2`  fp32 sum of at most kLevel1 = 8 level-0 chains (8 similar-sized terms: ~1e-7),
+    //   level 2  the workgroup's own fp64 slab in global memory, read-modify-written every 16,384 columns.
+    f32x16 acc2[kWide ? 2 : 1][kWide ? 2 : 1];
 #pragma unroll
     for (int m = 0; m < 2; ++m)
 #pragma unroll
@@ -158,14 +197,21 @@ __global__ __launch_bounds__(THREADS, 2) void gram_tile_kernel(const float* __re
             for (int e = 0; e < 16; ++e) acc[m][n][e] = 0.0f;
     if constexpr (kWide) {
 #pragma unroll
-        for (int e = 0; e < 64; ++e) wide[e] = 0.0;
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int n = 0; n < 2; ++n)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc2[m][n][e] = 0.0f;
     }
+    PartialT* out = partial + (static_cast<int64_t>(split) * n_tiles + tile) * (TM * TM);
+    int level1 = 0;          // level-0 chains summed into acc2 since the last slab update
+    bool slab_live = false;  // the slab already holds a partial sum
 
     const int frag_row = lane & 31;
-    const int frag_k = (lane >> 5) * 4;
+    const int frag_half = lane >> 5;
     constexpr int kFlushStages = kFlushK / BK;
 
-    auto compute = [&](int s) {
+    auto compute = [&](int s) __attribute__((always_inline)) {
         const float* A = lds + (s & 1) * 2 * TILE_FLOATS;
         const float* B = diagonal ? A : A + TILE_FLOATS;
 #pragma unroll
@@ -173,10 +219,10 @@ __global__ __launch_bounds__(THREADS, 2) void gram_tile_kernel(const float* __re
             f32x4 a[2], b[2];
 #pragma unroll
             for (int m = 0; m < 2; ++m)
-                a[m] = *reinterpret_cast<const f32x4*>(A + (wr * 64 + m * 32 + frag_row) * LDS_STRIDE + kk * 8 + frag_k);
+                a[m] = *reinterpret_cast<const f32x4*>(A + tile_off<DMA>(wr * 64 + m * 32 + frag_row, 2 * kk + frag_half));
 #pragma unroll
             for (int n = 0; n < 2; ++n)
-                b[n] = *reinterpret_cast<const f32x4*>(B + (wc * 64 + n * 32 + frag_row) * LDS_STRIDE + kk * 8 + frag_k);
+                b[n] = *reinterpret_cast<const f32x4*>(B + tile_off<DMA>(wc * 64 + n * 32 + frag_row, 2 * kk + frag_half));
 #pragma unroll
             for (int t = 0; t < 4; ++t)
 #pragma unroll
@@ -186,7 +232,27 @@ __global__ __launch_bounds__(THREADS, 2) void gram_tile_kernel(const float* __re
                         acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m][t], b[n][t], acc[m][n], 0, 0, 0);
         }
     };
-    auto flush = [&](int s) {
+    auto to_slab = [&](bool last) __attribute__((always_inline)) {
+        if constexpr (kWide) {
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int n = 0; n < 2; ++n)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        const int i = wr * 64 + m * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+                        const int j = wc * 64 + n * 32 + (lane & 31);
+                        double v = static_cast<double>(acc2[m][n][e]);
+                        if (last) v += static_cast<double>(acc[m][n][e]);
+                        if (slab_live) v += out[i * TM + j];
+                        out[i * TM + j] = v;
+                        acc2[m][n][e] = 0.0f;
+                    }
+            slab_live = true;
+            level1 = 0;
+        }
+    };
+    auto flush = [&](int s) __attribute__((always_inline)) {
         if constexpr (kWide) if ((s + 1) % kFlushStages == 0) {
 #pragma unroll
             for (int m = 0; m < 2; ++m)
@@ -194,47 +260,58 @@ __global__ __launch_bounds__(THREADS, 2) void gram_tile_kernel(const float* __re
                 for (int n = 0; n < 2; ++n)
 #pragma unroll
                     for (int e = 0; e < 16; ++e) {
-                        wide[(m * 2 + n) * 16 + e] += static_cast<double>(acc[m][n][e]);
+                        acc2[m][n][e] += acc[m][n][e];
                         acc[m][n][e] = 0.0f;
                     }
+            if (++level1 == kLevel1) to_slab(false);
         }
     };
 
+    // prologue: stage 0 into buffer 0
     if (n_stages > 0) {
-        fetch_any(0);
-        stash(0);
+        if (DMA && n_full > 0) {
+            dma(0, 0);
+        } else {
+            if (n_full > 0) fetch_full(0); else fetch_tail(0);
+            stash(0);
+        }
     }
     __syncthreads();
     int s = 0;
     for (; s + 1 < n_full; ++s) {   // steady state: the next stage is a full one
-        fetch_full(s + 1);
-        compute(s);
-        stash((s + 1) & 1);
-        __syncthreads();
+        if constexpr (DMA) {
+            dma(s + 1, (s + 1) & 1);      // asynchronous: lands in the other buffer while this one multiplies
+            compute(s);
+        } else {
+            fetch_full(s + 1);
+            compute(s);
+            stash((s + 1) & 1);
+        }
+        __syncthreads();                  // with a DMA in flight hipcc waits vmcnt(0) here
         flush(s);
     }
     for (; s < n_stages; ++s) {     // at most two stages: the last full one and the ragged tail
-        if (s + 1 < n_stages) fetch_any(s + 1);
+        if (s + 1 < n_stages) fetch_tail(s + 1);
         compute(s);
         if (s + 1 < n_stages) stash((s + 1) & 1);
         __syncthreads();
         flush(s);
     }
 
-    PartialT* out = partial + (static_cast<int64_t>(split) * n_tiles + tile) * (TM * TM);
+    if constexpr (kWide) {
+        to_slab(true);
+    } else {
 #pragma unroll
-    for (int m = 0; m < 2; ++m)
+        for (int m = 0; m < 2; ++m)
 #pragma unroll
-        for (int n = 0; n < 2; ++n)
+            for (int n = 0; n < 2; ++n)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int i = wr * 64 + m * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
-                const int j = wc * 64 + n * 32 + (lane & 31);
-                if constexpr (kWide)
-                    out[i * TM + j] = static_cast<PartialT>(wide[(m * 2 + n) * 16 + e] + static_cast<double>(acc[m][n][e]));
-                else
+                for (int e = 0; e < 16; ++e) {
+                    const int i = wr * 64 + m * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+                    const int j = wc * 64 + n * 32 + (lane & 31);
                     out[i * TM + j] = static_cast<PartialT>(acc[m][n][e]);
-            }
+                }
+    }
 }
 
 // gram[i][j] = sum over splits (fixed order) of the slab entry of the lower-triangle tile holding (i, j).
@@ -351,12 +428,19 @@ int launch_gram(byz_ctx* ctx, const float* G, int64_t n_rows, int64_t n_cols, in
     {
         KernelTimer t(ctx, BYZ_K_GRAM, stream);
         const int2* order = ctx->tile_order.as<int2>();
-        if (wide)
-            gram_tile_kernel<double><<<static_cast<unsigned>(grid_wgs), THREADS, 0, stream>>>(
-                G, n_rows, n_cols, ld, stages_per_split, ctx->gram_partials.as<double>(), (int)n_tiles, order, (int)per_xcd, (int)splits);
-        else
-            gram_tile_kernel<float><<<static_cast<unsigned>(grid_wgs), THREADS, 0, stream>>>(
-                G, n_rows, n_cols, ld, stages_per_split, ctx->gram_partials.as<float>(), (int)n_tiles, order, (int)per_xcd, (int)splits);
+        // global_load_lds moves 16 bytes per lane: every row segment must be 16-byte aligned
+        const bool dma = (ld % 4 == 0) && (reinterpret_cast<uintptr_t>(G) % 16 == 0) && env_int("BYZ_GRAM_NO_DMA", 0) == 0;
+        const unsigned grid = static_cast<unsigned>(grid_wgs);
+#define BYZ_GRAM(T, D)                                                                                        \
+    gram_tile_kernel<T, D><<<grid, THREADS, 0, stream>>>(G, n_rows, n_cols, ld, stages_per_split,              \
+                                                         ctx->gram_partials.as<T>(), (int)n_tiles, order,       \
+                                                         (int)per_xcd, (int)splits)
+        if (wide) {
+            if (dma) BYZ_GRAM(double, true); else BYZ_GRAM(double, false);
+        } else {
+            if (dma) BYZ_GRAM(float, true); else BYZ_GRAM(float, false);
+        }
+#undef BYZ_GRAM
         BYZ_TRY(check_launch("gram_tile_kernel"));
     }
     {
