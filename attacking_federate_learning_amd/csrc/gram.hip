@@ -315,20 +315,47 @@ __global__ __launch_bounds__(THREADS, 2) void gram_tile_kernel(const float* __re
 }
 
 // gram[i][j] = sum over splits (fixed order) of the slab entry of the lower-triangle tile holding (i, j).
-template <typename PartialT>
+// Q = 1: a block covers 64 columns x 4 rows, one thread per entry.
+// Q = 4: a block covers 64 columns of one row, four threads per entry each summing every fourth slab with four
+//        loads in flight (many slabs, few tiles: one dependent chain per entry was 50 us at 155 slabs).
+// The order of the fp64 additions is fixed either way: the result is deterministic.
+template <typename PartialT, int Q>
 __global__ __launch_bounds__(256) void gram_reduce_kernel(const PartialT* __restrict__ partial, int n_tiles,
                                                           int splits, int64_t n, double* __restrict__ gram) {
-    const int64_t j = static_cast<int64_t>(blockIdx.x) * 64 + (threadIdx.x & 63);
-    const int64_t i = static_cast<int64_t>(blockIdx.y) * 4 + (threadIdx.x >> 6);
-    if (i >= n || j >= n) return;
-    const int64_t hi = i > j ? i : j, lo = i > j ? j : i;
-    const int ti = static_cast<int>(hi / TM), tj = static_cast<int>(lo / TM);
-    const int tile = ti * (ti + 1) / 2 + tj;
-    const int64_t off = static_cast<int64_t>(tile) * (TM * TM) + (hi % TM) * TM + (lo % TM);
+    __shared__ double part[Q == 1 ? 1 : 256];
+    const int jl = threadIdx.x & 63, q = threadIdx.x >> 6;
+    const int64_t j = static_cast<int64_t>(blockIdx.x) * 64 + jl;
+    const int64_t i = Q == 1 ? static_cast<int64_t>(blockIdx.y) * 4 + q : static_cast<int64_t>(blockIdx.y);
+    const bool live = i < n && j < n;
     double s = 0.0;
-    for (int sp = 0; sp < splits; ++sp)
-        s += static_cast<double>(partial[static_cast<int64_t>(sp) * n_tiles * (TM * TM) + off]);
-    gram[i * n + j] = s;
+    if (live) {
+        const int64_t hi = i > j ? i : j, lo = i > j ? j : i;
+        const int ti = static_cast<int>(hi / TM), tj = static_cast<int>(lo / TM);
+        const int tile = ti * (ti + 1) / 2 + tj;
+        const int64_t off = static_cast<int64_t>(tile) * (TM * TM) + (hi % TM) * TM + (lo % TM);
+        const int64_t slab = static_cast<int64_t>(n_tiles) * (TM * TM);
+        if (Q == 1) {
+            for (int sp = 0; sp < splits; ++sp) s += static_cast<double>(partial[sp * slab + off]);
+        } else {
+            double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+            int sp = q;
+            for (; sp + 3 * Q < splits; sp += 4 * Q) {
+                s0 += static_cast<double>(partial[(sp + 0 * Q) * slab + off]);
+                s1 += static_cast<double>(partial[(sp + 1 * Q) * slab + off]);
+                s2 += static_cast<double>(partial[(sp + 2 * Q) * slab + off]);
+                s3 += static_cast<double>(partial[(sp + 3 * Q) * slab + off]);
+            }
+            for (; sp < splits; sp += Q) s0 += static_cast<double>(partial[sp * slab + off]);
+            s = (s0 + s1) + (s2 + s3);
+        }
+    }
+    if (Q == 1) {
+        if (live) gram[i * n + j] = s;
+    } else {
+        part[threadIdx.x] = s;
+        __syncthreads();
+        if (q == 0 && live) gram[i * n + j] = (part[jl] + part[64 + jl]) + (part[128 + jl] + part[192 + jl]);
+    }
 }
 
 __global__ __launch_bounds__(256) void distance_kernel(const double* __restrict__ gram, int64_t n,
@@ -371,7 +398,10 @@ int launch_gram(byz_ctx* ctx, const float* G, int64_t n_rows, int64_t n_cols, in
     // while keeping at least `min_stages` K stages (512 columns) per slab so that slab traffic stays a small
     // fraction of the matrix traffic.
     const int64_t slots = static_cast<int64_t>(ctx->num_cus) * 2;
-    const int64_t min_stages = env_int("BYZ_GRAM_MIN_STAGES", 16);
+    // few tiles and a short K (the reference's own sizes: N = 100, D = 79,510 is ONE tile): allow slabs of 128
+    // columns so that the tile count x slab count still covers the chip
+    int64_t min_stages = env_int("BYZ_GRAM_MIN_STAGES", 0);
+    if (min_stages <= 0) min_stages = n_tiles * (stages / 16) < slots ? 4 : 16;
     int64_t max_splits = stages / min_stages;
     if (max_splits < 1) max_splits = 1;
     if (max_splits > 4096) max_splits = 4096;
@@ -445,11 +475,16 @@ int launch_gram(byz_ctx* ctx, const float* G, int64_t n_rows, int64_t n_cols, in
     }
     {
         KernelTimer t(ctx, BYZ_K_GRAM_REDUCE, stream);
-        dim3 grid(static_cast<unsigned>(ceil_div(n_rows, 64)), static_cast<unsigned>(ceil_div(n_rows, 4)));
-        if (wide)
-            gram_reduce_kernel<double><<<grid, 256, 0, stream>>>(ctx->gram_partials.as<double>(), (int)n_tiles, (int)splits, n_rows, gram);
-        else
-            gram_reduce_kernel<float><<<grid, 256, 0, stream>>>(ctx->gram_partials.as<float>(), (int)n_tiles, (int)splits, n_rows, gram);
+        // four threads per entry only when entries alone cannot fill the chip (the 128 x 128 of one tile)
+        const bool many = splits >= 16 && n_rows * n_rows <= (1 << 18);
+        dim3 grid(static_cast<unsigned>(ceil_div(n_rows, 64)), static_cast<unsigned>(many ? n_rows : ceil_div(n_rows, 4)));
+#define BYZ_REDUCE(T, Q) gram_reduce_kernel<T, Q><<<grid, 256, 0, stream>>>(ctx->gram_partials.as<T>(), (int)n_tiles, (int)splits, n_rows, gram)
+        if (wide) {
+            if (many) BYZ_REDUCE(double, 4); else BYZ_REDUCE(double, 1);
+        } else {
+            if (many) BYZ_REDUCE(float, 4); else BYZ_REDUCE(float, 1);
+        }
+#undef BYZ_REDUCE
         BYZ_TRY(check_launch("gram_reduce_kernel"));
     }
     return BYZ_OK;

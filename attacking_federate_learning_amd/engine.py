@@ -292,8 +292,10 @@ class Engine:
             return self.defend_host('Krum', g, users_count, corrupted_count, check_assert=False)
         idx = ctypes.c_int32(-2)
         out, ptr = (None, None) if return_index else self._out_like(m, m.cols)
+        # the winning row is copied on the device; the index crosses to the host (one sync) only when asked for
         _check(self.lib.byz_krum_dev(self.ctx, _vp(m.ptr), m.rows, m.cols, m.ld, int(users_count),
-                                     int(corrupted_count), 0, _vp(ptr), ctypes.byref(idx), _vp(m.stream)))
+                                     int(corrupted_count), 0, _vp(ptr), ctypes.byref(idx) if return_index else None,
+                                     _vp(m.stream)))
         return int(idx.value) if return_index else out
 
     def _row(self, g, idx):

@@ -69,11 +69,14 @@ class ShardedAggregator:
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        # BYZ_FORCE_COLLECTIVES=1 issues the collectives even at world size 1 (exercises the RCCL path on one GPU)
+        import os
+        self.always_collective = dist.is_initialized() and os.environ.get('BYZ_FORCE_COLLECTIVES') == '1'
 
     # ---- the one exchange step of the path -------------------------------------------------------
     def global_distances(self, g_local):
         gram = self.kernels.gram(g_local)
-        if self.world > 1:
+        if self.world > 1 or self.always_collective:
             self.dist.all_reduce(gram, op=self.dist.ReduceOp.SUM, group=self.group)
         return self.kernels.distances_from_gram(gram)
 
@@ -150,7 +153,7 @@ class ShardedAggregator:
         return out
 
     def _maybe_gather(self, local_vec, gather):
-        if not gather or self.world == 1:
+        if not gather or (self.world == 1 and not self.always_collective):
             return local_vec
         import torch
         sizes = torch.tensor([local_vec.shape[0]], device=local_vec.device, dtype=torch.int64)

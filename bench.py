@@ -341,8 +341,11 @@ def main():
     torch.cuda.set_device(local_rank)
     device = torch.device('cuda', local_rank)
     os.environ.setdefault('BYZ_DEVICE', str(local_rank))
-    if world > 1:
+    if world > 1 or os.environ.get('BYZ_FORCE_COLLECTIVES') == '1':
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29511')
+        os.environ.setdefault('RANK', '0')
+        os.environ.setdefault('WORLD_SIZE', '1')
         dist.init_process_group('nccl', device_id=device)
 
     from attacking_federate_learning_amd.engine import Engine
@@ -399,7 +402,7 @@ def main():
             line['other_workloads'] = extras
     if rank == 0:
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 
