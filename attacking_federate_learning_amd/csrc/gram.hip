@@ -54,6 +54,35 @@ __device__ __forceinline__ f32x4 load_tail(const float* __restrict__ p, int64_t 
     return v;
 }
 
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+// Exact three-way split of eight fp32 values into bf16 planes: x = h + m + l with h, m, l the three 8-bit fields
+// of the 24-bit significand (truncation, so every residual is exact and nothing is rounded away).  Products of two
+// planes are exact in fp32, which is what lets bf16 MFMAs (16x the fp32 MFMA rate) carry an fp32 contraction.
+__device__ __forceinline__ void split8(const f32x4& lo4, const f32x4& hi4, bf16x8& h, bf16x8& m, bf16x8& l) {
+    uint32_t xb[8], r1b[8], r2b[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const float x = e < 4 ? lo4[e] : hi4[e - 4];
+        xb[e] = __float_as_uint(x);
+        const float r1 = x - __uint_as_float(xb[e] & 0xffff0000u);
+        r1b[e] = __float_as_uint(r1);
+        const float r2 = r1 - __uint_as_float(r1b[e] & 0xffff0000u);
+        r2b[e] = __float_as_uint(r2);
+    }
+    u32x4 hp, mp, lp;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {   // pack the high halves of two consecutive values: v_perm_b32
+        hp[e] = __builtin_amdgcn_perm(xb[2 * e + 1], xb[2 * e], 0x07060302u);
+        mp[e] = __builtin_amdgcn_perm(r1b[2 * e + 1], r1b[2 * e], 0x07060302u);
+        lp[e] = __builtin_amdgcn_perm(r2b[2 * e + 1], r2b[2 * e], 0x07060302u);
+    }
+    h = __builtin_bit_cast(bf16x8, hp);
+    m = __builtin_bit_cast(bf16x8, mp);
+    l = __builtin_bit_cast(bf16x8, lp);
+}
+
 // float offset of (row, 16-byte chunk 0..7) inside one operand tile.
 //   register-staged layout: rows padded to 36 floats (conflict-free ds_read_b128);
 //   LDS-DMA layout: rows of exactly 32 floats, because `global_load_lds` writes wave-uniform base + 16 * lane and
@@ -64,7 +93,7 @@ __device__ __forceinline__ int tile_off(int row, int chunk) {
     return DMA ? row * 32 + ((chunk ^ ((row >> 1) & 7)) << 2) : row * LDS_STRIDE + (chunk << 2);
 }
 
-template <typename PartialT, bool DMA>
+template <typename PartialT, bool DMA, bool SPLIT>
 __global__ __launch_bounds__(THREADS, 2) void gram_tile_kernel(const float* __restrict__ G, int64_t n_rows,
                                                                int64_t n_cols, int64_t ld,
                                                                int64_t stages_per_split,
@@ -214,22 +243,58 @@ __global__ __launch_bounds__(THREADS, 2) void gram_tile_kernel(const float* __re
     auto compute = [&](int s) __attribute__((always_inline)) {
         const float* A = lds + (s & 1) * 2 * TILE_FLOATS;
         const float* B = diagonal ? A : A + TILE_FLOATS;
+        if constexpr (SPLIT) {
+            // bf16 x 3: per 16-column step the lane's eight fp32 values of each operand row are split into three
+            // exact bf16 planes in registers, and six bf16 MFMAs per 32 x 32 block form
+            //   h h' + h m' + m h' + m m' + h l' + l h'      (dropped: m l' + l m' + l l' <= 2^-23 |x y|),
+            // smallest terms first.  6 x 32 cycles against 8 x 64 for the fp32 MFMAs of the same 16 columns.
 #pragma unroll
-        for (int kk = 0; kk < BK / 8; ++kk) {
-            f32x4 a[2], b[2];
+            for (int j = 0; j < BK / 16; ++j) {
+                bf16x8 ap[3][2], bp[3][2];   // [plane h, m, l][block]
 #pragma unroll
-            for (int m = 0; m < 2; ++m)
-                a[m] = *reinterpret_cast<const f32x4*>(A + tile_off<DMA>(wr * 64 + m * 32 + frag_row, 2 * kk + frag_half));
+                for (int m = 0; m < 2; ++m) {
+                    const int row = wr * 64 + m * 32 + frag_row;
+                    const f32x4 lo4 = *reinterpret_cast<const f32x4*>(A + tile_off<DMA>(row, 4 * j + 2 * frag_half));
+                    const f32x4 hi4 = *reinterpret_cast<const f32x4*>(A + tile_off<DMA>(row, 4 * j + 2 * frag_half + 1));
+                    split8(lo4, hi4, ap[0][m], ap[1][m], ap[2][m]);
+                }
 #pragma unroll
-            for (int n = 0; n < 2; ++n)
-                b[n] = *reinterpret_cast<const f32x4*>(B + tile_off<DMA>(wc * 64 + n * 32 + frag_row, 2 * kk + frag_half));
+                for (int n = 0; n < 2; ++n) {
+                    const int row = wc * 64 + n * 32 + frag_row;
+                    const f32x4 lo4 = *reinterpret_cast<const f32x4*>(B + tile_off<DMA>(row, 4 * j + 2 * frag_half));
+                    const f32x4 hi4 = *reinterpret_cast<const f32x4*>(B + tile_off<DMA>(row, 4 * j + 2 * frag_half + 1));
+                    split8(lo4, hi4, bp[0][n], bp[1][n], bp[2][n]);
+                }
+                // term-major order: consecutive MFMAs go to the four different accumulators, so none of them
+                // waits for the result of the one before it
+                constexpr int pa[6] = {2, 0, 1, 1, 0, 0};   // plane of the A operand: l h m m h h
+                constexpr int pb[6] = {0, 2, 1, 0, 1, 0};   // plane of the B operand: h l m h m h
 #pragma unroll
-            for (int t = 0; t < 4; ++t)
+                for (int t = 0; t < 6; ++t)
+#pragma unroll
+                    for (int m = 0; m < 2; ++m)
+#pragma unroll
+                        for (int n = 0; n < 2; ++n)
+                            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[pa[t]][m], bp[pb[t]][n], acc[m][n], 0, 0, 0);
+            }
+        } else {
+#pragma unroll
+            for (int kk = 0; kk < BK / 8; ++kk) {
+                f32x4 a[2], b[2];
 #pragma unroll
                 for (int m = 0; m < 2; ++m)
+                    a[m] = *reinterpret_cast<const f32x4*>(A + tile_off<DMA>(wr * 64 + m * 32 + frag_row, 2 * kk + frag_half));
 #pragma unroll
-                    for (int n = 0; n < 2; ++n)
-                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m][t], b[n][t], acc[m][n], 0, 0, 0);
+                for (int n = 0; n < 2; ++n)
+                    b[n] = *reinterpret_cast<const f32x4*>(B + tile_off<DMA>(wc * 64 + n * 32 + frag_row, 2 * kk + frag_half));
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+#pragma unroll
+                    for (int m = 0; m < 2; ++m)
+#pragma unroll
+                        for (int n = 0; n < 2; ++n)
+                            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m][t], b[n][t], acc[m][n], 0, 0, 0);
+            }
         }
     };
     auto to_slab = [&](bool last) __attribute__((always_inline)) {
@@ -461,14 +526,21 @@ int launch_gram(byz_ctx* ctx, const float* G, int64_t n_rows, int64_t n_cols, in
         // global_load_lds moves 16 bytes per lane: every row segment must be 16-byte aligned
         const bool dma = (ld % 4 == 0) && (reinterpret_cast<uintptr_t>(G) % 16 == 0) && env_int("BYZ_GRAM_NO_DMA", 0) == 0;
         const unsigned grid = static_cast<unsigned>(grid_wgs);
-#define BYZ_GRAM(T, D)                                                                                        \
-    gram_tile_kernel<T, D><<<grid, THREADS, 0, stream>>>(G, n_rows, n_cols, ld, stages_per_split,              \
-                                                         ctx->gram_partials.as<T>(), (int)n_tiles, order,       \
-                                                         (int)per_xcd, (int)splits)
+        // BYZ_GRAM_MODE=split: bf16 x 3 MFMAs (fp32-class accuracy, ~2x the fp32 MFMA throughput); default: exact fp32
+        const char* mode = std::getenv("BYZ_GRAM_MODE");
+        const bool split_mode = dma && mode && std::string(mode) == "split";
+#define BYZ_GRAM(T, D, S)                                                                                     \
+    gram_tile_kernel<T, D, S><<<grid, THREADS, 0, stream>>>(G, n_rows, n_cols, ld, stages_per_split,           \
+                                                            ctx->gram_partials.as<T>(), (int)n_tiles, order,    \
+                                                            (int)per_xcd, (int)splits)
         if (wide) {
-            if (dma) BYZ_GRAM(double, true); else BYZ_GRAM(double, false);
+            if (split_mode) BYZ_GRAM(double, true, true);
+            else if (dma) BYZ_GRAM(double, true, false);
+            else BYZ_GRAM(double, false, false);
         } else {
-            if (dma) BYZ_GRAM(float, true); else BYZ_GRAM(float, false);
+            if (split_mode) BYZ_GRAM(float, true, true);
+            else if (dma) BYZ_GRAM(float, true, false);
+            else BYZ_GRAM(float, false, false);
         }
 #undef BYZ_GRAM
         BYZ_TRY(check_launch("gram_tile_kernel"));
