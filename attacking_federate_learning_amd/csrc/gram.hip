@@ -380,6 +380,248 @@ __global__ __launch_bounds__(THREADS, 2) void gram_tile_kernel(const float* __re
 }
 
 // gram[i][j] = sum over splits (fixed order) of the slab entry of the lower-triangle tile holding (i, j).
+// ---------------------------------------------------------------------------------------------------------
+// bf16 x 3 with the split done ONCE per matrix element, at staging time.
+//
+// gram_tile_kernel<.., SPLIT> keeps fp32 in LDS and lets every wave split its own fragments, so each element is
+// split by the two waves that share its row block: 7.9 VALU operations per MFMA, and the VALU pipe (61% busy)
+// was as loaded as the matrix pipe (56%).  Here the workgroup converts each loaded float4 to three bf16 planes
+// before it goes to LDS (3.7 VALU per MFMA) and the waves read ready-made MFMA operands.
+//   LDS: [A | B][plane h, m, l][128 rows][32 bf16] = 48 KB, single-buffered (two workgroups per CU); the next
+//   stage's global loads are in flight in registers while the current stage multiplies.
+//   A row is 64 bytes, so 16 consecutive rows of one 16-byte chunk would hit only four bank groups: the chunk index
+//   is XOR-ed with (row >> 2) & 3 on both the write and the read side.
+// ---------------------------------------------------------------------------------------------------------
+constexpr int PLANE_BYTES = TM * 64;   // 128 rows x 32 bf16
+
+__device__ __forceinline__ int plane_off(int row, int chunk16) {   // byte offset of a 16-byte chunk (8 bf16)
+    return row * 64 + ((chunk16 ^ ((row >> 2) & 3)) << 4);
+}
+
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ void split4(const f32x4& v, u32x2& h, u32x2& m, u32x2& l) {
+    uint32_t xb[4], r1b[4], r2b[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        xb[e] = __float_as_uint(v[e]);
+        const float r1 = v[e] - __uint_as_float(xb[e] & 0xffff0000u);
+        r1b[e] = __float_as_uint(r1);
+        const float r2 = r1 - __uint_as_float(r1b[e] & 0xffff0000u);
+        r2b[e] = __float_as_uint(r2);
+    }
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+        h[e] = __builtin_amdgcn_perm(xb[2 * e + 1], xb[2 * e], 0x07060302u);
+        m[e] = __builtin_amdgcn_perm(r1b[2 * e + 1], r1b[2 * e], 0x07060302u);
+        l[e] = __builtin_amdgcn_perm(r2b[2 * e + 1], r2b[2 * e], 0x07060302u);
+    }
+}
+
+template <typename PartialT>
+__global__ __launch_bounds__(THREADS, 2) void gram_planes_kernel(const float* __restrict__ G, int64_t n_rows,
+                                                                 int64_t n_cols, int64_t ld, int64_t stages_per_split,
+                                                                 PartialT* __restrict__ partial, int n_tiles,
+                                                                 const int2* __restrict__ tile_order, int per_xcd,
+                                                                 int n_splits) {
+    __shared__ __attribute__((aligned(16))) unsigned char planes[2 * 3 * PLANE_BYTES];   // [A | B][h, m, l]
+
+    int split, t_list;
+    if (per_xcd > 0) {
+        const int xcd = blockIdx.x & 7;
+        const int seq = blockIdx.x >> 3;
+        const int base = n_tiles >> 3, rem = n_tiles & 7;
+        const int mine = base + (xcd < rem ? 1 : 0);
+        const int first = xcd * base + (xcd < rem ? xcd : rem);
+        split = seq / mine;
+        if (split >= n_splits) return;
+        t_list = first + (seq - split * mine);
+    } else {
+        split = blockIdx.x / n_tiles;
+        t_list = blockIdx.x - split * n_tiles;
+    }
+    const int2 tt = tile_order[t_list];
+    const int ti = tt.x, tj = tt.y;
+    const int tile = ti * (ti + 1) / 2 + tj;
+    const bool diagonal = (ti == tj);
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 1, wc = wave & 1;
+
+    const int64_t k_begin = static_cast<int64_t>(split) * stages_per_split * BK;
+    int64_t k_end = k_begin + stages_per_split * BK;
+    if (k_end > n_cols) k_end = n_cols;
+    const int n_stages = k_begin < k_end ? static_cast<int>((k_end - k_begin + BK - 1) / BK) : 0;
+    const int n_full = k_begin < k_end ? static_cast<int>((k_end - k_begin) / BK) : 0;
+
+    auto row_ptr = [&](int tile_row0, int local_row) {
+        int64_t r = static_cast<int64_t>(tile_row0) * TM + local_row;
+        if (r > n_rows - 1) r = n_rows - 1;
+        return G + r * ld;
+    };
+    const int ld_chunk = tid & 7;   // float4 within the 32-float row segment
+    const int ld_row = tid >> 3;
+    const float* src_a[4];
+    const float* src_b[4];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        src_a[p] = row_ptr(ti, ld_row + 32 * p) + 4 * ld_chunk;
+        src_b[p] = row_ptr(tj, ld_row + 32 * p) + 4 * ld_chunk;
+    }
+    f32x4 ra[4], rb[4];
+    auto fetch_full = [&](int stage) __attribute__((always_inline)) {
+        const int64_t k = k_begin + static_cast<int64_t>(stage) * BK;
+#pragma unroll
+        for (int p = 0; p < 4; ++p) ra[p] = *reinterpret_cast<const f32x4u*>(src_a[p] + k);
+        if (!diagonal) {
+#pragma unroll
+            for (int p = 0; p < 4; ++p) rb[p] = *reinterpret_cast<const f32x4u*>(src_b[p] + k);
+        }
+    };
+    auto fetch_tail = [&](int stage) __attribute__((always_inline)) {
+        const int64_t k = k_begin + static_cast<int64_t>(stage) * BK + 4 * ld_chunk;
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            ra[p] = load_tail(row_ptr(ti, ld_row + 32 * p) + k, k, k_end);
+            if (!diagonal) rb[p] = load_tail(row_ptr(tj, ld_row + 32 * p) + k, k, k_end);
+        }
+    };
+    auto stash = [&]() __attribute__((always_inline)) {   // split and store: 8 bytes per plane per float4
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const int row = ld_row + 32 * p;
+            const int off = plane_off(row, ld_chunk >> 1) + ((ld_chunk & 1) << 3);
+            u32x2 h, m, l;
+            split4(ra[p], h, m, l);
+            *reinterpret_cast<u32x2*>(planes + 0 * PLANE_BYTES + off) = h;
+            *reinterpret_cast<u32x2*>(planes + 1 * PLANE_BYTES + off) = m;
+            *reinterpret_cast<u32x2*>(planes + 2 * PLANE_BYTES + off) = l;
+            if (!diagonal) {
+                split4(rb[p], h, m, l);
+                *reinterpret_cast<u32x2*>(planes + 3 * PLANE_BYTES + off) = h;
+                *reinterpret_cast<u32x2*>(planes + 4 * PLANE_BYTES + off) = m;
+                *reinterpret_cast<u32x2*>(planes + 5 * PLANE_BYTES + off) = l;
+            }
+        }
+    };
+
+    f32x16 acc[2][2];
+    constexpr bool kWide = sizeof(PartialT) == 8;
+    f32x16 acc2[kWide ? 2 : 1][kWide ? 2 : 1];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[m][n][e] = 0.0f;
+    if constexpr (kWide) {
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int n = 0; n < 2; ++n)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc2[m][n][e] = 0.0f;
+    }
+    PartialT* out = partial + (static_cast<int64_t>(split) * n_tiles + tile) * (TM * TM);
+    int level1 = 0;
+    bool slab_live = false;
+
+    const int frag_row = lane & 31;
+    const int frag_half = lane >> 5;
+    constexpr int kFlushStages = kFlushK / BK;
+
+    auto compute = [&]() __attribute__((always_inline)) {
+        const unsigned char* A = planes;
+        const unsigned char* B = diagonal ? planes : planes + 3 * PLANE_BYTES;
+#pragma unroll
+        for (int j = 0; j < BK / 16; ++j) {
+            bf16x8 ap[3][2], bp[3][2];   // [plane][block]
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+                for (int m = 0; m < 2; ++m) {
+                    ap[pl][m] = *reinterpret_cast<const bf16x8*>(A + pl * PLANE_BYTES + plane_off(wr * 64 + m * 32 + frag_row, 2 * j + frag_half));
+                    bp[pl][m] = *reinterpret_cast<const bf16x8*>(B + pl * PLANE_BYTES + plane_off(wc * 64 + m * 32 + frag_row, 2 * j + frag_half));
+                }
+            constexpr int pa[6] = {2, 0, 1, 1, 0, 0};   // l h m m h h
+            constexpr int pb[6] = {0, 2, 1, 0, 1, 0};   // h l m h m h
+#pragma unroll
+            for (int t = 0; t < 6; ++t)
+#pragma unroll
+                for (int m = 0; m < 2; ++m)
+#pragma unroll
+                    for (int n = 0; n < 2; ++n)
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[pa[t]][m], bp[pb[t]][n], acc[m][n], 0, 0, 0);
+        }
+    };
+    auto to_slab = [&](bool last) __attribute__((always_inline)) {
+        if constexpr (kWide) {
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int n = 0; n < 2; ++n)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        const int i = wr * 64 + m * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+                        const int j = wc * 64 + n * 32 + (lane & 31);
+                        double v = static_cast<double>(acc2[m][n][e]);
+                        if (last) v += static_cast<double>(acc[m][n][e]);
+                        if (slab_live) v += out[i * TM + j];
+                        out[i * TM + j] = v;
+                        acc2[m][n][e] = 0.0f;
+                    }
+            slab_live = true;
+            level1 = 0;
+        }
+    };
+    auto flush = [&](int s) __attribute__((always_inline)) {
+        if constexpr (kWide) if ((s + 1) % kFlushStages == 0) {
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int n = 0; n < 2; ++n)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        acc2[m][n][e] += acc[m][n][e];
+                        acc[m][n][e] = 0.0f;
+                    }
+            if (++level1 == kLevel1) to_slab(false);
+        }
+    };
+
+    if (n_stages > 0) {
+        if (n_full > 0) fetch_full(0); else fetch_tail(0);
+        stash();
+    }
+    __syncthreads();
+    for (int s = 0; s < n_stages; ++s) {
+        if (s + 1 < n_full) fetch_full(s + 1);          // in flight while this stage multiplies
+        else if (s + 1 < n_stages) fetch_tail(s + 1);
+        compute();
+        __syncthreads();                                 // every wave is done reading the planes
+        if (s + 1 < n_stages) stash();
+        __syncthreads();
+        flush(s);
+    }
+
+    if constexpr (kWide) {
+        to_slab(true);
+    } else {
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int n = 0; n < 2; ++n)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int i = wr * 64 + m * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+                    const int j = wc * 64 + n * 32 + (lane & 31);
+                    out[i * TM + j] = static_cast<PartialT>(acc[m][n][e]);
+                }
+    }
+}
+
 // Q = 1: a block covers 64 columns x 4 rows, one thread per entry.
 // Q = 4: a block covers 64 columns of one row, four threads per entry each summing every fourth slab with four
 //        loads in flight (many slabs, few tiles: one dependent chain per entry was 50 us at 155 slabs).
@@ -529,11 +771,17 @@ int launch_gram(byz_ctx* ctx, const float* G, int64_t n_rows, int64_t n_cols, in
         // BYZ_GRAM_MODE=split: bf16 x 3 MFMAs (fp32-class accuracy, ~2x the fp32 MFMA throughput); default: exact fp32
         const char* mode = std::getenv("BYZ_GRAM_MODE");
         const bool split_mode = dma && mode && std::string(mode) == "split";
+        const bool planes_mode = mode && std::string(mode) == "planes";
 #define BYZ_GRAM(T, D, S)                                                                                     \
     gram_tile_kernel<T, D, S><<<grid, THREADS, 0, stream>>>(G, n_rows, n_cols, ld, stages_per_split,           \
                                                             ctx->gram_partials.as<T>(), (int)n_tiles, order,    \
                                                             (int)per_xcd, (int)splits)
-        if (wide) {
+        if (planes_mode) {
+            if (wide)
+                gram_planes_kernel<double><<<grid, THREADS, 0, stream>>>(G, n_rows, n_cols, ld, stages_per_split, ctx->gram_partials.as<double>(), (int)n_tiles, order, (int)per_xcd, (int)splits);
+            else
+                gram_planes_kernel<float><<<grid, THREADS, 0, stream>>>(G, n_rows, n_cols, ld, stages_per_split, ctx->gram_partials.as<float>(), (int)n_tiles, order, (int)per_xcd, (int)splits);
+        } else if (wide) {
             if (split_mode) BYZ_GRAM(double, true, true);
             else if (dma) BYZ_GRAM(double, true, false);
             else BYZ_GRAM(double, false, false);
