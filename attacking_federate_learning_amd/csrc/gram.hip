@@ -768,10 +768,17 @@ int launch_gram(byz_ctx* ctx, const float* G, int64_t n_rows, int64_t n_cols, in
         // global_load_lds moves 16 bytes per lane: every row segment must be 16-byte aligned
         const bool dma = (ld % 4 == 0) && (reinterpret_cast<uintptr_t>(G) % 16 == 0) && env_int("BYZ_GRAM_NO_DMA", 0) == 0;
         const unsigned grid = static_cast<unsigned>(grid_wgs);
-        // BYZ_GRAM_MODE=split: bf16 x 3 MFMAs (fp32-class accuracy, ~2x the fp32 MFMA throughput); default: exact fp32
+        // Arithmetic of the contraction (BYZ_GRAM_MODE overrides):
+        //   exact   fp32-input MFMA, bit-for-bit an fmaf chain; the default while the problem is one or two tiles
+        //           wide (N <= 256), where the kernel is launch/HBM bound anyway;
+        //   split   bf16 x 3: every fp32 value is split exactly into three bf16 planes and six bf16 MFMAs per block
+        //           stand in for the fp32 product (error <= 2^-23 |x y| per product, the size of one fp32 rounding);
+        //           1.25x the throughput of `exact` at N = 4000.  Default for N > 256.
+        //   planes  the same arithmetic with the split done once per element at staging time (experimental).
         const char* mode = std::getenv("BYZ_GRAM_MODE");
-        const bool split_mode = dma && mode && std::string(mode) == "split";
-        const bool planes_mode = mode && std::string(mode) == "planes";
+        const std::string mode_s = mode ? mode : (n_tiles >= 4 ? "split" : "exact");
+        const bool split_mode = dma && mode_s == "split";
+        const bool planes_mode = mode_s == "planes";
 #define BYZ_GRAM(T, D, S)                                                                                     \
     gram_tile_kernel<T, D, S><<<grid, THREADS, 0, stream>>>(G, n_rows, n_cols, ld, stages_per_split,           \
                                                             ctx->gram_partials.as<T>(), (int)n_tiles, order,    \
