@@ -44,6 +44,8 @@
 
 #include "lane_exchange.hpp"
 
+#include <cstdlib>
+
 namespace byz {
 namespace {
 
@@ -52,10 +54,8 @@ using namespace lanes;
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
 
-constexpr int kCols = 16;                 // columns per tile
+constexpr int kCols = 16;                 // columns per tile (4 waves x 4 columns, or 16 waves x 1 column)
 constexpr int kStride = 20;               // floats per LDS row: 16-byte aligned, b128 column reads conflict-free
-constexpr int kThreads = 256;             // 4 waves x 4 columns
-constexpr int kWaves = kThreads / 64;
 constexpr int kMaxRpl = 40;               // 2560 rows
 constexpr int kArithProbes = 12;          // value-space probes before switching to key-space midpoints
 constexpr int kCand = 16;                 // candidates per column handed to the sorting network
@@ -146,8 +146,8 @@ __device__ __forceinline__ float lane_value(float v, int src) {   // src is wave
 // bracket of column l & 3, so choosing the four next probes and absorbing the four counts costs one pass
 // of ~100 vector instructions, not four scalar ones with their branches.  Only the counting passes, the
 // compaction and the rare pivot search are per column.
-template <int RPL, bool ABS>
-__device__ __forceinline__ void select4(const float (&x)[4][RPL], int groups, int slots, int r, bool want_next,
+template <int RPL, int NC, bool ABS>
+__device__ __forceinline__ void select4(const float (&x)[NC][RPL], int groups, int slots, int r, bool want_next,
                                         Bracket (&q)[4], int lane, float* strip) {
     constexpr int GS = RPL >= 4 ? 4 : RPL;
     const int col = lane & 3;
@@ -159,7 +159,7 @@ __device__ __forceinline__ void select4(const float (&x)[4][RPL], int groups, in
     float hi = by_column(col, q[0].hi, q[1].hi, q[2].hi, q[3].hi);
     int c_lo = by_column(col, q[0].c_lo, q[1].c_lo, q[2].c_lo, q[3].c_lo);
     int c_hi = by_column(col, q[0].c_hi, q[1].c_hi, q[2].c_hi, q[3].c_hi);
-    int state = (c_hi - c_lo <= kCand) ? 1 : 0;   // 0 probing, 1 <= kCand candidates, 2 resolved, 3 split at T
+    int state = col >= NC ? 2 : ((c_hi - c_lo <= kCand) ? 1 : 0);   // 0 probing, 1 <= kCand candidates, 2 resolved, 3 split at T
     int last = 0, stalled = 0, probes = 0;
     float T = hi, res_a = 0.0f, res_b = 0.0f;
 
@@ -189,7 +189,7 @@ __device__ __forceinline__ void select4(const float (&x)[4][RPL], int groups, in
             const unsigned pivots = static_cast<unsigned>(__ballot(state == 0 && stalled && arith) & 0xFull);
             if (pivots) {
 #pragma unroll
-                for (int c = 0; c < 4; ++c) {
+                for (int c = 0; c < NC; ++c) {
                     if ((pivots >> c) & 1u) {
                         const float lo_c = lane_value(lo, c), hi_c = lane_value(hi, c);
                         bool have = false;
@@ -215,7 +215,7 @@ __device__ __forceinline__ void select4(const float (&x)[4][RPL], int groups, in
         // ---- counting pass: for each column still probing, the values greater than its probe
         uint32_t neg[4] = {0u, 0u, 0u, 0u};
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
+        for (int c = 0; c < NC; ++c) {
             if (__builtin_amdgcn_readlane(state, c) == 0) {
                 const float Tc = lane_value(T, c);
                 uint32_t n0 = 0u;
@@ -254,7 +254,7 @@ __device__ __forceinline__ void select4(const float (&x)[4][RPL], int groups, in
     }
     // ---- a probe that fell exactly between ranks r and r + 1: the neighbours on both sides
 #pragma unroll
-    for (int c = 0; c < 4; ++c) {
+    for (int c = 0; c < NC; ++c) {
         if (__builtin_amdgcn_readlane(state, c) == 3) {
             const float Tc = lane_value(T, c);
             float below = -pinf, above = pinf;
@@ -281,7 +281,7 @@ __device__ __forceinline__ void select4(const float (&x)[4][RPL], int groups, in
     int valid[4] = {0, 0, 0, 0};
     const unsigned to_sort = static_cast<unsigned>(__ballot(state == 1) & 0xFull);
 #pragma unroll
-    for (int c = 0; c < 4; ++c) {
+    for (int c = 0; c < NC; ++c) {
         if ((to_sort >> c) & 1u) {
             const float lo_next = uniform(from_fkey(fkey(lane_value(lo, c)) + 1u)), hi_c = lane_value(hi, c);
             int n_cand = 0;
@@ -388,35 +388,41 @@ __device__ __forceinline__ float tied_window_sum(const float (&v)[RPL], int grou
     return sum;
 }
 
-template <int RPL>
-__global__ __launch_bounds__(kThreads, (RPL <= 16 ? 4 : 2)) void median_window_kernel(
+// NC columns per wave, WAVES waves per workgroup, WAVES * NC = 16 columns per tile.  NC = 4 (4 waves) holds up to
+// 2560 rows; NC = 1 (16 waves, one column each) trades the amortisation of the probe bookkeeping for register space
+// and holds up to 5632 rows (Bulyan's second stage at N = 10,000: theta = 5200).
+template <int RPL, int NC, int WAVES>
+__global__ __launch_bounds__(64 * WAVES, (RPL * NC <= 64 ? 4 : (WAVES == 16 ? 4 : 2))) void median_window_kernel(
     const float* __restrict__ G, int n_rows, int64_t n_cols, int64_t ld, const int32_t* __restrict__ row_index,
     int keep, float* __restrict__ out) {
     constexpr int JC = RPL >= 4 ? 4 : RPL;   // registers (64-row groups) per transit chunk == guard group
     constexpr int NCH = RPL / JC;
     constexpr int GS = JC;
-    __shared__ __attribute__((aligned(16))) float transit[64 * JC * kStride + kWaves * 64 + 16];
+    constexpr int QUADS = kCols / 4;
+    constexpr int THREADS_ = 64 * WAVES;
+    constexpr int ROWS_PER_PASS = THREADS_ / QUADS;   // rows one staging pass of the workgroup covers
+    __shared__ __attribute__((aligned(16))) float transit[64 * JC * kStride + WAVES * 64 + 16];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     float* strip = transit + 64 * JC * kStride + wave * 64;
-    int* nonfinite = reinterpret_cast<int*>(transit + 64 * JC * kStride + kWaves * 64);   // one flag per column quad
+    int* nonfinite = reinterpret_cast<int*>(transit + 64 * JC * kStride + WAVES * 64);   // one flag per column quad
     const int64_t c_base = static_cast<int64_t>(blockIdx.x) * kCols;
     const float pinf = __builtin_inff();
     const float qnan = __uint_as_float(0x7fc00000u);
     const int chunks = (n_rows + 64 * JC - 1) / (64 * JC);   // == guard groups in use
     const int slots = chunks * 64 * JC;
 
-    if (tid < kWaves) nonfinite[tid] = 0;
+    if (tid < QUADS) nonfinite[tid] = 0;
 
     // ---- stage: global (128-byte row segments) -> LDS transit -> registers (4 columns x RPL rows per lane)
-    constexpr int QUADS = kCols / 4;
     const int ld_q = (tid % QUADS) * 4, ld_r = tid / QUADS;
     const int64_t ld_c = c_base + ld_q;
-    f32x4 tmp[JC];
+    constexpr int PASSES = 64 * JC / ROWS_PER_PASS;   // float4 loads per thread per chunk
+    f32x4 tmp[PASSES];
     float poison = 0.0f;   // x * 0 accumulates to NaN as soon as one loaded value is NaN or +-inf
     auto fetch = [&](int ch) {
 #pragma unroll
-        for (int p = 0; p < JC; ++p) {
-            const int row = ch * 64 * JC + 64 * p + ld_r;
+        for (int p = 0; p < PASSES; ++p) {
+            const int row = ch * 64 * JC + ROWS_PER_PASS * p + ld_r;
             f32x4 val = {pinf, pinf, pinf, pinf};
             if (row < n_rows) {
                 const int64_t src = row_index ? row_index[row] : row;
@@ -435,17 +441,17 @@ __global__ __launch_bounds__(kThreads, (RPL <= 16 ? 4 : 2)) void median_window_k
     };
     auto stash = [&](int ch) {
 #pragma unroll
-        for (int p = 0; p < JC; ++p) {
+        for (int p = 0; p < PASSES; ++p) {
             const f32x4 val = tmp[p];
-            if (ch * 64 * JC + 64 * p + ld_r < n_rows)
+            if (ch * 64 * JC + ROWS_PER_PASS * p + ld_r < n_rows)
                 poison = __builtin_fmaf(val.x + val.y, 0.0f, __builtin_fmaf(val.z + val.w, 0.0f, poison));
-            *reinterpret_cast<f32x4*>(transit + (64 * p + ld_r) * kStride + ld_q) = val;
+            *reinterpret_cast<f32x4*>(transit + (ROWS_PER_PASS * p + ld_r) * kStride + ld_q) = val;
         }
     };
-    float x[4][RPL];
-    float mn[4], mx[4];
+    float x[NC][RPL];
+    float mn[NC], mx[NC];
 #pragma unroll
-    for (int c = 0; c < 4; ++c) {
+    for (int c = 0; c < NC; ++c) {
         mn[c] = pinf;
         mx[c] = -pinf;
     }
@@ -459,10 +465,16 @@ __global__ __launch_bounds__(kThreads, (RPL <= 16 ? 4 : 2)) void median_window_k
             const bool last_chunk = ch == chunks - 1;   // uniform: only this chunk can hold padding rows
 #pragma unroll
             for (int jj = 0; jj < JC; ++jj) {
-                const f32x4 val = *reinterpret_cast<const f32x4*>(transit + (64 * jj + lane) * kStride + 4 * wave);
+                float val[NC];
+                if constexpr (NC == 4) {
+                    const f32x4 v4 = *reinterpret_cast<const f32x4*>(transit + (64 * jj + lane) * kStride + 4 * wave);
+                    val[0] = v4.x; val[1 % NC] = v4.y; val[2 % NC] = v4.z; val[3 % NC] = v4.w;
+                } else {
+                    val[0] = transit[(64 * jj + lane) * kStride + wave];
+                }
                 const bool real = !last_chunk || (ch * 64 * JC + 64 * jj + lane < n_rows);
 #pragma unroll
-                for (int c = 0; c < 4; ++c) {
+                for (int c = 0; c < NC; ++c) {
                     const float e = val[c];
                     x[c][ch * JC + jj] = e;
                     mn[c] = __builtin_fminf(mn[c], e);                 // +inf padding never wins a minimum
@@ -474,12 +486,12 @@ __global__ __launch_bounds__(kThreads, (RPL <= 16 ? 4 : 2)) void median_window_k
     }
     if (poison != poison) nonfinite[tid % QUADS] = 1;
     __syncthreads();
-    const bool suspicious = uniform(nonfinite[wave]) != 0;   // an LDS load is per-lane to the compiler: make it scalar
+    const bool suspicious = uniform(nonfinite[NC == 4 ? wave : wave / 4]) != 0;   // an LDS load is per-lane to the compiler: make it scalar
 
     Bracket q[4];
-    bool dead[4];       // the column's result is NaN
+    bool dead[NC];       // the column's result is NaN
 #pragma unroll
-    for (int c = 0; c < 4; ++c) {
+    for (int c = 0; c < NC; ++c) {
         dead[c] = keep <= 0;   // np.mean([]) is nan
         if (suspicious) {
             int n_nan = 0;
@@ -498,9 +510,9 @@ __global__ __launch_bounds__(kThreads, (RPL <= 16 ? 4 : 2)) void median_window_k
     }
 
     // ---- median (defences.py:49)
-    float med[4], lo_x[4], hi_x[4];
+    float med[NC], lo_x[NC], hi_x[NC];
 #pragma unroll
-    for (int c = 0; c < 4; ++c) {
+    for (int c = 0; c < NC; ++c) {
         lo_x[c] = wave_min(mn[c]);
         hi_x[c] = wave_max(mx[c]);
         q[c].hi = hi_x[c];
@@ -524,9 +536,9 @@ __global__ __launch_bounds__(kThreads, (RPL <= 16 ? 4 : 2)) void median_window_k
     }
     const bool even = (n_rows & 1) == 0;
     const int r_med = even ? (n_rows >> 1) - 1 : (n_rows - 1) >> 1;
-    bool run_med[4];
+    bool run_med[NC];
 #pragma unroll
-    for (int c = 0; c < 4; ++c) {
+    for (int c = 0; c < NC; ++c) {
         // more -inf than the median rank: the median is -inf and every deviation is NaN or +inf
         run_med[c] = !dead[c] && q[c].c_lo <= r_med;
         if (!run_med[c]) {
@@ -537,14 +549,16 @@ __global__ __launch_bounds__(kThreads, (RPL <= 16 ? 4 : 2)) void median_window_k
             q[c].c_hi = 0;
         }
     }
-    select4<RPL, false>(x, chunks, slots, r_med, even, q, lane, strip);
 #pragma unroll
-    for (int c = 0; c < 4; ++c) med[c] = uniform(even ? __fmul_rn(__fadd_rn(q[c].a, q[c].b), 0.5f) : q[c].a);
+    for (int c = NC; c < 4; ++c) q[c] = Bracket{0.0f, 0.0f, 0, 0, 0.0f, 0.0f};
+    select4<RPL, NC, false>(x, chunks, slots, r_med, even, q, lane, strip);
+#pragma unroll
+    for (int c = 0; c < NC; ++c) med[c] = uniform(even ? __fmul_rn(__fadd_rn(q[c].a, q[c].b), 0.5f) : q[c].a);
 
     // ---- deviations in place (defences.py:50: column - med); rounding is monotone, so the largest
     // |deviation| belongs to one of the extremes.  Padding stays +inf.
 #pragma unroll
-    for (int c = 0; c < 4; ++c) {
+    for (int c = 0; c < NC; ++c) {
 #pragma unroll
         for (int g = 0; g < RPL / GS; ++g) {
             if (g < chunks) {
@@ -566,12 +580,12 @@ __global__ __launch_bounds__(kThreads, (RPL <= 16 ? 4 : 2)) void median_window_k
         }
     }
     // ---- t = the keep-th smallest |deviation|
-    select4<RPL, true>(x, chunks, slots, keep - 1, false, q, lane, strip);
+    select4<RPL, NC, true>(x, chunks, slots, keep - 1, false, q, lane, strip);
 
     // ---- window sum: everything with |d| <= t, when that is exactly `keep` values
-    float result[4];
+    float result[NC];
 #pragma unroll
-    for (int c = 0; c < 4; ++c) {
+    for (int c = 0; c < NC; ++c) {
         const float t = q[c].a;
         float acc = 0.0f;
         int n_in = 0;
@@ -594,18 +608,19 @@ __global__ __launch_bounds__(kThreads, (RPL <= 16 ? 4 : 2)) void median_window_k
         // defences.py:51: np.mean(good) + med
         result[c] = dead[c] ? qnan : __fadd_rn(__fdiv_rn(sum, static_cast<float>(keep)), med[c]);
     }
-    if (lane < 4) {
-        const int64_t col = c_base + 4 * wave + lane;
-        const float r = lane == 0 ? result[0] : (lane == 1 ? result[1] : (lane == 2 ? result[2] : result[3]));
+    if (lane < NC) {
+        const int64_t col = c_base + NC * wave + lane;
+        float r = result[0];
+        if constexpr (NC == 4) r = lane == 0 ? result[0] : (lane == 1 ? result[1] : (lane == 2 ? result[2] : result[3]));
         if (col < n_cols) out[col] = r;
     }
 }
 
-template <int RPL>
+template <int RPL, int NC, int WAVES>
 int launch_rpl(const float* G, int64_t n_rows, int64_t n_cols, int64_t ld, const int32_t* row_index, int64_t keep,
                float* out, hipStream_t stream) {
     const int64_t n_tiles = ceil_div(n_cols, kCols);
-    median_window_kernel<RPL><<<static_cast<unsigned>(n_tiles), kThreads, 0, stream>>>(
+    median_window_kernel<RPL, NC, WAVES><<<static_cast<unsigned>(n_tiles), 64 * WAVES, 0, stream>>>(
         G, static_cast<int>(n_rows), n_cols, ld, row_index, static_cast<int>(keep), out);
     return check_launch("median_window_kernel");
 }
@@ -623,15 +638,22 @@ int launch_trimmed_mean(byz_ctx* ctx, const float* G, int64_t n_rows, int64_t n_
     BYZ_REQUIRE(ceil_div(n_cols, kCols) <= 0x7fffffff, "trimmed_mean: too many columns");
     KernelTimer t(ctx, BYZ_K_TRIMMED_MEAN, stream);
     const int64_t rpl = ceil_div(n_rows, 64);
-    if (rpl > kMaxRpl) return launch_trimmed_mean_sorted(ctx, G, n_rows, n_cols, ld, row_index, keep, out, stream);
-    if (rpl <= 1) return launch_rpl<1>(G, n_rows, n_cols, ld, row_index, keep, out, stream);
-    if (rpl <= 2) return launch_rpl<2>(G, n_rows, n_cols, ld, row_index, keep, out, stream);
-    if (rpl <= 4) return launch_rpl<4>(G, n_rows, n_cols, ld, row_index, keep, out, stream);
-    if (rpl <= 8) return launch_rpl<8>(G, n_rows, n_cols, ld, row_index, keep, out, stream);
-    if (rpl <= 16) return launch_rpl<16>(G, n_rows, n_cols, ld, row_index, keep, out, stream);
-    if (rpl <= 24) return launch_rpl<24>(G, n_rows, n_cols, ld, row_index, keep, out, stream);
-    if (rpl <= 32) return launch_rpl<32>(G, n_rows, n_cols, ld, row_index, keep, out, stream);
-    return launch_rpl<40>(G, n_rows, n_cols, ld, row_index, keep, out, stream);
+    {   // experiment knob: from this many 64-row groups on, use the one-column-per-wave variant
+        const char* e = std::getenv("BYZ_TM_NC1_FROM");
+        const int64_t from = e ? std::atoll(e) : 41;
+        if (rpl >= from && rpl <= 64) return launch_rpl<64, 1, 16>(G, n_rows, n_cols, ld, row_index, keep, out, stream);
+    }
+    if (rpl > 88) return launch_trimmed_mean_sorted(ctx, G, n_rows, n_cols, ld, row_index, keep, out, stream);
+    if (rpl <= 1) return launch_rpl<1, 4, 4>(G, n_rows, n_cols, ld, row_index, keep, out, stream);
+    if (rpl <= 2) return launch_rpl<2, 4, 4>(G, n_rows, n_cols, ld, row_index, keep, out, stream);
+    if (rpl <= 4) return launch_rpl<4, 4, 4>(G, n_rows, n_cols, ld, row_index, keep, out, stream);
+    if (rpl <= 8) return launch_rpl<8, 4, 4>(G, n_rows, n_cols, ld, row_index, keep, out, stream);
+    if (rpl <= 16) return launch_rpl<16, 4, 4>(G, n_rows, n_cols, ld, row_index, keep, out, stream);
+    if (rpl <= 24) return launch_rpl<24, 4, 4>(G, n_rows, n_cols, ld, row_index, keep, out, stream);
+    if (rpl <= 32) return launch_rpl<32, 4, 4>(G, n_rows, n_cols, ld, row_index, keep, out, stream);
+    if (rpl <= kMaxRpl) return launch_rpl<40, 4, 4>(G, n_rows, n_cols, ld, row_index, keep, out, stream);
+    if (rpl <= 64) return launch_rpl<64, 1, 16>(G, n_rows, n_cols, ld, row_index, keep, out, stream);
+    return launch_rpl<88, 1, 16>(G, n_rows, n_cols, ld, row_index, keep, out, stream);
 }
 
 }  // namespace byz

@@ -194,7 +194,8 @@ def test_trimmed_mean_heavy_ties_match_the_reference_rule(eng, n, c):
     assert close(eng.trimmed_mean(g, n, c), want)
 
 
-@pytest.mark.parametrize('n,d', [(1025, 64), (1500, 130), (2080, 257), (4096, 36)])
+@pytest.mark.parametrize('n,d', [(1025, 64), (1500, 130), (2080, 257), (2561, 40), (4096, 36), (5200, 50), (5632, 17),
+                                 (6000, 20)])
 def test_trimmed_mean_general_kernel(eng, n, d):
     g = gaussian(6000 + n, n, d)
     c = n // 4
