@@ -136,6 +136,8 @@ void byz_ctx_destroy(byz_ctx* ctx) {
     ctx->gram_partials.release();
     ctx->gram.release();
     ctx->tile_order.release();
+    ctx->gram_tickets.release();
+    ctx->dup_rep.release();
     ctx->dist.release();
     ctx->colstat_partials.release();
     ctx->sorted_idx.release();

@@ -97,6 +97,8 @@ struct byz_ctx {
     byz::Buffer gram_partials;   // split-K slabs of the Gram kernel
     byz::Buffer gram;            // n x n fp64 Gram
     byz::Buffer tile_order;      // (ti, tj) of every lower-triangle tile, in XCD-friendly order
+    byz::Buffer dup_rep;         // representative row of every group of identical rows (+ one flag word)
+    byz::Buffer gram_tickets;    // chunked Gram schedule: next chunk allowed to update a tile's slab
     std::vector<int32_t> tile_order_host;
     int64_t tile_order_T = -1;
     byz::Buffer dist;            // n x n fp32 distances (when the caller does not pass one)

@@ -98,7 +98,8 @@ __global__ __launch_bounds__(THREADS, 2) void gram_tile_kernel(const float* __re
                                                                int64_t n_cols, int64_t ld,
                                                                int64_t stages_per_split,
                                                                PartialT* __restrict__ partial, int n_tiles,
-                                                               const int2* __restrict__ tile_order, int per_xcd, int n_splits) {
+                                                               const int2* __restrict__ tile_order, int per_xcd, int n_splits,
+                                                               int* __restrict__ tickets) {
     __shared__ __attribute__((aligned(16))) float lds[2 * 2 * TILE_FLOATS];  // [2 buffers][A | B][TM][row]
 
     // Workgroup -> (tile, K split).  Workgroups are dealt to the 8 XCDs round-robin (observed; only speed
@@ -232,13 +233,26 @@ __global__ __launch_bounds__(THREADS, 2) void gram_tile_kernel(const float* __re
 #pragma unroll
                 for (int e = 0; e < 16; ++e) acc2[m][n][e] = 0.0f;
     }
-    PartialT* out = partial + (static_cast<int64_t>(split) * n_tiles + tile) * (TM * TM);
+    // Two schedules share this kernel.
+    //   split-K (tickets == nullptr): `split` indexes one of n_splits slabs per tile; gram_reduce_kernel adds them.
+    //   chunked (tickets != nullptr): `split` is a K chunk of 8,192 columns and all chunks of a tile accumulate, in
+    //   chunk order, into the tile's ONE fp64 slab (ticket per tile, see the epilogue).  Short workgroups that start
+    //   together stay within a few stages of each other, so the ~64 workgroups an XCD runs at a time really do
+    //   share their 8 + 8 operand row blocks in its L2: with split-K over 322,000 columns (N = 4000, D = 1e7) they
+    //   drifted apart and the L2 hit rate was 5% (5.0 TB of fabric reads for a 160 GB matrix).
+    const bool chunked = tickets != nullptr;
+    PartialT* out = partial + (chunked ? static_cast<int64_t>(tile) : static_cast<int64_t>(split) * n_tiles + tile) * (TM * TM);
     int level1 = 0;          // level-0 chains summed into acc2 since the last slab update
     bool slab_live = false;  // the slab already holds a partial sum
 
     const int frag_row = lane & 31;
     const int frag_half = lane >> 5;
-    constexpr int kFlushStages = kFlushK / BK;
+    // The bf16 MFMAs add into their fp32 accumulator with truncation, not round-to-nearest (measured: a 2048-column
+    // chain of squares comes out 2e-6 low, the fp32-input MFMA 1e-7 either way; the dropped split terms explain only
+    // 5e-8).  The bias grows with the chain length, so split mode keeps level-0 chains at 256 columns and lets the
+    // round-to-nearest VALU additions of level 1 carry up to 64 of them.
+    constexpr int kFlushStages = SPLIT ? 8 : kFlushK / BK;
+    constexpr int kLevel1Count = SPLIT ? 64 : kLevel1;   // a chunk of the chunked schedule (8192 columns) never reaches it
 
     auto compute = [&](int s) __attribute__((always_inline)) {
         const float* A = lds + (s & 1) * 2 * TILE_FLOATS;
@@ -328,7 +342,7 @@ __global__ __launch_bounds__(THREADS, 2) void gram_tile_kernel(const float* __re
                         acc2[m][n][e] += acc[m][n][e];
                         acc[m][n][e] = 0.0f;
                     }
-            if (++level1 == kLevel1) to_slab(false);
+            if (++level1 == kLevel1Count) to_slab(false);
         }
     };
 
@@ -364,7 +378,33 @@ __global__ __launch_bounds__(THREADS, 2) void gram_tile_kernel(const float* __re
     }
 
     if constexpr (kWide) {
-        to_slab(true);
+        if (chunked) {
+            // wait for the previous chunk of this tile (dispatched earlier, so it is running or done), then
+            // read-modify-write the slab, then pass the ticket on.  Release/acquire at agent scope: the slab lines
+            // may sit in another CU's L1 or be dirty in L2 (MI355X_MICROARCH.md, inter-workgroup visibility).
+            if (split > 0) {
+                if (tid == 0) {
+                    unsigned spins = 0;
+                    while (__hip_atomic_load(tickets + tile, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != split) {
+                        __builtin_amdgcn_s_sleep(8);
+                        if (++spins > (1u << 26)) break;   // bounded: a lost ticket must not hang the device
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                }
+                __syncthreads();
+                slab_live = true;
+            }
+            to_slab(true);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (tid == 0) {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __hip_atomic_store(tickets + tile, split + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        } else {
+            to_slab(true);
+        }
     } else {
 #pragma unroll
         for (int m = 0; m < 2; ++m)
@@ -379,7 +419,6 @@ __global__ __launch_bounds__(THREADS, 2) void gram_tile_kernel(const float* __re
     }
 }
 
-// gram[i][j] = sum over splits (fixed order) of the slab entry of the lower-triangle tile holding (i, j).
 // ---------------------------------------------------------------------------------------------------------
 // bf16 x 3 with the split done ONCE per matrix element, at staging time.
 //
@@ -681,6 +720,45 @@ __global__ __launch_bounds__(256) void distance_kernel(const double* __restrict_
     dist[i * n + j] = d;
 }
 
+// Identical rows (every malicious client submits the same vector, malicious.py:26-27) must keep bitwise identical
+// distance rows, because the reference resolves their exactly tied Krum scores by visit order.  The fp32-input MFMA
+// gives that for free (a * b is computed the same way whichever operand a row is); the bf16 x 3 arithmetic does not
+// (its six terms are accumulated in an order that depends on which operand a row is), although it still gives
+// d_pq == 0 exactly for identical rows p, q.  So duplicates are recognised by d == 0 and every member of a group
+// takes the distances of the group's first row: rep[i] = the smallest j with d_ij == 0 (or i itself).
+__global__ __launch_bounds__(256) void duplicate_rep_kernel(const float* __restrict__ dist, int64_t n,
+                                                            int32_t* __restrict__ rep, int32_t* __restrict__ any) {
+    const int64_t i = static_cast<int64_t>(blockIdx.x) * 4 + (threadIdx.x >> 6);   // one wave per row
+    const int lane = threadIdx.x & 63;
+    if (i >= n) return;
+    int best = static_cast<int>(i);
+    for (int64_t j0 = 0; j0 < i; j0 += 64) {
+        const int64_t j = j0 + lane;
+        const bool hit = j < i && dist[i * n + j] == 0.0f;
+        const unsigned long long m = __ballot(hit);
+        if (m) {
+            best = static_cast<int>(j0) + __builtin_ctzll(m);
+            break;
+        }
+    }
+    if (lane == 0) {
+        rep[i] = best;
+        if (best != static_cast<int>(i)) *any = 1;
+    }
+}
+
+__global__ __launch_bounds__(256) void duplicate_copy_kernel(float* __restrict__ dist, int64_t n,
+                                                             const int32_t* __restrict__ rep,
+                                                             const int32_t* __restrict__ any) {
+    if (*any == 0) return;   // no duplicates: the matrix stays as it is
+    const int64_t j = static_cast<int64_t>(blockIdx.x) * 64 + (threadIdx.x & 63);
+    const int64_t i = static_cast<int64_t>(blockIdx.y) * 4 + (threadIdx.x >> 6);
+    if (i >= n || j >= n || i == j) return;
+    const int ri = rep[i], rj = rep[j];
+    if (ri == i && rj == j) return;            // both are representatives: nobody writes this entry
+    dist[i * n + j] = ri == rj ? 0.0f : dist[static_cast<int64_t>(ri) * n + rj];
+}
+
 int env_int(const char* name, int fallback) {
     const char* v = std::getenv(name);
     return v ? std::atoi(v) : fallback;
@@ -732,11 +810,34 @@ int launch_gram(byz_ctx* ctx, const float* G, int64_t n_rows, int64_t n_cols, in
     if (splits < 1) splits = 1;
     if (splits > stages) splits = stages;
     if (splits > 65535) splits = 65535;
-    const int64_t stages_per_split = ceil_div(stages, splits);
+    // Arithmetic of the contraction (BYZ_GRAM_MODE overrides):
+    //   exact   fp32-input MFMA, bit-for-bit an fmaf chain; the default while the problem is at most two tiles wide
+    //           (N <= 256), where the kernel is launch/HBM bound anyway;
+    //   split   bf16 x 3: every fp32 value is split exactly into three bf16 planes and six bf16 MFMAs per block stand
+    //           in for the fp32 product.  Default for N > 256.
+    //   planes  the same arithmetic with the split done once per element at staging time (experimental).
+    const char* mode_env = std::getenv("BYZ_GRAM_MODE");
+    const std::string mode_s = mode_env ? mode_env : (n_tiles >= 4 ? "split" : "exact");
+    const bool dma = (ld % 4 == 0) && (reinterpret_cast<uintptr_t>(G) % 16 == 0) && env_int("BYZ_GRAM_NO_DMA", 0) == 0;
+    const bool split_mode = dma && mode_s == "split";
+    const bool planes_mode = mode_s == "planes";
+    // chunked schedule (see the kernel): many tiles and a long K
+    const int64_t chunk_stages = env_int("BYZ_GRAM_CHUNK_COLS", 8192) / BK;
+    const bool chunked = n_tiles >= 256 && stages > 2 * chunk_stages && env_int("BYZ_GRAM_NO_CHUNKS", 0) == 0 &&
+                         chunk_stages * BK <= 8192 && !planes_mode;   // a chunk must end before level 1 spills to the slab
+    if (chunked) splits = ceil_div(stages, chunk_stages);
+    const int64_t stages_per_split = chunked ? chunk_stages : ceil_div(stages, splits);
     splits = ceil_div(stages, stages_per_split);
-    const bool wide = stages_per_split * BK > kFlushK;
+    // the fp32 slab format is only for K ranges that fit ONE level-0 chain
+    const bool wide = chunked || stages_per_split * BK > (split_mode ? 256 : kFlushK);
     const size_t slab = static_cast<size_t>(TM) * TM * (wide ? sizeof(double) : sizeof(float));
-    BYZ_TRY(ctx->gram_partials.ensure(static_cast<size_t>(splits) * n_tiles * slab));
+    BYZ_TRY(ctx->gram_partials.ensure(static_cast<size_t>(chunked ? 1 : splits) * n_tiles * slab));
+    int* tickets = nullptr;
+    if (chunked) {
+        BYZ_TRY(ctx->gram_tickets.ensure(static_cast<size_t>(n_tiles) * sizeof(int)));
+        tickets = ctx->gram_tickets.as<int>();
+        BYZ_HIP(hipMemsetAsync(tickets, 0, static_cast<size_t>(n_tiles) * sizeof(int), stream));
+    }
     // tile list in 8 x 8 super-block order (see the kernel); rebuilt only when the tile count changes
     if (ctx->tile_order_T != T) {
         ctx->tile_order_host.clear();
@@ -765,24 +866,11 @@ int launch_gram(byz_ctx* ctx, const float* G, int64_t n_rows, int64_t n_cols, in
     {
         KernelTimer t(ctx, BYZ_K_GRAM, stream);
         const int2* order = ctx->tile_order.as<int2>();
-        // global_load_lds moves 16 bytes per lane: every row segment must be 16-byte aligned
-        const bool dma = (ld % 4 == 0) && (reinterpret_cast<uintptr_t>(G) % 16 == 0) && env_int("BYZ_GRAM_NO_DMA", 0) == 0;
-        const unsigned grid = static_cast<unsigned>(grid_wgs);
-        // Arithmetic of the contraction (BYZ_GRAM_MODE overrides):
-        //   exact   fp32-input MFMA, bit-for-bit an fmaf chain; the default while the problem is one or two tiles
-        //           wide (N <= 256), where the kernel is launch/HBM bound anyway;
-        //   split   bf16 x 3: every fp32 value is split exactly into three bf16 planes and six bf16 MFMAs per block
-        //           stand in for the fp32 product (error <= 2^-23 |x y| per product, the size of one fp32 rounding);
-        //           1.25x the throughput of `exact` at N = 4000.  Default for N > 256.
-        //   planes  the same arithmetic with the split done once per element at staging time (experimental).
-        const char* mode = std::getenv("BYZ_GRAM_MODE");
-        const std::string mode_s = mode ? mode : (n_tiles >= 4 ? "split" : "exact");
-        const bool split_mode = dma && mode_s == "split";
-        const bool planes_mode = mode_s == "planes";
+        const unsigned grid = static_cast<unsigned>(grid_wgs);   // (dma: global_load_lds moves 16 bytes per lane, so every row segment must be 16-byte aligned)
 #define BYZ_GRAM(T, D, S)                                                                                     \
     gram_tile_kernel<T, D, S><<<grid, THREADS, 0, stream>>>(G, n_rows, n_cols, ld, stages_per_split,           \
                                                             ctx->gram_partials.as<T>(), (int)n_tiles, order,    \
-                                                            (int)per_xcd, (int)splits)
+                                                            (int)per_xcd, (int)splits, tickets)
         if (planes_mode) {
             if (wide)
                 gram_planes_kernel<double><<<grid, THREADS, 0, stream>>>(G, n_rows, n_cols, ld, stages_per_split, ctx->gram_partials.as<double>(), (int)n_tiles, order, (int)per_xcd, (int)splits);
@@ -803,9 +891,9 @@ int launch_gram(byz_ctx* ctx, const float* G, int64_t n_rows, int64_t n_cols, in
     {
         KernelTimer t(ctx, BYZ_K_GRAM_REDUCE, stream);
         // four threads per entry only when entries alone cannot fill the chip (the 128 x 128 of one tile)
-        const bool many = splits >= 16 && n_rows * n_rows <= (1 << 18);
+        const bool many = !chunked && splits >= 16 && n_rows * n_rows <= (1 << 18);
         dim3 grid(static_cast<unsigned>(ceil_div(n_rows, 64)), static_cast<unsigned>(many ? n_rows : ceil_div(n_rows, 4)));
-#define BYZ_REDUCE(T, Q) gram_reduce_kernel<T, Q><<<grid, 256, 0, stream>>>(ctx->gram_partials.as<T>(), (int)n_tiles, (int)splits, n_rows, gram)
+#define BYZ_REDUCE(T, Q) gram_reduce_kernel<T, Q><<<grid, 256, 0, stream>>>(ctx->gram_partials.as<T>(), (int)n_tiles, (int)(chunked ? 1 : splits), n_rows, gram)
         if (wide) {
             if (many) BYZ_REDUCE(double, 4); else BYZ_REDUCE(double, 1);
         } else {
@@ -822,7 +910,15 @@ int launch_distances_from_gram(byz_ctx* ctx, const double* gram, int64_t n, floa
     KernelTimer t(ctx, BYZ_K_DISTANCES, stream);
     dim3 grid(static_cast<unsigned>(ceil_div(n, 64)), static_cast<unsigned>(ceil_div(n, 4)));
     distance_kernel<<<grid, 256, 0, stream>>>(gram, n, dist);
-    return check_launch("distance_kernel");
+    BYZ_TRY(check_launch("distance_kernel"));
+    // exact ties for identical rows, whatever arithmetic produced the Gram (see duplicate_rep_kernel)
+    BYZ_TRY(ctx->dup_rep.ensure(static_cast<size_t>(n + 1) * sizeof(int32_t)));
+    int32_t* rep = ctx->dup_rep.as<int32_t>();
+    BYZ_HIP(hipMemsetAsync(rep + n, 0, sizeof(int32_t), stream));
+    duplicate_rep_kernel<<<static_cast<unsigned>(ceil_div(n, 4)), 256, 0, stream>>>(dist, n, rep, rep + n);
+    BYZ_TRY(check_launch("duplicate_rep_kernel"));
+    duplicate_copy_kernel<<<grid, 256, 0, stream>>>(dist, n, rep, rep + n);
+    return check_launch("duplicate_copy_kernel");
 }
 
 }  // namespace byz

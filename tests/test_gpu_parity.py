@@ -140,6 +140,35 @@ def test_distances_vs_fp64(eng, n, d):
     assert np.array_equal(got, got.T) and np.all(np.isinf(np.diag(got)))
 
 
+def test_distances_chunked_schedule_large_n(eng):
+    """N > 2816 (>= 256 tiles) with a long K takes the chunked, ticketed Gram schedule and the bf16 x 3 arithmetic:
+    fp64 reference on the GPU, identical rows must still give exact zeros and identical distance rows."""
+    torch = pytest.importorskip('torch')
+    n, d = 2900, 40000
+    gen = torch.Generator(device='cuda').manual_seed(77)
+    g = torch.randn((n, d), generator=gen, device='cuda', dtype=torch.float32)
+    g[5] = g[2900 - 1]
+    g[1700] = g[5]
+    dist = torch.from_numpy(eng.pairwise_distances(g).numpy()).cuda()
+    g64 = g.double()
+    sq = (g64 * g64).sum(1)
+    want = (sq[:, None] + sq[None, :] - 2.0 * (g64 @ g64.T)).clamp_min(0).sqrt()
+    off = ~torch.eye(n, dtype=torch.bool, device='cuda')
+    same = torch.zeros((n, n), dtype=torch.bool, device='cuda')
+    for a in (5, 1700, n - 1):
+        for b in (5, 1700, n - 1):
+            same[a, b] = True
+    mask = off & ~same
+    rel = ((dist.double() - want).abs() / want)[mask]
+    assert float(rel.max()) < 1e-6, float(rel.max())
+    assert float(dist[5, 1700]) == 0.0 and float(dist[5, n - 1]) == 0.0 and float(dist[1700, n - 1]) == 0.0
+    assert torch.equal(dist[5, mask[5]], dist[1700, mask[1700]])
+    assert torch.equal(dist, dist.T)
+    # a second call must reproduce the matrix bit for bit (fixed accumulation order through the tickets)
+    again = torch.from_numpy(eng.pairwise_distances(g).numpy()).cuda()
+    assert torch.equal(dist, again)
+
+
 def test_identical_rows_have_zero_distance_and_tie_exactly(eng):
     g = gaussian(7, 50, 33333)
     g[:12] = g[3]
