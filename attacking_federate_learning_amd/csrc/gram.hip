@@ -99,7 +99,7 @@ __global__ __launch_bounds__(THREADS, 2) void gram_tile_kernel(const float* __re
                                                                int64_t stages_per_split,
                                                                PartialT* __restrict__ partial, int n_tiles,
                                                                const int2* __restrict__ tile_order, int per_xcd, int n_splits,
-                                                               int* __restrict__ tickets) {
+                                                               int* __restrict__ tickets, int round_size) {
     __shared__ __attribute__((aligned(16))) float lds[2 * 2 * TILE_FLOATS];  // [2 buffers][A | B][TM][row]
 
     // Workgroup -> (tile, K split).  Workgroups are dealt to the 8 XCDs round-robin (observed; only speed
@@ -116,7 +116,29 @@ __global__ __launch_bounds__(THREADS, 2) void gram_tile_kernel(const float* __re
         const int mine = base + (xcd < rem ? 1 : 0);
         const int first = xcd * base + (xcd < rem ? xcd : rem);
         split = seq / mine;
-        if (split >= n_splits) return;
+        if (tickets != nullptr) {
+            // Chunked schedule: the XCD's workgroups run in rounds of `round_size` (its resident capacity).  A
+            // workgroup starts only when every workgroup of the earlier rounds of its XCD has finished, so a round
+            // starts together and its members walk K in step: that is what makes them hit each other's operand
+            // lines in the XCD's L2 (staggered starts left the hit rate at 28%).  Only scheduling depends on this:
+            // earlier workgroups never wait for later ones, and the wait is bounded.
+            int* done = tickets + n_tiles + xcd;
+            const int round = round_size > 0 ? seq / round_size : 0;   // 0 disables the gate
+            if (round > 0 && threadIdx.x == 0) {
+                unsigned spins = 0;
+                while (__hip_atomic_load(done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < round * round_size) {
+                    __builtin_amdgcn_s_sleep(16);
+                    if (++spins > (1u << 20)) break;
+                }
+            }
+            __syncthreads();
+            if (split >= n_splits) {
+                if (threadIdx.x == 0) __hip_atomic_fetch_add(done, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                return;
+            }
+        } else if (split >= n_splits) {
+            return;
+        }
         t_list = first + (seq - split * mine);
     } else {  // few tiles: plain tile-fastest order, every XCD busy
         split = blockIdx.x / n_tiles;
@@ -401,6 +423,8 @@ __global__ __launch_bounds__(THREADS, 2) void gram_tile_kernel(const float* __re
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __hip_atomic_store(tickets + tile, split + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (per_xcd > 0)
+                    __hip_atomic_fetch_add(tickets + n_tiles + (blockIdx.x & 7), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         } else {
             to_slab(true);
@@ -834,9 +858,9 @@ int launch_gram(byz_ctx* ctx, const float* G, int64_t n_rows, int64_t n_cols, in
     BYZ_TRY(ctx->gram_partials.ensure(static_cast<size_t>(chunked ? 1 : splits) * n_tiles * slab));
     int* tickets = nullptr;
     if (chunked) {
-        BYZ_TRY(ctx->gram_tickets.ensure(static_cast<size_t>(n_tiles) * sizeof(int)));
+        BYZ_TRY(ctx->gram_tickets.ensure(static_cast<size_t>(n_tiles + 8) * sizeof(int)));   // + one finished-count per XCD
         tickets = ctx->gram_tickets.as<int>();
-        BYZ_HIP(hipMemsetAsync(tickets, 0, static_cast<size_t>(n_tiles) * sizeof(int), stream));
+        BYZ_HIP(hipMemsetAsync(tickets, 0, static_cast<size_t>(n_tiles + 8) * sizeof(int), stream));
     }
     // tile list in 8 x 8 super-block order (see the kernel); rebuilt only when the tile count changes
     if (ctx->tile_order_T != T) {
@@ -866,11 +890,12 @@ int launch_gram(byz_ctx* ctx, const float* G, int64_t n_rows, int64_t n_cols, in
     {
         KernelTimer t(ctx, BYZ_K_GRAM, stream);
         const int2* order = ctx->tile_order.as<int2>();
+        const int round_size = env_int("BYZ_GRAM_ROUND", ctx->num_cus / 8 * 2);   // workgroups an XCD holds at a time
         const unsigned grid = static_cast<unsigned>(grid_wgs);   // (dma: global_load_lds moves 16 bytes per lane, so every row segment must be 16-byte aligned)
 #define BYZ_GRAM(T, D, S)                                                                                     \
     gram_tile_kernel<T, D, S><<<grid, THREADS, 0, stream>>>(G, n_rows, n_cols, ld, stages_per_split,           \
                                                             ctx->gram_partials.as<T>(), (int)n_tiles, order,    \
-                                                            (int)per_xcd, (int)splits, tickets)
+                                                            (int)per_xcd, (int)splits, tickets, round_size)
         if (planes_mode) {
             if (wide)
                 gram_planes_kernel<double><<<grid, THREADS, 0, stream>>>(G, n_rows, n_cols, ld, stages_per_split, ctx->gram_partials.as<double>(), (int)n_tiles, order, (int)per_xcd, (int)splits);
