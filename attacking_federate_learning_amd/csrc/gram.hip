@@ -2,29 +2,38 @@
 //
 // The reference evaluates ||g_i - g_j|| pair by pair; here the N x N matrix comes from the Gram identity
 //     d_ij = sqrt(max(0, c_ii + c_jj - 2 c_ij)),   C = G * G^T,
-// because C is a genuine dense contraction over the D parameters and that is what the matrix cores are
-// for.  fp32 data is kept exact: v_mfma_f32_32x32x2_f32 (f32 in, f32 accumulate), which is bit-for-bit a
-// k-ordered fmaf chain.
+// because C is a genuine dense contraction over the D parameters and that is what the matrix cores are for.
+//
+// Arithmetic (two modes, same tiling):
+//   exact  v_mfma_f32_32x32x2_f32 (f32 in, f32 accumulate): bit-for-bit a k-ordered fmaf chain.  157.3 TF peak.
+//   split  every fp32 operand is split EXACTLY into three bf16 planes (the three 8-bit fields of its 24-bit
+//          significand) and six v_mfma_f32_32x32x16_bf16 per block stand in for the fp32 product; the three dropped
+//          cross terms are below 2^-23 |x y| (measured bias on a sum of squares: -5e-8 relative).  Default for N > 256.
 //
 // Data layout and tiling (gfx950):
 //   * G is row-major (N x D): both operands of C = G G^T are K-contiguous, so every global load is a
-//     128-byte row segment (BK = 32 floats) read as dwordx4 by 8 adjacent lanes.
-//   * One workgroup = 4 waves = one 128 x 128 tile of C (lower triangle only, tj <= ti) over one K slice
-//     (split-K): small N has too few tiles to fill 256 CUs, so the D axis supplies the parallelism.
-//   * Operand tiles go global -> registers -> LDS (row stride 36 floats: ds_read_b128 of 16 different
-//     rows at one k offset is conflict-free), double-buffered, one barrier per K stage; the next stage's
-//     global loads are in flight while the current stage's MFMAs run.
-//   * Each wave owns a 64 x 64 sub-tile = 2 x 2 MFMA 32x32 blocks = 64 accumulator registers.
+//     128-byte row segment (BK = 32 floats).
+//   * One workgroup = 4 waves = one 128 x 128 tile of C (lower triangle only, tj <= ti); each wave owns a
+//     64 x 64 sub-tile = 2 x 2 MFMA 32 x 32 blocks = 64 accumulator registers.  Two workgroups per CU.
+//   * Operand tiles reach LDS by LDS-DMA (global_load_lds_dwordx4: no VGPR round trip, no ds_write pass),
+//     double-buffered, one barrier per stage.  The DMA image is lane-linear, so rows are exactly 32 floats and the
+//     bank conflicts of the fragment reads are removed by an XOR swizzle applied to the DMA's SOURCE address and to
+//     every read.  Rows that are not 16-byte aligned take the register-staged path (padded 36-float rows).
+//   * K schedule.  Few tiles: split-K, one slab per (tile, split), reduced in fp64 in a fixed order.  Many tiles
+//     and a long K: chunks of 8192 columns; all chunks of a tile add, in chunk order (a ticket per tile), into
+//     the tile's one fp64 slab, and each XCD runs its workgroups in rounds that start together, so the workgroups
+//     that share operand row blocks stay in step and hit each other's lines in the XCD's L2.
 //
 // Numerics:
-//   * an fp32 accumulator chain never exceeds kFlushK = 2048 products; longer K ranges are flushed into
-//     fp64 running sums, and the split-K slabs are reduced in fp64 in a fixed order (deterministic);
+//   * three accumulation levels: an MFMA chain of at most 2048 columns (256 in split mode, because the bf16
+//     MFMA adds into its accumulator with truncation), fp32 sums of a few such chains, fp64 slabs;
 //   * c_ii, c_jj and c_ij all come out of the same code with the same k order, so bitwise-identical rows
-//     (every malicious client submits the same vector, malicious.py:26-27) give d_ij == 0 exactly and
-//     identical distance rows -- the exact ties the reference resolves by visit order survive.
+//     (every malicious client submits the same vector, malicious.py:26-27) give d_ij == 0 exactly; the rows of
+//     such a group are then given bitwise identical distance rows (duplicate_rep_kernel), which is what lets the
+//     exact ties the reference resolves by visit order survive in either arithmetic.
 //
-// Algorithmic work per call: N^2 * D flops (half Gram, 2 flops per MAC), 4 N D bytes read.  Bound: fp32
-// MFMA (157.3 TF) once N/4 flop/B exceeds the machine balance (N >~ 80), HBM below that.
+// Algorithmic work per call: N^2 * D flops (half Gram, 2 flops per MAC), 4 N D bytes read.  Bound: MFMA once
+// N/4 flop/B exceeds the machine balance (N >~ 80), HBM below that.
 #include "common.hpp"
 
 #include <cstdlib>
@@ -443,248 +452,6 @@ __global__ __launch_bounds__(THREADS, 2) void gram_tile_kernel(const float* __re
     }
 }
 
-// ---------------------------------------------------------------------------------------------------------
-// bf16 x 3 with the split done ONCE per matrix element, at staging time.
-//
-// gram_tile_kernel<.., SPLIT> keeps fp32 in LDS and lets every wave split its own fragments, so each element is
-// split by the two waves that share its row block: 7.9 VALU operations per MFMA, and the VALU pipe (61% busy)
-// was as loaded as the matrix pipe (56%).  Here the workgroup converts each loaded float4 to three bf16 planes
-// before it goes to LDS (3.7 VALU per MFMA) and the waves read ready-made MFMA operands.
-//   LDS: [A | B][plane h, m, l][128 rows][32 bf16] = 48 KB, single-buffered (two workgroups per CU); the next
-//   stage's global loads are in flight in registers while the current stage multiplies.
-//   A row is 64 bytes, so 16 consecutive rows of one 16-byte chunk would hit only four bank groups: the chunk index
-//   is XOR-ed with (row >> 2) & 3 on both the write and the read side.
-// ---------------------------------------------------------------------------------------------------------
-constexpr int PLANE_BYTES = TM * 64;   // 128 rows x 32 bf16
-
-__device__ __forceinline__ int plane_off(int row, int chunk16) {   // byte offset of a 16-byte chunk (8 bf16)
-    return row * 64 + ((chunk16 ^ ((row >> 2) & 3)) << 4);
-}
-
-typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
-
-__device__ __forceinline__ void split4(const f32x4& v, u32x2& h, u32x2& m, u32x2& l) {
-    uint32_t xb[4], r1b[4], r2b[4];
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        xb[e] = __float_as_uint(v[e]);
-        const float r1 = v[e] - __uint_as_float(xb[e] & 0xffff0000u);
-        r1b[e] = __float_as_uint(r1);
-        const float r2 = r1 - __uint_as_float(r1b[e] & 0xffff0000u);
-        r2b[e] = __float_as_uint(r2);
-    }
-#pragma unroll
-    for (int e = 0; e < 2; ++e) {
-        h[e] = __builtin_amdgcn_perm(xb[2 * e + 1], xb[2 * e], 0x07060302u);
-        m[e] = __builtin_amdgcn_perm(r1b[2 * e + 1], r1b[2 * e], 0x07060302u);
-        l[e] = __builtin_amdgcn_perm(r2b[2 * e + 1], r2b[2 * e], 0x07060302u);
-    }
-}
-
-template <typename PartialT>
-__global__ __launch_bounds__(THREADS, 2) void gram_planes_kernel(const float* __restrict__ G, int64_t n_rows,
-                                                                 int64_t n_cols, int64_t ld, int64_t stages_per_split,
-                                                                 PartialT* __restrict__ partial, int n_tiles,
-                                                                 const int2* __restrict__ tile_order, int per_xcd,
-                                                                 int n_splits) {
-    __shared__ __attribute__((aligned(16))) unsigned char planes[2 * 3 * PLANE_BYTES];   // [A | B][h, m, l]
-
-    int split, t_list;
-    if (per_xcd > 0) {
-        const int xcd = blockIdx.x & 7;
-        const int seq = blockIdx.x >> 3;
-        const int base = n_tiles >> 3, rem = n_tiles & 7;
-        const int mine = base + (xcd < rem ? 1 : 0);
-        const int first = xcd * base + (xcd < rem ? xcd : rem);
-        split = seq / mine;
-        if (split >= n_splits) return;
-        t_list = first + (seq - split * mine);
-    } else {
-        split = blockIdx.x / n_tiles;
-        t_list = blockIdx.x - split * n_tiles;
-    }
-    const int2 tt = tile_order[t_list];
-    const int ti = tt.x, tj = tt.y;
-    const int tile = ti * (ti + 1) / 2 + tj;
-    const bool diagonal = (ti == tj);
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wr = wave >> 1, wc = wave & 1;
-
-    const int64_t k_begin = static_cast<int64_t>(split) * stages_per_split * BK;
-    int64_t k_end = k_begin + stages_per_split * BK;
-    if (k_end > n_cols) k_end = n_cols;
-    const int n_stages = k_begin < k_end ? static_cast<int>((k_end - k_begin + BK - 1) / BK) : 0;
-    const int n_full = k_begin < k_end ? static_cast<int>((k_end - k_begin) / BK) : 0;
-
-    auto row_ptr = [&](int tile_row0, int local_row) {
-        int64_t r = static_cast<int64_t>(tile_row0) * TM + local_row;
-        if (r > n_rows - 1) r = n_rows - 1;
-        return G + r * ld;
-    };
-    const int ld_chunk = tid & 7;   // float4 within the 32-float row segment
-    const int ld_row = tid >> 3;
-    const float* src_a[4];
-    const float* src_b[4];
-#pragma unroll
-    for (int p = 0; p < 4; ++p) {
-        src_a[p] = row_ptr(ti, ld_row + 32 * p) + 4 * ld_chunk;
-        src_b[p] = row_ptr(tj, ld_row + 32 * p) + 4 * ld_chunk;
-    }
-    f32x4 ra[4], rb[4];
-    auto fetch_full = [&](int stage) __attribute__((always_inline)) {
-        const int64_t k = k_begin + static_cast<int64_t>(stage) * BK;
-#pragma unroll
-        for (int p = 0; p < 4; ++p) ra[p] = *reinterpret_cast<const f32x4u*>(src_a[p] + k);
-        if (!diagonal) {
-#pragma unroll
-            for (int p = 0; p < 4; ++p) rb[p] = *reinterpret_cast<const f32x4u*>(src_b[p] + k);
-        }
-    };
-    auto fetch_tail = [&](int stage) __attribute__((always_inline)) {
-        const int64_t k = k_begin + static_cast<int64_t>(stage) * BK + 4 * ld_chunk;
-#pragma unroll
-        for (int p = 0; p < 4; ++p) {
-            ra[p] = load_tail(row_ptr(ti, ld_row + 32 * p) + k, k, k_end);
-            if (!diagonal) rb[p] = load_tail(row_ptr(tj, ld_row + 32 * p) + k, k, k_end);
-        }
-    };
-    auto stash = [&]() __attribute__((always_inline)) {   // split and store: 8 bytes per plane per float4
-#pragma unroll
-        for (int p = 0; p < 4; ++p) {
-            const int row = ld_row + 32 * p;
-            const int off = plane_off(row, ld_chunk >> 1) + ((ld_chunk & 1) << 3);
-            u32x2 h, m, l;
-            split4(ra[p], h, m, l);
-            *reinterpret_cast<u32x2*>(planes + 0 * PLANE_BYTES + off) = h;
-            *reinterpret_cast<u32x2*>(planes + 1 * PLANE_BYTES + off) = m;
-            *reinterpret_cast<u32x2*>(planes + 2 * PLANE_BYTES + off) = l;
-            if (!diagonal) {
-                split4(rb[p], h, m, l);
-                *reinterpret_cast<u32x2*>(planes + 3 * PLANE_BYTES + off) = h;
-                *reinterpret_cast<u32x2*>(planes + 4 * PLANE_BYTES + off) = m;
-                *reinterpret_cast<u32x2*>(planes + 5 * PLANE_BYTES + off) = l;
-            }
-        }
-    };
-
-    f32x16 acc[2][2];
-    constexpr bool kWide = sizeof(PartialT) == 8;
-    f32x16 acc2[kWide ? 2 : 1][kWide ? 2 : 1];
-#pragma unroll
-    for (int m = 0; m < 2; ++m)
-#pragma unroll
-        for (int n = 0; n < 2; ++n)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[m][n][e] = 0.0f;
-    if constexpr (kWide) {
-#pragma unroll
-        for (int m = 0; m < 2; ++m)
-#pragma unroll
-            for (int n = 0; n < 2; ++n)
-#pragma unroll
-                for (int e = 0; e < 16; ++e) acc2[m][n][e] = 0.0f;
-    }
-    PartialT* out = partial + (static_cast<int64_t>(split) * n_tiles + tile) * (TM * TM);
-    int level1 = 0;
-    bool slab_live = false;
-
-    const int frag_row = lane & 31;
-    const int frag_half = lane >> 5;
-    constexpr int kFlushStages = kFlushK / BK;
-
-    auto compute = [&]() __attribute__((always_inline)) {
-        const unsigned char* A = planes;
-        const unsigned char* B = diagonal ? planes : planes + 3 * PLANE_BYTES;
-#pragma unroll
-        for (int j = 0; j < BK / 16; ++j) {
-            bf16x8 ap[3][2], bp[3][2];   // [plane][block]
-#pragma unroll
-            for (int pl = 0; pl < 3; ++pl)
-#pragma unroll
-                for (int m = 0; m < 2; ++m) {
-                    ap[pl][m] = *reinterpret_cast<const bf16x8*>(A + pl * PLANE_BYTES + plane_off(wr * 64 + m * 32 + frag_row, 2 * j + frag_half));
-                    bp[pl][m] = *reinterpret_cast<const bf16x8*>(B + pl * PLANE_BYTES + plane_off(wc * 64 + m * 32 + frag_row, 2 * j + frag_half));
-                }
-            constexpr int pa[6] = {2, 0, 1, 1, 0, 0};   // l h m m h h
-            constexpr int pb[6] = {0, 2, 1, 0, 1, 0};   // h l m h m h
-#pragma unroll
-            for (int t = 0; t < 6; ++t)
-#pragma unroll
-                for (int m = 0; m < 2; ++m)
-#pragma unroll
-                    for (int n = 0; n < 2; ++n)
-                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[pa[t]][m], bp[pb[t]][n], acc[m][n], 0, 0, 0);
-        }
-    };
-    auto to_slab = [&](bool last) __attribute__((always_inline)) {
-        if constexpr (kWide) {
-#pragma unroll
-            for (int m = 0; m < 2; ++m)
-#pragma unroll
-                for (int n = 0; n < 2; ++n)
-#pragma unroll
-                    for (int e = 0; e < 16; ++e) {
-                        const int i = wr * 64 + m * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
-                        const int j = wc * 64 + n * 32 + (lane & 31);
-                        double v = static_cast<double>(acc2[m][n][e]);
-                        if (last) v += static_cast<double>(acc[m][n][e]);
-                        if (slab_live) v += out[i * TM + j];
-                        out[i * TM + j] = v;
-                        acc2[m][n][e] = 0.0f;
-                    }
-            slab_live = true;
-            level1 = 0;
-        }
-    };
-    auto flush = [&](int s) __attribute__((always_inline)) {
-        if constexpr (kWide) if ((s + 1) % kFlushStages == 0) {
-#pragma unroll
-            for (int m = 0; m < 2; ++m)
-#pragma unroll
-                for (int n = 0; n < 2; ++n)
-#pragma unroll
-                    for (int e = 0; e < 16; ++e) {
-                        acc2[m][n][e] += acc[m][n][e];
-                        acc[m][n][e] = 0.0f;
-                    }
-            if (++level1 == kLevel1) to_slab(false);
-        }
-    };
-
-    if (n_stages > 0) {
-        if (n_full > 0) fetch_full(0); else fetch_tail(0);
-        stash();
-    }
-    __syncthreads();
-    for (int s = 0; s < n_stages; ++s) {
-        if (s + 1 < n_full) fetch_full(s + 1);          // in flight while this stage multiplies
-        else if (s + 1 < n_stages) fetch_tail(s + 1);
-        compute();
-        __syncthreads();                                 // every wave is done reading the planes
-        if (s + 1 < n_stages) stash();
-        __syncthreads();
-        flush(s);
-    }
-
-    if constexpr (kWide) {
-        to_slab(true);
-    } else {
-#pragma unroll
-        for (int m = 0; m < 2; ++m)
-#pragma unroll
-            for (int n = 0; n < 2; ++n)
-#pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    const int i = wr * 64 + m * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
-                    const int j = wc * 64 + n * 32 + (lane & 31);
-                    out[i * TM + j] = static_cast<PartialT>(acc[m][n][e]);
-                }
-    }
-}
-
 // Q = 1: a block covers 64 columns x 4 rows, one thread per entry.
 // Q = 4: a block covers 64 columns of one row, four threads per entry each summing every fourth slab with four
 //        loads in flight (many slabs, few tiles: one dependent chain per entry was 50 us at 155 slabs).
@@ -839,16 +606,14 @@ int launch_gram(byz_ctx* ctx, const float* G, int64_t n_rows, int64_t n_cols, in
     //           (N <= 256), where the kernel is launch/HBM bound anyway;
     //   split   bf16 x 3: every fp32 value is split exactly into three bf16 planes and six bf16 MFMAs per block stand
     //           in for the fp32 product.  Default for N > 256.
-    //   planes  the same arithmetic with the split done once per element at staging time (experimental).
     const char* mode_env = std::getenv("BYZ_GRAM_MODE");
     const std::string mode_s = mode_env ? mode_env : (n_tiles >= 4 ? "split" : "exact");
     const bool dma = (ld % 4 == 0) && (reinterpret_cast<uintptr_t>(G) % 16 == 0) && env_int("BYZ_GRAM_NO_DMA", 0) == 0;
     const bool split_mode = dma && mode_s == "split";
-    const bool planes_mode = mode_s == "planes";
     // chunked schedule (see the kernel): many tiles and a long K
     const int64_t chunk_stages = env_int("BYZ_GRAM_CHUNK_COLS", 8192) / BK;
     const bool chunked = n_tiles >= 256 && stages > 2 * chunk_stages && env_int("BYZ_GRAM_NO_CHUNKS", 0) == 0 &&
-                         chunk_stages * BK <= 8192 && !planes_mode;   // a chunk must end before level 1 spills to the slab
+                         chunk_stages * BK <= 8192;   // a chunk must end before level 1 spills to the slab
     if (chunked) splits = ceil_div(stages, chunk_stages);
     const int64_t stages_per_split = chunked ? chunk_stages : ceil_div(stages, splits);
     splits = ceil_div(stages, stages_per_split);
@@ -896,12 +661,7 @@ int launch_gram(byz_ctx* ctx, const float* G, int64_t n_rows, int64_t n_cols, in
     gram_tile_kernel<T, D, S><<<grid, THREADS, 0, stream>>>(G, n_rows, n_cols, ld, stages_per_split,           \
                                                             ctx->gram_partials.as<T>(), (int)n_tiles, order,    \
                                                             (int)per_xcd, (int)splits, tickets, round_size)
-        if (planes_mode) {
-            if (wide)
-                gram_planes_kernel<double><<<grid, THREADS, 0, stream>>>(G, n_rows, n_cols, ld, stages_per_split, ctx->gram_partials.as<double>(), (int)n_tiles, order, (int)per_xcd, (int)splits);
-            else
-                gram_planes_kernel<float><<<grid, THREADS, 0, stream>>>(G, n_rows, n_cols, ld, stages_per_split, ctx->gram_partials.as<float>(), (int)n_tiles, order, (int)per_xcd, (int)splits);
-        } else if (wide) {
+        if (wide) {
             if (split_mode) BYZ_GRAM(double, true, true);
             else if (dma) BYZ_GRAM(double, true, false);
             else BYZ_GRAM(double, false, false);

@@ -82,6 +82,9 @@ class Workload:
     name = ''
     defence = ''
 
+    def dtype(self):
+        return 'f32'
+
     def describe(self):
         raise NotImplementedError
 
@@ -114,10 +117,17 @@ class BulyanSharded(Workload):
             out, sel = self.agg.bulyan(self.g, self.n, self.f, gather=True, return_selection=True)
             self.last = (out, sel)
 
+    def dtype(self):
+        # fp32 data and fp32 results; for N > 256 the Gram contraction runs as an exact three-way bf16 split of every
+        # fp32 operand on the bf16 matrix cores (six bf16 MFMAs per fp32 product block, fp32 accumulate)
+        return 'f32 (Gram: bf16x3 exact-split MFMA, fp32 accumulate)' if self.n > 256 else 'f32'
+
     def dominant(self):
-        # the Gram: N^2 * D_local flops per launch (half Gram, 2 flop per MAC) -- SURVEY.md 8(d)
+        # the Gram: N^2 * D_local flops per launch (half Gram, 2 flop per MAC) -- SURVEY.md 8(d).  The peak is the
+        # dense fp32-input MFMA peak: the algorithmic flops are fp32 flops, whatever instructions carry them.
         return {'kernel': 'gram_tile', 'bound': 'mfma', 'work': float(self.n) ** 2 * self.d_local,
-                'peak': PEAK_MFMA_F32, 'unit': 'TFLOP/s', 'scale': 1e12}
+                'peak': PEAK_MFMA_F32, 'unit': 'TFLOP/s', 'scale': 1e12,
+                'issued_factor': 6.0 if self.n > 256 else 1.0, 'issued_peak': 2.5e15 if self.n > 256 else PEAK_MFMA_F32}
 
     def config(self):
         return {'workload': '%s: %s N=%d D=%d f=%d theta=%d (BASELINE configs[%d]), columns sharded %d-way'
@@ -220,10 +230,16 @@ def roofline_of(wl, per_kernel, traffic_table):
         rec = traffic_table.get('%s/%s' % (wl.name, dom['kernel']))
         if rec:
             traffic = rec.get('hbm_bytes_per_launch')
-    return {'kernel': dom['kernel'], 'bound': dom['bound'], 'achieved': achieved / dom['scale'],
-            'peak': dom['peak'] / dom['scale'], 'unit': dom['unit'], 'frac': achieved / dom['peak'],
-            'traffic': traffic, 'avg_launch_ms': avg_s * 1e3, 'launches': k['launches'],
-            'algorithmic_work_per_launch': dom['work']}
+    out = {'kernel': dom['kernel'], 'bound': dom['bound'], 'achieved': achieved / dom['scale'],
+           'peak': dom['peak'] / dom['scale'], 'unit': dom['unit'], 'frac': achieved / dom['peak'],
+           'traffic': traffic, 'avg_launch_ms': avg_s * 1e3, 'launches': k['launches'],
+           'algorithmic_work_per_launch': dom['work']}
+    if dom.get('issued_factor', 1.0) != 1.0:
+        # the matrix-core instructions actually issued: 6 bf16 MFMA flops per algorithmic fp32 flop, against the
+        # dense bf16 MFMA peak -- how busy the matrix pipe really is
+        out['mfma_issued'] = {'achieved': achieved * dom['issued_factor'] / 1e12, 'peak': dom['issued_peak'] / 1e12,
+                              'unit': 'TFLOP/s (bf16 MFMA)', 'frac': achieved * dom['issued_factor'] / dom['issued_peak']}
+    return out
 
 
 def kernel_table(per_kernel, steps):
@@ -372,7 +388,7 @@ def main():
         'metric': 'aggregation rounds/sec at N clients x D params (%s)' % wl.defence,
         'value': args.steps / elapsed, 'unit': 'rounds/s', 'n_gpus': args.gpus, 'steps': args.steps,
         'warmup': args.warmup, 'ms_per_step': ms_per_step, 'higher_is_better': True,
-        'scaling': 'strong', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+        'scaling': 'strong', 'vs_baseline': None, 'dtype': wl.dtype(), 'data': 'synthetic',
         'config': wl.config(),
         'roofline': roofline_of(wl, per_kernel, traffic),
         'kernels': kernel_table(per_kernel, args.steps),
