@@ -6,7 +6,7 @@ export TMPDIR=/tmp
 cd /tmp
 run() {  # tag counter cmd...
   tag=$1; ctr=$2; shift 2
-  timeout 1200 rocprofv3 --pmc $ctr --kernel-trace -d $OUT/$tag.$ctr -o p --output-format csv -- "$@" > $OUT/$tag.$ctr.log 2>&1
+  timeout 240 rocprofv3 --pmc $ctr --kernel-trace -d $OUT/$tag.$ctr -o p --output-format csv -- "$@" > $OUT/$tag.$ctr.log 2>&1
 }
 for ctr in FETCH_SIZE WRITE_SIZE; do
   run c4 $ctr python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-extras --steps 1 --warmup 0
