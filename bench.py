@@ -85,6 +85,9 @@ class Workload:
     def dtype(self):
         return 'f32'
 
+    def at_profiled_size(self):
+        return True
+
     def describe(self):
         raise NotImplementedError
 
@@ -129,6 +132,9 @@ class BulyanSharded(Workload):
                 'peak': PEAK_MFMA_F32, 'unit': 'TFLOP/s', 'scale': 1e12,
                 'issued_factor': 6.0 if self.n > 256 else 1.0, 'issued_peak': 2.5e15 if self.n > 256 else PEAK_MFMA_F32}
 
+    def at_profiled_size(self):
+        return self.name == 'c4' and self.n == 4000 and self.d_local == 10000000
+
     def config(self):
         return {'workload': '%s: %s N=%d D=%d f=%d theta=%d (BASELINE configs[%d]), columns sharded %d-way'
                             % (self.name, self.defence, self.n, self.d_total, self.f, self.n - 2 * self.f,
@@ -151,6 +157,9 @@ class TrimmedMeanC3(Workload):
         return {'kernel': 'trimmed_mean', 'bound': 'hbm', 'work': 4.0 * self.n * self.d + 4.0 * self.d,
                 'peak': PEAK_HBM, 'unit': 'GB/s', 'scale': 1e9}
 
+    def at_profiled_size(self):
+        return self.n == 1000 and self.d == 1000000
+
     def config(self):
         return {'workload': 'c3: TrimmedMean N=%d D=%d trim=%d (BASELINE configs[2])' % (self.n, self.d, self.c),
                 'clients': self.n, 'params': self.d, 'corrupted': self.c}
@@ -170,6 +179,9 @@ class KrumC2(Workload):
         return {'kernel': 'gram_tile', 'bound': 'hbm', 'work': 4.0 * self.n * self.d + 4.0 * self.n * self.n,
                 'peak': PEAK_HBM, 'unit': 'GB/s', 'scale': 1e9}
 
+    def at_profiled_size(self):
+        return self.n == 100 and self.d == 79510
+
     def config(self):
         return {'workload': 'c2: Krum N=%d D=%d f=%d (BASELINE configs[1])' % (self.n, self.d, self.f),
                 'clients': self.n, 'params': self.d, 'corrupted': self.f}
@@ -188,6 +200,9 @@ class AttackOnly(Workload):
     def dominant(self):
         return {'kernel': 'column_stats', 'bound': 'hbm', 'work': 4.0 * self.m * self.d + 4.0 * self.d,
                 'peak': PEAK_HBM, 'unit': 'GB/s', 'scale': 1e9}
+
+    def at_profiled_size(self):
+        return self.m == 2400 and self.d == 1000000
 
     def config(self):
         return {'workload': 'attack: A Little Is Enough over m=%d malicious rows, D=%d' % (self.m, self.d),
@@ -227,7 +242,8 @@ def roofline_of(wl, per_kernel, traffic_table):
     achieved = dom['work'] / avg_s
     traffic = None
     if traffic_table:
-        rec = traffic_table.get('%s/%s' % (wl.name, dom['kernel']))
+        # the committed PMC passes were taken at the BASELINE sizes of each workload; other sizes report null
+        rec = traffic_table.get('%s/%s' % (wl.name, dom['kernel'])) if wl.at_profiled_size() else None
         if rec:
             traffic = rec.get('hbm_bytes_per_launch')
     out = {'kernel': dom['kernel'], 'bound': dom['bound'], 'achieved': achieved / dom['scale'],
