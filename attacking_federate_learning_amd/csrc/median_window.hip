@@ -53,6 +53,7 @@ using namespace lanes;
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int kCols = 16;                 // columns per tile (4 waves x 4 columns, or 16 waves x 1 column)
 constexpr int kStride = 20;               // floats per LDS row: 16-byte aligned, b128 column reads conflict-free
@@ -333,6 +334,206 @@ __device__ __forceinline__ void select4(const float (&x)[NC][RPL], int groups, i
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Bucket selection: the fast path of both selections.
+//
+// One pass puts every value of a column into one of 64 equal-width buckets of [lo, hi] (an LDS histogram per wave and
+// column, ds_add_u32), a 64-lane prefix sum finds the bucket that holds the wanted rank, and if that bucket has at most
+// 64 values they are compacted and sorted by one 64-lane bitonic network; otherwise a second level splits that one
+// bucket into 64 again.  Gaussian columns of 1000 values need one level (the busiest bucket holds ~45 values), 2560
+// values need two.  That is ~13 vector instructions per value and selection against ~45 for the probing search below,
+// which stays as the general path: any column the buckets cannot resolve (outliers that squeeze everything into one
+// bucket, non-finite ranges, more than 64 equal values) sends the wave's columns through select4.
+//
+// The bucket index floor((a - lo) * inv) is monotone in a, so "all values in lower buckets" are exactly the values that
+// sort before the target bucket: the rank bookkeeping is exact whatever the rounding of the index arithmetic does.
+// Padding (+inf) lands in an extra bucket 64 that nothing reads.
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int kBuckets = 64;
+constexpr int kWaveScratch = 64 + (kBuckets + 1) * 4 + 4 * 64;   // floats per wave: strip, histogram, candidates
+
+__device__ __forceinline__ uint32_t bucket_of(float a, float lo, float inv) {
+    const float t = __builtin_fminf((a - lo) * inv, static_cast<float>(kBuckets));   // +inf padding -> bucket 64
+    return static_cast<uint32_t>(t);   // v_cvt_u32_f32: negative values and NaN give 0
+}
+
+// For columns c with want[c]: ranks r (and r + 1 with want_next) of mag(x[c]); ok[c] says whether the column was resolved.
+template <int RPL, int NC, bool ABS>
+__device__ __forceinline__ void bucket_select(const float (&x)[NC][RPL], int groups, int r, bool want_next,
+                                              const float (&lo0)[NC], const float (&hi0)[NC], const bool (&want)[NC],
+                                              float (&res_a)[NC], float (&res_b)[NC], bool (&ok)[NC], int lane,
+                                              float* scratch) {
+    constexpr int GS = RPL >= 4 ? 4 : RPL;
+    // [column][bucket 0..64]: consecutive buckets are consecutive banks, so only lanes that hit the SAME bucket
+    // serialise ([bucket][column] put every add of one instruction on 8 banks: SQ_LDS_BANK_CONFLICT = 1.7x the busy cycles)
+    uint32_t* hist = reinterpret_cast<uint32_t*>(scratch + 64);
+    constexpr int HS = kBuckets + 1;   // histogram stride per column
+    float* cand = scratch + 64 + (kBuckets + 1) * 4;                        // [column][64]
+    const float pinf = __builtin_inff();
+    float lo[NC], inv[NC];          // current level's bucket map
+    float plo[NC], pinv[NC];        // parent level's map and target bucket (level 2 only)
+    uint32_t pb[NC];
+    int below[NC];                  // values known to sort before the current range
+    bool live[NC];                  // still being resolved by buckets
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        ok[c] = false;
+        below[c] = 0;
+        plo[c] = 0.0f; pinv[c] = 0.0f; pb[c] = 0u;
+        const float width = hi0[c] - lo0[c];
+        live[c] = want[c] && finite_f(lo0[c]) && finite_f(hi0[c]) && finite_f(width) && width > 0.0f;
+        if (want[c] && finite_f(lo0[c]) && hi0[c] == lo0[c]) {   // every value is the same
+            ok[c] = true;
+            res_a[c] = res_b[c] = lo0[c];
+        }
+        lo[c] = lo0[c];
+        inv[c] = live[c] ? uniform(static_cast<float>(kBuckets) * (1.0f - 1.0f / 1048576.0f) / width) : 0.0f;
+        live[c] = live[c] && finite_f(inv[c]);
+    }
+#pragma unroll
+    for (int level = 0; level < 2; ++level) {
+        bool any = false;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) any = any || live[c];
+        if (!any) break;
+        // ---- histogram
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int c = 0; c < 4; ++c) hist[c * HS + lane] = 0u;
+        if (lane < 4) hist[lane * HS + kBuckets] = 0u;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            if (live[c]) {
+#pragma unroll
+                for (int g = 0; g < RPL / GS; ++g) {
+                    if (g < groups) {
+#pragma unroll
+                        for (int jj = 0; jj < GS; ++jj) {
+                            const float a = mag<ABS>(x[c][g * GS + jj]);
+                            const uint32_t b = bucket_of(a, lo[c], inv[c]);
+                            if (level == 0) {
+                                atomicAdd(hist + c * HS + b, 1u);
+                            } else if (bucket_of(a, plo[c], pinv[c]) == pb[c]) {   // only the parent bucket's values
+                                atomicAdd(hist + c * HS + (b < kBuckets ? b : kBuckets - 1), 1u);
+                            }
+                        }
+                    }
+                }
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const u32x4 cnt4 = {hist[lane], hist[HS + lane], hist[2 * HS + lane], hist[3 * HS + lane]};   // lane = bucket
+        // ---- inclusive prefix sums over the 64 buckets (two columns per register: counts stay below 65536)
+        uint32_t p01 = cnt4[0] | (cnt4[1] << 16), p23 = cnt4[2] | (cnt4[3] << 16);
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t u01 = __shfl_up(p01, d, 64), u23 = __shfl_up(p23, d, 64);
+            if (lane >= d) {
+                p01 += u01;
+                p23 += u23;
+            }
+        }
+        const uint32_t incl[4] = {p01 & 0xffffu, p01 >> 16, p23 & 0xffffu, p23 >> 16};
+        // ---- target bucket(s) of every live column
+        uint32_t tb[NC], tb1[NC];
+        int n_in[NC];
+        bool extract[NC];
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            extract[c] = false;
+            tb[c] = tb1[c] = 0u;
+            n_in[c] = 0;
+            if (live[c]) {
+                const int rr = r - below[c];                      // rank inside the current range
+                const uint32_t excl = incl[c] - cnt4[c];
+                const unsigned long long m0 = __ballot(static_cast<int>(excl) <= rr && rr < static_cast<int>(incl[c]));
+                const unsigned long long m1 = __ballot(static_cast<int>(excl) <= rr + 1 && rr + 1 < static_cast<int>(incl[c]));
+                if (m0 == 0ull || (want_next && m1 == 0ull)) {    // inconsistent counts (NaN in the range?): general path
+                    live[c] = false;
+                } else {
+                    tb[c] = static_cast<uint32_t>(__builtin_ctzll(m0));
+                    tb1[c] = want_next ? static_cast<uint32_t>(__builtin_ctzll(m1)) : tb[c];
+                    const int first = __builtin_amdgcn_readlane(static_cast<int>(incl[c] - cnt4[c]), static_cast<int>(tb[c]));
+                    const int last = __builtin_amdgcn_readlane(static_cast<int>(incl[c]), static_cast<int>(tb1[c]));
+                    n_in[c] = last - first;                       // values in buckets tb .. tb1
+                    if (n_in[c] <= 64) {
+                        extract[c] = true;
+                        below[c] += first;
+                    } else if (level == 0 && tb1[c] == tb[c]) {   // split this bucket once more
+                        below[c] += first;
+                        plo[c] = lo[c];
+                        pinv[c] = inv[c];
+                        pb[c] = tb[c];
+                        const float w = 1.0f / inv[c];             // ~ bucket width
+                        lo[c] = uniform(plo[c] + (static_cast<float>(tb[c]) - 0.01f) * w);
+                        inv[c] = uniform(static_cast<float>(kBuckets) * (1.0f - 1.0f / 1048576.0f) / (1.02f * w));
+                        if (!finite_f(inv[c]) || !finite_f(lo[c])) live[c] = false;
+                    } else {
+                        live[c] = false;                          // too crowded: general path
+                    }
+                }
+            }
+        }
+        // ---- compaction of the target buckets and one 64-lane sort for all columns
+        bool any_extract = false;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) any_extract = any_extract || extract[c];
+        if (any_extract) {
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                if (extract[c]) {
+                    int n_cand = 0;
+#pragma unroll
+                    for (int g = 0; g < RPL / GS; ++g) {
+                        if (g < groups) {
+#pragma unroll
+                            for (int jj = 0; jj < GS; ++jj) {
+                                const float a = mag<ABS>(x[c][g * GS + jj]);
+                                uint32_t b = bucket_of(a, lo[c], inv[c]);
+                                bool in;
+                                if (level == 0) {
+                                    in = b >= tb[c] && b <= tb1[c];
+                                } else {
+                                    b = b < kBuckets ? b : kBuckets - 1;
+                                    in = bucket_of(a, plo[c], pinv[c]) == pb[c] && b >= tb[c] && b <= tb1[c];
+                                }
+                                const unsigned long long m = __ballot(in);
+                                if (m) {
+                                    const int pos = n_cand + __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(m >> 32),
+                                                                                        __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(m), 0));
+                                    if (in && pos < 64) cand[c * 64 + pos] = a;
+                                    n_cand += __popcll(m);
+                                }
+                            }
+                        }
+                    }
+                    if (n_cand != n_in[c]) extract[c] = false;   // the histogram and the sweep disagree: general path
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            float sv[NC][1];
+#pragma unroll
+            for (int c = 0; c < NC; ++c) sv[c][0] = (extract[c] && lane < n_in[c]) ? cand[c * 64 + lane] : pinf;
+            wave_bitonic_sort<1, NC>(sv, lane);
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                if (extract[c]) {
+                    const int i = r - below[c];
+                    res_a[c] = lane_value(sv[c][0], i & 63);
+                    res_b[c] = want_next ? lane_value(sv[c][0], (i + 1) & 63) : res_a[c];
+                    ok[c] = true;
+                    live[c] = false;
+                }
+            }
+        }
+    }
+}
+
 // Ties at exactly t beyond the keep-th value (rare with continuous data, normal when many clients submit the
 // same vector): the reference's stable sort keeps the lowest rows.  v holds the deviations.
 template <int RPL>
@@ -388,106 +589,15 @@ __device__ __forceinline__ float tied_window_sum(const float (&v)[RPL], int grou
     return sum;
 }
 
-// NC columns per wave, WAVES waves per workgroup, WAVES * NC = 16 columns per tile.  NC = 4 (4 waves) holds up to
-// 2560 rows; NC = 1 (16 waves, one column each) trades the amortisation of the probe bookkeeping for register space
-// and holds up to 5632 rows (Bulyan's second stage at N = 10,000: theta = 5200).
-template <int RPL, int NC, int WAVES>
-__global__ __launch_bounds__(64 * WAVES, (RPL * NC <= 64 ? 4 : (WAVES == 16 ? 4 : 2))) void median_window_kernel(
-    const float* __restrict__ G, int n_rows, int64_t n_cols, int64_t ld, const int32_t* __restrict__ row_index,
-    int keep, float* __restrict__ out) {
-    constexpr int JC = RPL >= 4 ? 4 : RPL;   // registers (64-row groups) per transit chunk == guard group
-    constexpr int NCH = RPL / JC;
-    constexpr int GS = JC;
-    constexpr int QUADS = kCols / 4;
-    constexpr int THREADS_ = 64 * WAVES;
-    constexpr int ROWS_PER_PASS = THREADS_ / QUADS;   // rows one staging pass of the workgroup covers
-    __shared__ __attribute__((aligned(16))) float transit[64 * JC * kStride + WAVES * 64 + 16];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    float* strip = transit + 64 * JC * kStride + wave * 64;
-    int* nonfinite = reinterpret_cast<int*>(transit + 64 * JC * kStride + WAVES * 64);   // one flag per column quad
-    const int64_t c_base = static_cast<int64_t>(blockIdx.x) * kCols;
+// Everything after the tile's values sit in registers: NaN screening, the two selections, the window sum, the store.
+template <int RPL, int NC>
+__device__ __forceinline__ void finish_tile(float (&x)[NC][RPL], const float (&mn)[NC], const float (&mx)[NC],
+                                            bool suspicious, int chunks, int slots, int n_rows, int keep, int lane,
+                                            int wave, float* strip, int64_t c_base, int64_t n_cols,
+                                            float* __restrict__ out) {
+    constexpr int GS = RPL >= 4 ? 4 : RPL;
     const float pinf = __builtin_inff();
     const float qnan = __uint_as_float(0x7fc00000u);
-    const int chunks = (n_rows + 64 * JC - 1) / (64 * JC);   // == guard groups in use
-    const int slots = chunks * 64 * JC;
-
-    if (tid < QUADS) nonfinite[tid] = 0;
-
-    // ---- stage: global (128-byte row segments) -> LDS transit -> registers (4 columns x RPL rows per lane)
-    const int ld_q = (tid % QUADS) * 4, ld_r = tid / QUADS;
-    const int64_t ld_c = c_base + ld_q;
-    constexpr int PASSES = 64 * JC / ROWS_PER_PASS;   // float4 loads per thread per chunk
-    f32x4 tmp[PASSES];
-    float poison = 0.0f;   // x * 0 accumulates to NaN as soon as one loaded value is NaN or +-inf
-    auto fetch = [&](int ch) {
-#pragma unroll
-        for (int p = 0; p < PASSES; ++p) {
-            const int row = ch * 64 * JC + ROWS_PER_PASS * p + ld_r;
-            f32x4 val = {pinf, pinf, pinf, pinf};
-            if (row < n_rows) {
-                const int64_t src = row_index ? row_index[row] : row;
-                const float* ptr = G + src * ld + ld_c;
-                if (ld_c + 4 <= n_cols) {
-                    val = *reinterpret_cast<const f32x4u*>(ptr);
-                } else {  // ragged last tile: columns past the matrix are computed on zeros and never stored
-                    val = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-                    if (ld_c + 0 < n_cols) val.x = ptr[0];
-                    if (ld_c + 1 < n_cols) val.y = ptr[1];
-                    if (ld_c + 2 < n_cols) val.z = ptr[2];
-                }
-            }
-            tmp[p] = val;
-        }
-    };
-    auto stash = [&](int ch) {
-#pragma unroll
-        for (int p = 0; p < PASSES; ++p) {
-            const f32x4 val = tmp[p];
-            if (ch * 64 * JC + ROWS_PER_PASS * p + ld_r < n_rows)
-                poison = __builtin_fmaf(val.x + val.y, 0.0f, __builtin_fmaf(val.z + val.w, 0.0f, poison));
-            *reinterpret_cast<f32x4*>(transit + (ROWS_PER_PASS * p + ld_r) * kStride + ld_q) = val;
-        }
-    };
-    float x[NC][RPL];
-    float mn[NC], mx[NC];
-#pragma unroll
-    for (int c = 0; c < NC; ++c) {
-        mn[c] = pinf;
-        mx[c] = -pinf;
-    }
-    fetch(0);
-#pragma unroll
-    for (int ch = 0; ch < NCH; ++ch) {
-        if (ch < chunks) {
-            stash(ch);
-            if (ch + 1 < chunks) fetch(ch + 1);
-            __syncthreads();
-            const bool last_chunk = ch == chunks - 1;   // uniform: only this chunk can hold padding rows
-#pragma unroll
-            for (int jj = 0; jj < JC; ++jj) {
-                float val[NC];
-                if constexpr (NC == 4) {
-                    const f32x4 v4 = *reinterpret_cast<const f32x4*>(transit + (64 * jj + lane) * kStride + 4 * wave);
-                    val[0] = v4.x; val[1 % NC] = v4.y; val[2 % NC] = v4.z; val[3 % NC] = v4.w;
-                } else {
-                    val[0] = transit[(64 * jj + lane) * kStride + wave];
-                }
-                const bool real = !last_chunk || (ch * 64 * JC + 64 * jj + lane < n_rows);
-#pragma unroll
-                for (int c = 0; c < NC; ++c) {
-                    const float e = val[c];
-                    x[c][ch * JC + jj] = e;
-                    mn[c] = __builtin_fminf(mn[c], e);                 // +inf padding never wins a minimum
-                    mx[c] = __builtin_fmaxf(mx[c], real ? e : -pinf);  // and is masked out of the maximum
-                }
-            }
-            __syncthreads();
-        }
-    }
-    if (poison != poison) nonfinite[tid % QUADS] = 1;
-    __syncthreads();
-    const bool suspicious = uniform(nonfinite[NC == 4 ? wave : wave / 4]) != 0;   // an LDS load is per-lane to the compiler: make it scalar
-
     Bracket q[4];
     bool dead[NC];       // the column's result is NaN
 #pragma unroll
@@ -551,7 +661,27 @@ __global__ __launch_bounds__(64 * WAVES, (RPL * NC <= 64 ? 4 : (WAVES == 16 ? 4 
     }
 #pragma unroll
     for (int c = NC; c < 4; ++c) q[c] = Bracket{0.0f, 0.0f, 0, 0, 0.0f, 0.0f};
-    select4<RPL, NC, false>(x, chunks, slots, r_med, even, q, lane, strip);
+    {
+        bool want[NC], got[NC];
+        float ba[NC], bb[NC];
+#pragma unroll
+        for (int c = 0; c < NC; ++c) want[c] = run_med[c] && lo_x[c] > -pinf;
+        // (the one-column-per-wave variant has no registers to spare for the bucket bookkeeping: probing search only)
+        if constexpr (NC == 4) bucket_select<RPL, NC, false>(x, chunks, r_med, even, lo_x, hi_x, want, ba, bb, got, lane, strip);
+        else for (int c = 0; c < NC; ++c) got[c] = false;
+        bool generic = false;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) generic = generic || (run_med[c] && !got[c]);
+        if (generic) {
+            select4<RPL, NC, false>(x, chunks, slots, r_med, even, q, lane, strip);
+        } else {
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                q[c].a = run_med[c] ? ba[c] : 0.0f;
+                q[c].b = run_med[c] ? bb[c] : 0.0f;
+            }
+        }
+    }
 #pragma unroll
     for (int c = 0; c < NC; ++c) med[c] = uniform(even ? __fmul_rn(__fadd_rn(q[c].a, q[c].b), 0.5f) : q[c].a);
 
@@ -580,7 +710,27 @@ __global__ __launch_bounds__(64 * WAVES, (RPL * NC <= 64 ? 4 : (WAVES == 16 ? 4 
         }
     }
     // ---- t = the keep-th smallest |deviation|
-    select4<RPL, NC, true>(x, chunks, slots, keep - 1, false, q, lane, strip);
+    {
+        bool want[NC], got[NC];
+        float ba[NC], bb[NC], zero[NC], top[NC];
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            want[c] = !dead[c];
+            zero[c] = 0.0f;
+            top[c] = q[c].hi;   // max |deviation|
+        }
+        if constexpr (NC == 4) bucket_select<RPL, NC, true>(x, chunks, keep - 1, false, zero, top, want, ba, bb, got, lane, strip);
+        else for (int c = 0; c < NC; ++c) got[c] = false;
+        bool generic = false;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) generic = generic || (!dead[c] && !got[c]);
+        if (generic) {
+            select4<RPL, NC, true>(x, chunks, slots, keep - 1, false, q, lane, strip);
+        } else {
+#pragma unroll
+            for (int c = 0; c < NC; ++c) q[c].a = dead[c] ? 0.0f : ba[c];
+        }
+    }
 
     // ---- window sum: everything with |d| <= t, when that is exactly `keep` values
     float result[NC];
@@ -616,12 +766,226 @@ __global__ __launch_bounds__(64 * WAVES, (RPL * NC <= 64 ? 4 : (WAVES == 16 ? 4 
     }
 }
 
+// NC columns per wave, WAVES waves per workgroup, WAVES * NC = 16 columns per tile.  NC = 4 (4 waves) holds up to
+// 2560 rows; NC = 1 (16 waves, one column each) trades the amortisation of the probe bookkeeping for register space
+// and holds up to 5632 rows (Bulyan's second stage at N = 10,000: theta = 5200).
+template <int RPL, int NC, int WAVES>
+__global__ __launch_bounds__(64 * WAVES, (RPL * NC <= 64 || WAVES == 16 ? 4 : 2)) void median_window_kernel(
+    const float* __restrict__ G, int n_rows, int64_t n_cols, int64_t ld, const int32_t* __restrict__ row_index,
+    int keep, float* __restrict__ out, int stagger_cycles) {
+    constexpr int JC = RPL >= 4 ? 4 : RPL;   // registers (64-row groups) per transit chunk == guard group
+    constexpr int NCH = RPL / JC;
+    constexpr int GS = JC;
+    constexpr int COLS = WAVES * NC;          // columns per tile
+    constexpr int STRIDE = COLS + 4;          // floats per LDS row: 16-byte aligned, conflict-free b128 column reads
+    constexpr int QUADS = COLS / 4;
+    constexpr int THREADS_ = 64 * WAVES;
+    constexpr int ROWS_PER_PASS = THREADS_ / QUADS;   // rows one staging pass of the workgroup covers
+    __shared__ __attribute__((aligned(16))) float transit[64 * JC * STRIDE + WAVES * kWaveScratch + 16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    float* strip = transit + 64 * JC * STRIDE + wave * kWaveScratch;   // per-wave scratch: strip, histogram, candidates
+    int* nonfinite = reinterpret_cast<int*>(transit + 64 * JC * STRIDE + WAVES * kWaveScratch);   // one flag per column quad
+    const int64_t c_base = static_cast<int64_t>(blockIdx.x) * COLS;
+    const float pinf = __builtin_inff();
+    const float qnan = __uint_as_float(0x7fc00000u);
+    const int chunks = (n_rows + 64 * JC - 1) / (64 * JC);   // == guard groups in use
+    const int slots = chunks * 64 * JC;
+
+    if (tid < QUADS) nonfinite[tid] = 0;
+
+    // Phase stagger.  All workgroups of a CU start together and take equally long, so left alone they load together and
+    // then compute together, and load time and compute time add up.  The first generation of workgroups (one per
+    // resident slot; workgroups are dealt 8 XCDs x 32 CUs round-robin, so blockIdx >> 8 is the slot within the CU) is
+    // delayed by a quarter of a tile time per slot; every later workgroup starts when an earlier one ends, so the offsets
+    // persist and one slot's loads overlap the other slots' arithmetic.  Only speed depends on it.
+    if (stagger_cycles > 0 && blockIdx.x < 1024u) {
+        const int phase = static_cast<int>(blockIdx.x >> 8);
+        for (int i = 0; i < phase * stagger_cycles; i += 4096) __builtin_amdgcn_s_sleep(64);   // 64 x 64 cycles
+    }
+
+    // ---- stage: global (128-byte row segments) -> LDS transit -> registers (4 columns x RPL rows per lane)
+    const int ld_q = (tid % QUADS) * 4, ld_r = tid / QUADS;
+    const int64_t ld_c = c_base + ld_q;
+    constexpr int PASSES = 64 * JC / ROWS_PER_PASS;   // float4 loads per thread per chunk
+    f32x4 tmp[PASSES];
+    float poison = 0.0f;   // x * 0 accumulates to NaN as soon as one loaded value is NaN or +-inf
+    auto fetch = [&](int ch) {
+#pragma unroll
+        for (int p = 0; p < PASSES; ++p) {
+            const int row = ch * 64 * JC + ROWS_PER_PASS * p + ld_r;
+            f32x4 val = {pinf, pinf, pinf, pinf};
+            if (row < n_rows) {
+                const int64_t src = row_index ? row_index[row] : row;
+                const float* ptr = G + src * ld + ld_c;
+                if (ld_c + 4 <= n_cols) {
+                    val = *reinterpret_cast<const f32x4u*>(ptr);
+                } else {  // ragged last tile: columns past the matrix are computed on zeros and never stored
+                    val = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+                    if (ld_c + 0 < n_cols) val.x = ptr[0];
+                    if (ld_c + 1 < n_cols) val.y = ptr[1];
+                    if (ld_c + 2 < n_cols) val.z = ptr[2];
+                }
+            }
+            tmp[p] = val;
+        }
+    };
+    auto stash = [&](int ch) {
+#pragma unroll
+        for (int p = 0; p < PASSES; ++p) {
+            const f32x4 val = tmp[p];
+            if (ch * 64 * JC + ROWS_PER_PASS * p + ld_r < n_rows)
+                poison = __builtin_fmaf(val.x + val.y, 0.0f, __builtin_fmaf(val.z + val.w, 0.0f, poison));
+            *reinterpret_cast<f32x4*>(transit + (ROWS_PER_PASS * p + ld_r) * STRIDE + ld_q) = val;
+        }
+    };
+    float x[NC][RPL];
+    float mn[NC], mx[NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        mn[c] = pinf;
+        mx[c] = -pinf;
+    }
+    fetch(0);
+#pragma unroll
+    for (int ch = 0; ch < NCH; ++ch) {
+        if (ch < chunks) {
+            stash(ch);
+            if (ch + 1 < chunks) fetch(ch + 1);
+            __syncthreads();
+            const bool last_chunk = ch == chunks - 1;   // uniform: only this chunk can hold padding rows
+#pragma unroll
+            for (int jj = 0; jj < JC; ++jj) {
+                float val[NC];
+                if constexpr (NC == 4) {
+                    const f32x4 v4 = *reinterpret_cast<const f32x4*>(transit + (64 * jj + lane) * STRIDE + 4 * wave);
+                    val[0] = v4.x; val[1 % NC] = v4.y; val[2 % NC] = v4.z; val[3 % NC] = v4.w;
+                } else {
+                    val[0] = transit[(64 * jj + lane) * STRIDE + wave];
+                }
+                const bool real = !last_chunk || (ch * 64 * JC + 64 * jj + lane < n_rows);
+#pragma unroll
+                for (int c = 0; c < NC; ++c) {
+                    const float e = val[c];
+                    x[c][ch * JC + jj] = e;
+                    mn[c] = __builtin_fminf(mn[c], e);                 // +inf padding never wins a minimum
+                    mx[c] = __builtin_fmaxf(mx[c], real ? e : -pinf);  // and is masked out of the maximum
+                }
+            }
+            __syncthreads();
+        }
+    }
+    if (poison != poison) nonfinite[tid % QUADS] = 1;
+    __syncthreads();
+    const bool suspicious = uniform(nonfinite[NC == 4 ? wave : wave / 4]) != 0;   // an LDS load is per-lane to the compiler: make it scalar
+
+    finish_tile<RPL, NC>(x, mn, mx, suspicious, chunks, slots, n_rows, keep, lane, wave, strip, c_base, n_cols, out);
+}
+
+// Persistent LDS-DMA variant for up to 1024 rows (the trimmed-mean sizes of the reference: N <= 1000 clients).
+//
+// The kernel above loads a tile, then computes on it, and every workgroup of a CU does so in the same phase (they
+// start together and take equally long), so the load time and the compute time ADD: 1.15 ms + 1.7 ms at C3.  Here a
+// workgroup walks over many tiles, and while it computes on tile t (in registers) the whole of tile t + 1 is already
+// streaming into LDS by LDS-DMA: no VGPRs, no ds_write pass, 16 wave-instructions of 1 KiB each per wave in flight.
+//   LDS image: [row][16 floats]; `global_load_lds` writes wave-uniform base + 16 * lane, so a wave-instruction covers
+//   16 rows x 4 quads.  Reading one quad down 64 rows would hit four bank groups only; the quad index is XOR-ed with
+//   (row >> 2) & 3 on the DMA's source address and on the read.
+//   Rows past R are +inf, written once (masked lanes of the DMA never touch them).
+// Requires 16-byte aligned row segments (ld % 4 == 0, n_cols % 4 == 0, aligned base); anything else takes the kernel above.
+template <int RPL>
+__global__ __launch_bounds__(256, (RPL <= 8 ? 4 : 2)) void median_window_dma_kernel(
+    const float* __restrict__ G, int n_rows, int64_t n_cols, int64_t ld, const int32_t* __restrict__ row_index,
+    int keep, float* __restrict__ out, int64_t n_tiles) {
+    constexpr int NC = 4, WAVES = 4;
+    constexpr int GS = RPL >= 4 ? 4 : RPL;
+    constexpr int ROWS = 64 * RPL;
+    __shared__ __attribute__((aligned(16))) float tile[ROWS * 16 + WAVES * kWaveScratch];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    float* strip = tile + ROWS * 16 + wave * kWaveScratch;
+    const float pinf = __builtin_inff();
+    const int chunks = (n_rows + 64 * GS - 1) / (64 * GS);   // guard groups in use
+    const int slots = chunks * 64 * GS;
+
+    // padding rows, once
+    for (int i = n_rows * 4 + tid; i < slots * 4; i += 256)
+        *reinterpret_cast<f32x4*>(tile + i * 4) = f32x4{pinf, pinf, pinf, pinf};
+
+    const int64_t last_quad_col = n_cols - 4;
+    auto issue = [&](int64_t t) __attribute__((always_inline)) {
+        const int64_t c_base = t * kCols;
+        for (int r0 = wave * 16; r0 < n_rows; r0 += 64) {   // 16 rows per wave-instruction
+            const int row = r0 + (lane >> 2);
+            if (row < n_rows) {
+                const int64_t src = row_index ? row_index[row] : row;
+                const int quad = (lane & 3) ^ ((row >> 2) & 3);
+                int64_t col = c_base + 4 * quad;
+                if (col > last_quad_col) col = last_quad_col;   // ragged last tile: duplicates, never stored
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(G + src * ld + col),
+                                                 (__attribute__((address_space(3))) void*)(tile + r0 * 16), 16, 0, 0);
+            }
+        }
+    };
+
+    int64_t t = blockIdx.x;
+    if (t < n_tiles) issue(t);
+    for (; t < n_tiles; t += gridDim.x) {
+        __syncthreads();   // the DMA of this tile has landed (hipcc waits vmcnt(0) here) and is visible to every wave
+        float x[NC][RPL];
+        float mn[NC], mx[NC];
+        float poison = 0.0f;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            mn[c] = pinf;
+            mx[c] = -pinf;
+        }
+#pragma unroll
+        for (int g = 0; g < RPL / GS; ++g) {
+            if (g < chunks) {
+                const bool last_group = g == chunks - 1;
+#pragma unroll
+                for (int jj = 0; jj < GS; ++jj) {
+                    const int row = 64 * (g * GS + jj) + lane;
+                    const f32x4 v4 = *reinterpret_cast<const f32x4*>(tile + row * 16 + ((wave ^ ((row >> 2) & 3)) << 2));
+                    const bool real = !last_group || row < n_rows;
+                    const float val[4] = {v4.x, v4.y, v4.z, v4.w};
+                    poison = __builtin_fmaf(real ? (v4.x + v4.y) + (v4.z + v4.w) : 0.0f, 0.0f, poison);
+#pragma unroll
+                    for (int c = 0; c < NC; ++c) {
+                        const float e = val[c];
+                        x[c][g * GS + jj] = e;
+                        mn[c] = __builtin_fminf(mn[c], e);
+                        mx[c] = __builtin_fmaxf(mx[c], real ? e : -pinf);
+                    }
+                }
+            }
+        }
+        const bool suspicious = __ballot(poison != poison) != 0ull;
+        __syncthreads();   // every wave holds its values: the LDS tile is free again
+        if (t + gridDim.x < n_tiles) issue(t + gridDim.x);
+        finish_tile<RPL, NC>(x, mn, mx, suspicious, chunks, slots, n_rows, keep, lane, wave, strip, t * kCols, n_cols, out);
+    }
+}
+
+template <int RPL>
+int launch_dma(byz_ctx* ctx, const float* G, int64_t n_rows, int64_t n_cols, int64_t ld, const int32_t* row_index,
+               int64_t keep, float* out, hipStream_t stream) {
+    const int64_t n_tiles = ceil_div(n_cols, kCols);
+    const int per_cu = RPL <= 8 ? 4 : 2;
+    int64_t grid = static_cast<int64_t>(ctx->num_cus) * per_cu;
+    if (grid > n_tiles) grid = n_tiles;
+    median_window_dma_kernel<RPL><<<static_cast<unsigned>(grid), 256, 0, stream>>>(
+        G, static_cast<int>(n_rows), n_cols, ld, row_index, static_cast<int>(keep), out, n_tiles);
+    return check_launch("median_window_dma_kernel");
+}
+
 template <int RPL, int NC, int WAVES>
 int launch_rpl(const float* G, int64_t n_rows, int64_t n_cols, int64_t ld, const int32_t* row_index, int64_t keep,
                float* out, hipStream_t stream) {
-    const int64_t n_tiles = ceil_div(n_cols, kCols);
+    const int64_t n_tiles = ceil_div(n_cols, static_cast<int64_t>(WAVES * NC));
     median_window_kernel<RPL, NC, WAVES><<<static_cast<unsigned>(n_tiles), 64 * WAVES, 0, stream>>>(
-        G, static_cast<int>(n_rows), n_cols, ld, row_index, static_cast<int>(keep), out);
+        G, static_cast<int>(n_rows), n_cols, ld, row_index, static_cast<int>(keep), out,
+        std::getenv("BYZ_TM_STAGGER") ? std::atoi(std::getenv("BYZ_TM_STAGGER")) : RPL * NC * 450);
     return check_launch("median_window_kernel");
 }
 
@@ -644,10 +1008,19 @@ int launch_trimmed_mean(byz_ctx* ctx, const float* G, int64_t n_rows, int64_t n_
         if (rpl >= from && rpl <= 64) return launch_rpl<64, 1, 16>(G, n_rows, n_cols, ld, row_index, keep, out, stream);
     }
     if (rpl > 88) return launch_trimmed_mean_sorted(ctx, G, n_rows, n_cols, ld, row_index, keep, out, stream);
+    // 16-byte aligned row segments and at most 1024 rows: the persistent LDS-DMA kernel
+    const bool dma_ok = (ld % 4 == 0) && (n_cols % 4 == 0) && (reinterpret_cast<uintptr_t>(G) % 16 == 0) && rpl <= 16 &&
+                        std::getenv("BYZ_TM_DMA") != nullptr;   // measured slower than the staggered kernel (2 waves per SIMD)
+    if (dma_ok) {
+        if (rpl <= 4) return launch_dma<4>(ctx, G, n_rows, n_cols, ld, row_index, keep, out, stream);
+        if (rpl <= 8) return launch_dma<8>(ctx, G, n_rows, n_cols, ld, row_index, keep, out, stream);
+        return launch_dma<16>(ctx, G, n_rows, n_cols, ld, row_index, keep, out, stream);
+    }
     if (rpl <= 1) return launch_rpl<1, 4, 4>(G, n_rows, n_cols, ld, row_index, keep, out, stream);
     if (rpl <= 2) return launch_rpl<2, 4, 4>(G, n_rows, n_cols, ld, row_index, keep, out, stream);
     if (rpl <= 4) return launch_rpl<4, 4, 4>(G, n_rows, n_cols, ld, row_index, keep, out, stream);
     if (rpl <= 8) return launch_rpl<8, 4, 4>(G, n_rows, n_cols, ld, row_index, keep, out, stream);
+    if (rpl <= 16 && std::getenv("BYZ_TM_W8")) return launch_rpl<16, 4, 8>(G, n_rows, n_cols, ld, row_index, keep, out, stream);
     if (rpl <= 16) return launch_rpl<16, 4, 4>(G, n_rows, n_cols, ld, row_index, keep, out, stream);
     if (rpl <= 24) return launch_rpl<24, 4, 4>(G, n_rows, n_cols, ld, row_index, keep, out, stream);
     if (rpl <= 32) return launch_rpl<32, 4, 4>(G, n_rows, n_cols, ld, row_index, keep, out, stream);
