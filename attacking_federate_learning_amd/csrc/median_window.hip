@@ -773,9 +773,9 @@ template <int RPL, int NC, int WAVES>
 __global__ __launch_bounds__(64 * WAVES, (RPL * NC <= 64 || WAVES == 16 ? 4 : 2)) void median_window_kernel(
     const float* __restrict__ G, int n_rows, int64_t n_cols, int64_t ld, const int32_t* __restrict__ row_index,
     int keep, float* __restrict__ out, int stagger_cycles) {
-    constexpr int JC = RPL >= 4 ? 4 : RPL;   // registers (64-row groups) per transit chunk == guard group
+    constexpr int GS = RPL >= 4 ? 4 : RPL;                    // registers (64-row groups) per guard group
+    constexpr int JC = GS;   // registers per transit chunk (512-row chunks cost a wave per SIMD of occupancy: 2.38 -> 2.96 ms)
     constexpr int NCH = RPL / JC;
-    constexpr int GS = JC;
     constexpr int COLS = WAVES * NC;          // columns per tile
     constexpr int STRIDE = COLS + 4;          // floats per LDS row: 16-byte aligned, conflict-free b128 column reads
     constexpr int QUADS = COLS / 4;
@@ -788,8 +788,9 @@ __global__ __launch_bounds__(64 * WAVES, (RPL * NC <= 64 || WAVES == 16 ? 4 : 2)
     const int64_t c_base = static_cast<int64_t>(blockIdx.x) * COLS;
     const float pinf = __builtin_inff();
     const float qnan = __uint_as_float(0x7fc00000u);
-    const int chunks = (n_rows + 64 * JC - 1) / (64 * JC);   // == guard groups in use
-    const int slots = chunks * 64 * JC;
+    const int chunks = (n_rows + 64 * JC - 1) / (64 * JC);   // transit chunks to stage
+    const int groups = (n_rows + 64 * GS - 1) / (64 * GS);   // guard groups in use
+    const int slots = groups * 64 * GS;
 
     if (tid < QUADS) nonfinite[tid] = 0;
 
@@ -797,7 +798,8 @@ __global__ __launch_bounds__(64 * WAVES, (RPL * NC <= 64 || WAVES == 16 ? 4 : 2)
     // then compute together, and load time and compute time add up.  The first generation of workgroups (one per
     // resident slot; workgroups are dealt 8 XCDs x 32 CUs round-robin, so blockIdx >> 8 is the slot within the CU) is
     // delayed by a quarter of a tile time per slot; every later workgroup starts when an earlier one ends, so the offsets
-    // persist and one slot's loads overlap the other slots' arithmetic.  Only speed depends on it.
+    // persist and one slot's loads overlap the other slots' arithmetic.  Only speed depends on it.  (Measured on C3: no
+    // effect at any delay, so the default is off: the phases are not what keeps staging and selection from overlapping.)
     if (stagger_cycles > 0 && blockIdx.x < 1024u) {
         const int phase = static_cast<int>(blockIdx.x >> 8);
         for (int i = 0; i < phase * stagger_cycles; i += 4096) __builtin_amdgcn_s_sleep(64);   // 64 x 64 cycles
@@ -878,7 +880,7 @@ __global__ __launch_bounds__(64 * WAVES, (RPL * NC <= 64 || WAVES == 16 ? 4 : 2)
     __syncthreads();
     const bool suspicious = uniform(nonfinite[NC == 4 ? wave : wave / 4]) != 0;   // an LDS load is per-lane to the compiler: make it scalar
 
-    finish_tile<RPL, NC>(x, mn, mx, suspicious, chunks, slots, n_rows, keep, lane, wave, strip, c_base, n_cols, out);
+    finish_tile<RPL, NC>(x, mn, mx, suspicious, groups, slots, n_rows, keep, lane, wave, strip, c_base, n_cols, out);
 }
 
 // Persistent LDS-DMA variant for up to 1024 rows (the trimmed-mean sizes of the reference: N <= 1000 clients).
@@ -985,7 +987,7 @@ int launch_rpl(const float* G, int64_t n_rows, int64_t n_cols, int64_t ld, const
     const int64_t n_tiles = ceil_div(n_cols, static_cast<int64_t>(WAVES * NC));
     median_window_kernel<RPL, NC, WAVES><<<static_cast<unsigned>(n_tiles), 64 * WAVES, 0, stream>>>(
         G, static_cast<int>(n_rows), n_cols, ld, row_index, static_cast<int>(keep), out,
-        std::getenv("BYZ_TM_STAGGER") ? std::atoi(std::getenv("BYZ_TM_STAGGER")) : RPL * NC * 450);
+        std::getenv("BYZ_TM_STAGGER") ? std::atoi(std::getenv("BYZ_TM_STAGGER")) : 0);   // measured: no effect, off
     return check_launch("median_window_kernel");
 }
 
