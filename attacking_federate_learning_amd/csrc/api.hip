@@ -173,6 +173,11 @@ int byz_ctx_reserve(byz_ctx* ctx, int64_t n_rows, int64_t n_cols) {
     BYZ_TRY(ctx->row_top.ensure(static_cast<size_t>(n_rows) * sizeof(double)));
     BYZ_TRY(ctx->stage_out.ensure(static_cast<size_t>(n_cols) * 3 * sizeof(float)));
     BYZ_TRY(ctx->pinned.ensure(static_cast<size_t>(n_rows) * sizeof(int32_t) + 64));
+    {   // the Gram's schedule words and the duplicate-row table
+        const int64_t T = ceil_div(n_rows, 128);
+        BYZ_TRY(ctx->gram_tickets.ensure(static_cast<size_t>(T * (T + 1) / 2 + 8) * sizeof(int32_t)));
+        BYZ_TRY(ctx->dup_rep.ensure(static_cast<size_t>(n_rows + 1) * sizeof(int32_t)));
+    }
     return BYZ_OK;
 }
 

@@ -538,6 +538,24 @@ __global__ __launch_bounds__(256) void duplicate_rep_kernel(const float* __restr
     }
 }
 
+// rep[] chains (i -> j -> k when "zero distance" came from cancellation rather than identity and is not transitive) are
+// followed to their root, so that the copy below only ever reads rows and columns nobody writes.
+__global__ __launch_bounds__(1024) void duplicate_compress_kernel(int64_t n, int32_t* __restrict__ rep,
+                                                                  const int32_t* __restrict__ any) {
+    if (*any == 0) return;
+    for (int round = 0; round < 16; ++round) {   // rep[i] < i along a chain: pointer jumping converges in log2(n) rounds
+        bool changed = false;
+        for (int64_t i = threadIdx.x; i < n; i += blockDim.x) {
+            const int32_t r = rep[i], rr = rep[r];
+            if (rr != r) {
+                rep[i] = rr;
+                changed = true;
+            }
+        }
+        if (!__syncthreads_or(changed ? 1 : 0)) break;
+    }
+}
+
 __global__ __launch_bounds__(256) void duplicate_copy_kernel(float* __restrict__ dist, int64_t n,
                                                              const int32_t* __restrict__ rep,
                                                              const int32_t* __restrict__ any) {
@@ -702,6 +720,8 @@ int launch_distances_from_gram(byz_ctx* ctx, const double* gram, int64_t n, floa
     BYZ_HIP(hipMemsetAsync(rep + n, 0, sizeof(int32_t), stream));
     duplicate_rep_kernel<<<static_cast<unsigned>(ceil_div(n, 4)), 256, 0, stream>>>(dist, n, rep, rep + n);
     BYZ_TRY(check_launch("duplicate_rep_kernel"));
+    duplicate_compress_kernel<<<1, 1024, 0, stream>>>(n, rep, rep + n);
+    BYZ_TRY(check_launch("duplicate_compress_kernel"));
     duplicate_copy_kernel<<<grid, 256, 0, stream>>>(dist, n, rep, rep + n);
     return check_launch("duplicate_copy_kernel");
 }

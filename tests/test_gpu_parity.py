@@ -231,6 +231,27 @@ def test_trimmed_mean_general_kernel(eng, n, d):
     assert close(eng.trimmed_mean(g, n, c), ideal.trimmed_mean(g, c))
 
 
+@pytest.mark.parametrize('n,m', [(300, 72), (1000, 240), (130, 129)])
+def test_trimmed_mean_with_many_identical_rows(eng, n, m):
+    """More than 64 clients submit the same vector (the attack's normal case): a bucket then holds more equal values
+    than the 64-lane sort takes and the kernel must fall back to the probing search."""
+    g = scaled(5100 + n, n, 257)
+    g[:m] = faithful.drift_vector(g[:m].copy(), 1.5)
+    c = n // 5
+    assert close(eng.trimmed_mean(g, n, c), ideal.trimmed_mean(g, c))
+    assert close(eng.trimmed_mean(g[:, :64], n, c), faithful.trimmed_mean(g[:, :64], n, c))
+
+
+def test_trimmed_mean_with_outliers(eng):
+    """+-1e30 outliers squeeze every other value into one bucket of the first histogram."""
+    g = gaussian(5200, 1000, 300)
+    g[3, :] = 1e30
+    g[700, ::2] = -1e30
+    g[11, 5] = np.inf
+    want = ideal.trimmed_mean(g, 200)
+    assert close(eng.trimmed_mean(g, 1000, 200), want)
+
+
 def test_trimmed_mean_row_index_orders_the_rows(eng):
     g = (np.round(gaussian(61, 60, 200)) ).astype(np.float32)   # integers: ties everywhere
     order = np.random.default_rng(3).permutation(60)[:41].astype(np.int32)
