@@ -350,6 +350,14 @@ __device__ __forceinline__ void select4(const float (&x)[NC][RPL], int groups, i
 // Padding (+inf) lands in an extra bucket 64 that nothing reads.
 // ---------------------------------------------------------------------------------------------------------------
 constexpr int kBuckets = 64;
+// The target bucket must fit one 64-lane sort.  With rows/64 values per bucket on average the central bucket of a
+// bell-shaped column overflows from about 1500 rows, and a failed attempt is pure overhead (measured at theta = 2080:
+// 74 ms without the attempt, 110 ms with it), so the fast path is compiled only for tiles of at most this many rows
+// per lane.
+#ifndef BYZ_BUCKET_MAX_RPL
+#define BYZ_BUCKET_MAX_RPL 16
+#endif
+constexpr int kBucketMaxRpl = BYZ_BUCKET_MAX_RPL;
 constexpr int kWaveScratch = 64 + (kBuckets + 1) * 4 + 4 * 64;   // floats per wave: strip, histogram, candidates
 
 __device__ __forceinline__ uint32_t bucket_of(float a, float lo, float inv) {
@@ -667,7 +675,7 @@ __device__ __forceinline__ void finish_tile(float (&x)[NC][RPL], const float (&m
 #pragma unroll
         for (int c = 0; c < NC; ++c) want[c] = run_med[c] && lo_x[c] > -pinf;
         // (the one-column-per-wave variant has no registers to spare for the bucket bookkeeping: probing search only)
-        if constexpr (NC == 4) bucket_select<RPL, NC, false>(x, chunks, r_med, even, lo_x, hi_x, want, ba, bb, got, lane, strip);
+        if constexpr (NC == 4 && RPL <= kBucketMaxRpl) bucket_select<RPL, NC, false>(x, chunks, r_med, even, lo_x, hi_x, want, ba, bb, got, lane, strip);
         else for (int c = 0; c < NC; ++c) got[c] = false;
         bool generic = false;
 #pragma unroll
@@ -719,7 +727,7 @@ __device__ __forceinline__ void finish_tile(float (&x)[NC][RPL], const float (&m
             zero[c] = 0.0f;
             top[c] = q[c].hi;   // max |deviation|
         }
-        if constexpr (NC == 4) bucket_select<RPL, NC, true>(x, chunks, keep - 1, false, zero, top, want, ba, bb, got, lane, strip);
+        if constexpr (NC == 4 && RPL <= kBucketMaxRpl) bucket_select<RPL, NC, true>(x, chunks, keep - 1, false, zero, top, want, ba, bb, got, lane, strip);
         else for (int c = 0; c < NC; ++c) got[c] = false;
         bool generic = false;
 #pragma unroll
