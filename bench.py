@@ -433,6 +433,13 @@ def main():
                 torch.cuda.empty_cache()
             line['other_workloads'] = extras
     if rank == 0:
+        # RCCL writes its NCCL_DEBUG=VERSION banner through C stdio, which a pipe buffers until exit: push it out
+        # first so that the JSON line is the last thing on stdout
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except OSError:
+            pass
         print(json.dumps(line), flush=True)
     if dist.is_initialized():
         dist.destroy_process_group()
