@@ -793,16 +793,8 @@ __global__ __launch_bounds__(64 * WAVES, (RPL * NC <= 64 || WAVES == 16 ? 4 : 2)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     float* strip = transit + 64 * JC * STRIDE + wave * kWaveScratch;   // per-wave scratch: strip, histogram, candidates
     int* nonfinite = reinterpret_cast<int*>(transit + 64 * JC * STRIDE + WAVES * kWaveScratch);   // one flag per column quad
-    // Workgroups are dealt to the 8 XCDs round-robin (observed; only speed depends on it).  Give each XCD a contiguous
-    // range of column tiles: the two tiles that share a 128-byte line of every row then run on the SAME XCD at about
-    // the same time, and its L2 asks HBM for the line once instead of two XCDs asking for 64 bytes each.
-    int64_t tile = blockIdx.x;
-    if (stagger_cycles >= 0) {
-        const int64_t n_tiles = gridDim.x, q = n_tiles >> 3, r = n_tiles & 7;
-        const int64_t xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
-        tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-    }
-    const int64_t c_base = tile * COLS;
+    // (an XCD-contiguous tile order, so that the two tiles sharing a 128-byte line run on one XCD, measured no effect)
+    const int64_t c_base = static_cast<int64_t>(blockIdx.x) * COLS;
     const float pinf = __builtin_inff();
     const float qnan = __uint_as_float(0x7fc00000u);
     const int chunks = (n_rows + 64 * JC - 1) / (64 * JC);   // transit chunks to stage
