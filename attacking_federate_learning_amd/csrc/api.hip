@@ -355,6 +355,44 @@ int byz_server_update_dev(byz_ctx* ctx, float* weights, float* velocity, const f
     return launch_server_update(ctx, weights, velocity, agg, n, momentum, learning_rate, as_stream(stream));
 }
 
+// ---- the steps either side of the path -------------------------------------------
+int byz_backdoor_initial_params_dev(byz_ctx* ctx, const float* original_params, const float* grads_mean, int64_t n,
+                                    float learning_rate, float* out, void* stream) {
+    BYZ_TRY(enter(ctx));
+    BYZ_REQUIRE(original_params && grads_mean && out && n > 0, "backdoor_initial_params: bad arguments");
+    return launch_backdoor_initial(ctx, original_params, grads_mean, n, learning_rate, out, as_stream(stream));
+}
+
+int byz_backdoor_clip_dev(byz_ctx* ctx, const float* grads_mean, const float* grads_stdev, const float* original_params,
+                          const float* mal_net_params, int64_t n, float learning_rate, float num_std, float* out,
+                          void* stream) {
+    BYZ_TRY(enter(ctx));
+    BYZ_REQUIRE(grads_mean && grads_stdev && original_params && mal_net_params && out && n > 0,
+                "backdoor_clip: bad arguments");
+    return launch_backdoor_clip(ctx, grads_mean, grads_stdev, original_params, mal_net_params, n, learning_rate,
+                                num_std, out, as_stream(stream));
+}
+
+int byz_assemble_row_dev(byz_ctx* ctx, float* G, int64_t n_rows, int64_t n_cols, int64_t ld, int64_t row,
+                         int64_t n_segments, const float* const* segments_dev, const int64_t* lengths, void* stream) {
+    BYZ_TRY(enter(ctx));
+    BYZ_TRY(check_matrix(G, n_rows, n_cols, ld, "assemble_row"));
+    BYZ_REQUIRE(row >= 0 && row < n_rows, "assemble_row: row %lld outside 0..%lld", (long long)row, (long long)n_rows - 1);
+    BYZ_REQUIRE(n_segments > 0 && segments_dev && lengths, "assemble_row: no segments");
+    return launch_assemble_row(ctx, G + row * ld, n_cols, n_segments, segments_dev, lengths, as_stream(stream));
+}
+
+int byz_assemble_row_host(byz_ctx* ctx, float* G, int64_t n_rows, int64_t n_cols, int64_t ld, int64_t row,
+                          const float* grads_host, void* stream) {
+    BYZ_TRY(enter(ctx));
+    BYZ_TRY(check_matrix(G, n_rows, n_cols, ld, "assemble_row"));
+    BYZ_REQUIRE(row >= 0 && row < n_rows && grads_host, "assemble_row: row %lld outside 0..%lld", (long long)row,
+                (long long)n_rows - 1);
+    BYZ_HIP(hipMemcpyAsync(G + row * ld, grads_host, static_cast<size_t>(n_cols) * sizeof(float), hipMemcpyHostToDevice,
+                           as_stream(stream)));
+    return BYZ_OK;
+}
+
 // ---- host-pointer convenience --------------------------------------------------------------------
 int byz_defend_host(byz_ctx* ctx, int name, const float* G_host, int64_t n_rows, int64_t n_cols,
                     int64_t users_count, int64_t corrupted_count, int check_assert, float* out_host,

@@ -173,6 +173,15 @@ int launch_server_update(byz_ctx* ctx, float* w, float* v, const float* agg, int
 int launch_copy_row(byz_ctx* ctx, const float* G, int64_t ld, int64_t n_rows, int64_t n_cols,
                     const int32_t* index_dev, float* out, hipStream_t stream);
 
+// round_edges.hip: the steps either side of the path
+constexpr int kMaxSegments = 32;   // tensors one assemble launch can place (more take further launches)
+int launch_backdoor_initial(byz_ctx* ctx, const float* params, const float* mean, int64_t n, float lr, float* out,
+                            hipStream_t stream);
+int launch_backdoor_clip(byz_ctx* ctx, const float* mean, const float* stdev, const float* params, const float* mal,
+                         int64_t n, float lr, float z, float* out, hipStream_t stream);
+int launch_assemble_row(byz_ctx* ctx, float* row, int64_t n_cols, int64_t n_segments, const float* const* segments,
+                        const int64_t* lengths, hipStream_t stream);
+
 int launch_gram(byz_ctx* ctx, const float* G, int64_t n_rows, int64_t n_cols, int64_t ld, double* gram,
                 hipStream_t stream);
 int launch_distances_from_gram(byz_ctx* ctx, const double* gram, int64_t n, float* dist,

@@ -1,0 +1,183 @@
+// The steps either side of the aggregation path, each a single HBM-bound pass.
+//
+//   backdoor hook     reference backdoor.py:52-65   BackdoorAttack._attack_grads without its training loop:
+//                                                   the start parameters of the malicious network, and the
+//                                                   clip of the resulting gradient to mean +- z * std
+//   gradient assembly reference user.py:92,         a client's per-parameter gradient tensors written straight into
+//                     server.py:81-83               its row of the device-resident N x D matrix
+//
+// Arithmetic of the backdoor hook is numpy's, operation by operation in fp32 (no contraction into FMAs, IEEE
+// division), so the results are bit-identical to the reference's on the same inputs:
+//     t        = lr * mean
+//     initial  = params - t                               backdoor.py:54
+//     new      = mal_net + t                              backdoor.py:59
+//     grads    = (initial - new) / lr                     backdoor.py:60
+//     out      = clip(grads, mean - z * std, mean + z * std)   backdoor.py:62-63
+// np.clip is minimum(maximum(x, lo), hi) with NaN propagating from either operand.
+//
+// Bytes per element: initial 12 (2 reads, 1 write); clip 20 (4 reads, 1 write); assembly 8 (1 read, 1 write).
+#include "common.hpp"
+
+// hipcc contracts a * b - c into an FMA by default (-ffp-contract=fast, and the __fmul_rn / __fsub_rn wrappers do not
+// stop it: they are inline functions carrying the same flag); numpy rounds the product first.  This file is built
+// with -ffp-contract=off (build_native.py) and says so here as well.
+#pragma clang fp contract(off)
+
+namespace byz {
+namespace {
+
+constexpr int kThreads = 256;
+constexpr int kVec = 4;   // elements per thread and pass in the vector kernels
+
+__device__ __forceinline__ float np_maximum(float a, float b) { return (a != a || a > b) ? a : b; }   // numpy: NaN wins
+__device__ __forceinline__ float np_minimum(float a, float b) { return (a != a || a < b) ? a : b; }
+
+__device__ __forceinline__ float clip_one(float mean, float stdev, float params, float mal, float lr, float z) {
+    const float t = lr * mean;
+    const float initial = params - t;
+    const float renewed = mal + t;
+    const float grads = (initial - renewed) / lr;   // IEEE division (hipcc's default for fp32 '/')
+    const float band = z * stdev;
+    return np_minimum(np_maximum(grads, mean - band), mean + band);
+}
+
+template <bool VEC>
+__global__ __launch_bounds__(kThreads) void backdoor_initial_kernel(const float* __restrict__ params,
+                                                                    const float* __restrict__ mean, int64_t n,
+                                                                    float lr, float* __restrict__ out) {
+    const int64_t i = (static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x) * (VEC ? kVec : 1);
+    if constexpr (VEC) {
+        if (i + kVec <= n) {
+            const float4 p = *reinterpret_cast<const float4*>(params + i);
+            const float4 m = *reinterpret_cast<const float4*>(mean + i);
+            float4 o;
+            o.x = p.x - lr * m.x;
+            o.y = p.y - lr * m.y;
+            o.z = p.z - lr * m.z;
+            o.w = p.w - lr * m.w;
+            *reinterpret_cast<float4*>(out + i) = o;
+            return;
+        }
+        for (int64_t k = i; k < n; ++k) out[k] = params[k] - lr * mean[k];
+    } else {
+        if (i < n) out[i] = params[i] - lr * mean[i];
+    }
+}
+
+template <bool VEC>
+__global__ __launch_bounds__(kThreads) void backdoor_clip_kernel(const float* __restrict__ mean,
+                                                                 const float* __restrict__ stdev,
+                                                                 const float* __restrict__ params,
+                                                                 const float* __restrict__ mal, int64_t n, float lr,
+                                                                 float z, float* __restrict__ out) {
+    const int64_t i = (static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x) * (VEC ? kVec : 1);
+    if constexpr (VEC) {
+        if (i + kVec <= n) {
+            const float4 m = *reinterpret_cast<const float4*>(mean + i);
+            const float4 s = *reinterpret_cast<const float4*>(stdev + i);
+            const float4 p = *reinterpret_cast<const float4*>(params + i);
+            const float4 q = *reinterpret_cast<const float4*>(mal + i);
+            float4 o;
+            o.x = clip_one(m.x, s.x, p.x, q.x, lr, z);
+            o.y = clip_one(m.y, s.y, p.y, q.y, lr, z);
+            o.z = clip_one(m.z, s.z, p.z, q.z, lr, z);
+            o.w = clip_one(m.w, s.w, p.w, q.w, lr, z);
+            *reinterpret_cast<float4*>(out + i) = o;
+            return;
+        }
+        for (int64_t k = i; k < n; ++k) out[k] = clip_one(mean[k], stdev[k], params[k], mal[k], lr, z);
+    } else {
+        if (i < n) out[i] = clip_one(mean[i], stdev[i], params[i], mal[i], lr, z);
+    }
+}
+
+// One launch copies up to kMaxSegments tensors into consecutive ranges of one row.  The table travels in the kernel
+// arguments (no host-to-device copy, nothing to keep alive); blockIdx.y is the segment.
+struct SegmentTable {
+    const float* src[kMaxSegments];
+    int64_t start[kMaxSegments + 1];   // first column of every segment, and the end of the last one
+};
+
+__global__ __launch_bounds__(kThreads) void assemble_row_kernel(SegmentTable table, float* __restrict__ row) {
+    const int seg = blockIdx.y;
+    const float* __restrict__ src = table.src[seg];
+    const int64_t begin = table.start[seg], len = table.start[seg + 1] - begin;
+    float* __restrict__ dst = row + begin;
+    const int64_t stride = static_cast<int64_t>(gridDim.x) * kThreads;
+    const int64_t first = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x;
+    // 16-byte moves when source and destination agree on alignment; the ragged head and tail go one by one
+    const uintptr_t sa = reinterpret_cast<uintptr_t>(src), da = reinterpret_cast<uintptr_t>(dst);
+    if (((sa ^ da) & 15u) == 0 && len >= 8) {
+        const int64_t head = ((16 - (sa & 15u)) & 15u) / 4;
+        const int64_t quads = (len - head) / 4;
+        const int64_t tail = head + quads * 4;
+        for (int64_t q = first; q < quads; q += stride)
+            *reinterpret_cast<float4*>(dst + head + 4 * q) = *reinterpret_cast<const float4*>(src + head + 4 * q);
+        if (first < head) dst[first] = src[first];
+        if (tail + first < len) dst[tail + first] = src[tail + first];   // fewer than 4 elements
+    } else {
+        for (int64_t k = first; k < len; k += stride) dst[k] = src[k];
+    }
+}
+
+bool aligned16(const void* p) { return reinterpret_cast<uintptr_t>(p) % 16 == 0; }
+
+}  // namespace
+
+int launch_backdoor_initial(byz_ctx* ctx, const float* params, const float* mean, int64_t n, float lr, float* out,
+                            hipStream_t stream) {
+    KernelTimer t(ctx, BYZ_K_MISC, stream);
+    if (aligned16(params) && aligned16(mean) && aligned16(out)) {
+        backdoor_initial_kernel<true><<<static_cast<unsigned>(ceil_div(n, static_cast<int64_t>(kThreads) * kVec)), kThreads, 0, stream>>>(params, mean, n, lr, out);
+    } else {
+        backdoor_initial_kernel<false><<<static_cast<unsigned>(ceil_div(n, kThreads)), kThreads, 0, stream>>>(params, mean, n, lr, out);
+    }
+    return check_launch("backdoor_initial_kernel");
+}
+
+int launch_backdoor_clip(byz_ctx* ctx, const float* mean, const float* stdev, const float* params, const float* mal,
+                         int64_t n, float lr, float z, float* out, hipStream_t stream) {
+    KernelTimer t(ctx, BYZ_K_MISC, stream);
+    if (aligned16(mean) && aligned16(stdev) && aligned16(params) && aligned16(mal) && aligned16(out)) {
+        backdoor_clip_kernel<true><<<static_cast<unsigned>(ceil_div(n, static_cast<int64_t>(kThreads) * kVec)), kThreads, 0, stream>>>(mean, stdev, params, mal, n, lr, z, out);
+    } else {
+        backdoor_clip_kernel<false><<<static_cast<unsigned>(ceil_div(n, kThreads)), kThreads, 0, stream>>>(mean, stdev, params, mal, n, lr, z, out);
+    }
+    return check_launch("backdoor_clip_kernel");
+}
+
+int launch_assemble_row(byz_ctx* ctx, float* row, int64_t n_cols, int64_t n_segments, const float* const* segments,
+                        const int64_t* lengths, hipStream_t stream) {
+    int64_t total = 0;
+    for (int64_t s = 0; s < n_segments; ++s) {
+        BYZ_REQUIRE(segments[s] && lengths[s] >= 0, "assemble_row: bad segment %lld", (long long)s);
+        total += lengths[s];
+    }
+    BYZ_REQUIRE(total == n_cols, "assemble_row: segments hold %lld values, the row %lld", (long long)total,
+                (long long)n_cols);
+    KernelTimer t(ctx, BYZ_K_MISC, stream);
+    int64_t column = 0;
+    for (int64_t s0 = 0; s0 < n_segments; s0 += kMaxSegments) {
+        SegmentTable table;
+        const int count = static_cast<int>(n_segments - s0 < kMaxSegments ? n_segments - s0 : kMaxSegments);
+        int64_t longest = 1;
+        for (int k = 0; k < kMaxSegments; ++k) {
+            table.src[k] = k < count ? segments[s0 + k] : nullptr;
+            table.start[k] = column;
+            if (k < count) {
+                column += lengths[s0 + k];
+                if (lengths[s0 + k] > longest) longest = lengths[s0 + k];
+            }
+        }
+        table.start[kMaxSegments] = column;
+        // one pass of 16-byte moves covers 1024 values per workgroup; cap the grid, the kernel strides
+        int64_t blocks = ceil_div(longest, static_cast<int64_t>(kThreads) * 4);
+        const int64_t cap = static_cast<int64_t>(ctx->num_cus) * 8;
+        if (blocks > cap) blocks = cap;
+        assemble_row_kernel<<<dim3(static_cast<unsigned>(blocks), static_cast<unsigned>(count)), kThreads, 0, stream>>>(table, row);
+        BYZ_TRY(check_launch("assemble_row_kernel"));
+    }
+    return BYZ_OK;
+}
+
+}  // namespace byz

@@ -388,6 +388,105 @@ class Engine:
         _check(self.lib.byz_server_update_dev(self.ctx, _vp(ptr_of(weights)), _vp(ptr_of(velocity)), _vp(ptr_of(agg)),
                                               int(n), float(momentum), float(learning_rate), _vp(stream)))
 
+    # ---- backdoor.py:52-65 (the hook's arithmetic; the training loop stays with the caller) ----
+    def _vectors(self, *vectors):
+        """Same-length fp32 vectors -> (device pointers, n, stream, keepalives, torch example or None).
+        Host vectors (numpy) are uploaded; torch CUDA tensors and DeviceBuffers are used in place."""
+        ptrs, keep, stream, example = [], [], None, None
+        n = None
+        for v in vectors:
+            if isinstance(v, DeviceBuffer):
+                assert v.dtype == np.float32
+                size, ptr = int(np.prod(v.shape)), v.ptr
+            elif _is_torch(v) and v.is_cuda:
+                import torch
+                if v.dtype != torch.float32 or not v.is_contiguous():
+                    raise ValueError('device vectors must be contiguous float32')
+                size, ptr, example = v.numel(), v.data_ptr(), v
+                stream = torch.cuda.current_stream(v.device).cuda_stream
+            else:
+                host = v.detach().cpu().numpy() if _is_torch(v) else np.asarray(v)
+                buf = self.to_device(np.ascontiguousarray(host, dtype=np.float32).ravel())
+                keep.append(buf)
+                size, ptr = int(np.prod(buf.shape)), buf.ptr
+            if n is None:
+                n = size
+            elif size != n:
+                raise ValueError('vector lengths differ: %d and %d' % (n, size))
+            ptrs.append(ptr)
+            keep.append(v)
+        return ptrs, n, stream, keep, example
+
+    def _vector_out(self, n, example):
+        if example is not None:
+            import torch
+            t = torch.empty(int(n), dtype=torch.float32, device=example.device)
+            return t, t.data_ptr()
+        b = DeviceBuffer(self, (int(n),), np.float32)
+        return b, b.ptr
+
+    def backdoor_initial_params(self, original_params, grads_mean, learning_rate):
+        """original_params - learning_rate * grads_mean (backdoor.py:54).  numpy in -> numpy out;
+        device-resident in -> device-resident out."""
+        (p, m), n, stream, keep, example = self._vectors(original_params, grads_mean)
+        out, optr = self._vector_out(n, example)
+        _check(self.lib.byz_backdoor_initial_params_dev(self.ctx, _vp(p), _vp(m), n, float(np.float32(learning_rate)),
+                                                        _vp(optr), _vp(stream)))
+        host = example is None and not any(isinstance(v, DeviceBuffer) for v in (original_params, grads_mean))
+        return out.numpy() if host else out
+
+    def backdoor_clip(self, grads_mean, grads_stdev, original_params, mal_net_params, learning_rate, num_std):
+        """The gradient that leads to `mal_net_params`, clipped to mean +- num_std * std (backdoor.py:57-63)."""
+        args = (grads_mean, grads_stdev, original_params, mal_net_params)
+        (m, s, p, q), n, stream, keep, example = self._vectors(*args)
+        out, optr = self._vector_out(n, example)
+        _check(self.lib.byz_backdoor_clip_dev(self.ctx, _vp(m), _vp(s), _vp(p), _vp(q), n,
+                                              float(np.float32(learning_rate)), float(np.float32(num_std)),
+                                              _vp(optr), _vp(stream)))
+        host = example is None and not any(isinstance(v, DeviceBuffer) for v in args)
+        return out.numpy() if host else out
+
+    # ---- user.py:92 + server.py:81-83 --------------------------------------------------------------
+    def assemble_row(self, g, row, grads):
+        """Row `row` of the device-resident matrix `g` := the client's gradient.
+
+        `grads` is either the client's flat vector (numpy, what `usr.grads` is in the reference: one
+        host-to-device copy) or a sequence of device tensors, one per model parameter in parameter order
+        (torch CUDA tensors or DeviceBuffers): those are concatenated straight into the row by one kernel,
+        and the gradient never visits the host."""
+        m = self._device_matrix(g)
+        if m is None:
+            raise ValueError('assemble_row() fills a device-resident matrix')
+        if isinstance(grads, (list, tuple)):
+            ptrs, lens, keep = [], [], []
+            for t in grads:
+                if isinstance(t, DeviceBuffer):
+                    assert t.dtype == np.float32
+                    ptrs.append(t.ptr)
+                    lens.append(int(np.prod(t.shape)))
+                elif _is_torch(t) and t.is_cuda:
+                    import torch
+                    if t.dtype != torch.float32:
+                        raise ValueError('gradient tensors must be float32')
+                    t = t if t.is_contiguous() else t.contiguous()
+                    ptrs.append(t.data_ptr())
+                    lens.append(t.numel())
+                else:
+                    raise ValueError('a list of gradients must hold device tensors; pass host data as one flat vector')
+                keep.append(t)
+            table = (ctypes.c_void_p * len(ptrs))(*ptrs)
+            lengths = (ctypes.c_int64 * len(lens))(*lens)
+            _check(self.lib.byz_assemble_row_dev(self.ctx, _vp(m.ptr), m.rows, m.cols, m.ld, int(row), len(ptrs),
+                                                 table, lengths, _vp(m.stream)))
+            return
+        host = grads.detach().cpu().numpy() if _is_torch(grads) else np.asarray(grads)
+        host = np.ascontiguousarray(host, dtype=np.float32).ravel()
+        if host.size != m.cols:
+            raise ValueError('the row holds %d values, the gradient %d' % (m.cols, host.size))
+        _check(self.lib.byz_assemble_row_host(self.ctx, _vp(m.ptr), m.rows, m.cols, m.ld, int(row),
+                                              host.ctypes.data_as(ctypes.c_void_p), _vp(m.stream)))
+        self.synchronize(m.stream)   # `host` may be a temporary
+
     # ---- timing ------------------------------------------------------------------------------
     def timing(self, on=True):
         _check(self.lib.byz_timing_enable(self.ctx, int(bool(on))))

@@ -209,6 +209,57 @@ class AttackOnly(Workload):
                 'clients': self.m, 'params': self.d}
 
 
+class BackdoorHook(Workload):
+    """the two vector steps of BackdoorAttack._attack_grads (backdoor.py:54, 57-63)."""
+    name, defence = 'backdoor', 'BackdoorAttack'
+
+    def __init__(self, torch, eng, d, device, seed):
+        self.eng, self.d = eng, d
+        gen = torch.Generator(device=device).manual_seed(seed)
+        self.mean, self.params, self.mal = (torch.randn(d, device=device, generator=gen) for _ in range(3))
+        self.std = torch.rand(d, device=device, generator=gen)
+
+    def step(self):
+        start = self.eng.backdoor_initial_params(self.params, self.mean, 0.1)
+        self.last = self.eng.backdoor_clip(self.mean, self.std, self.params, self.mal, 0.1, 1.5), start
+
+    def dominant(self):   # two launches per step: 12 + 20 bytes per element, 16 on average
+        return {'kernel': 'misc', 'bound': 'hbm', 'work': 16.0 * self.d, 'peak': PEAK_HBM, 'unit': 'GB/s', 'scale': 1e9}
+
+    def at_profiled_size(self):
+        return False
+
+    def config(self):
+        return {'workload': 'backdoor hook: start parameters + clipped gradient, D=%d' % self.d, 'params': self.d}
+
+
+class Assembly(Workload):
+    """N clients' per-parameter device gradients -> rows of the device-resident matrix."""
+    name, defence = 'assembly', 'collect_gradients'
+
+    def __init__(self, torch, eng, n, shapes, device, seed):
+        from attacking_federate_learning_amd.assembly import GradientMatrix
+        self.eng, self.n = eng, n
+        self.d = sum(int(np.prod(sh)) for sh in shapes)
+        gen = torch.Generator(device=device).manual_seed(seed)
+        self.grads = [torch.randn(sh, device=device, generator=gen) for sh in shapes]   # one client's .grad tensors
+        self.matrix = GradientMatrix(n, self.d, engine=eng, torch_device=device)
+
+    def step(self):
+        for idx in range(self.n):
+            self.matrix.set_row(idx, self.grads)
+
+    def dominant(self):   # one launch per client: its row read once, written once
+        return {'kernel': 'misc', 'bound': 'hbm', 'work': 8.0 * self.d, 'peak': PEAK_HBM, 'unit': 'GB/s', 'scale': 1e9}
+
+    def at_profiled_size(self):
+        return False
+
+    def config(self):
+        return {'workload': 'gradient assembly: %d clients x %d tensors -> device matrix, D=%d' % (self.n, len(self.grads), self.d),
+                'clients': self.n, 'params': self.d}
+
+
 # ---- timing ---------------------------------------------------------------------------------------
 def timed_steps(torch, dist, wl, eng, steps, warmup, world):
     for _ in range(warmup):
@@ -421,7 +472,10 @@ def main():
             for make in (lambda: TrimmedMeanC3(torch, eng, 1000, 1_000_000, device, 1236),
                          lambda: KrumC2(torch, eng, 100, 79510, device, 1235),
                          lambda: KrumC2(torch, eng, 100, 21840, device, 1234),
-                         lambda: AttackOnly(torch, eng, 2400, 1_000_000, device, 1238)):
+                         lambda: AttackOnly(torch, eng, 2400, 1_000_000, device, 1238),
+                         # the steps either side of the path; MnistNet's parameter shapes
+                         lambda: BackdoorHook(torch, eng, 10_000_000, device, 1239),
+                         lambda: Assembly(torch, eng, 100, [(100, 784), (100,), (10, 100), (10,)], device, 1240)):
                 w2 = make()
                 k2 = 20
                 e2, pk2 = timed_steps(torch, dist, w2, eng, k2, 3, 1)

@@ -133,6 +133,31 @@ int byz_server_update_dev(byz_ctx* ctx, float* weights_dev, float* velocity_dev,
                           const float* agg_dev, int64_t n, float momentum, float learning_rate,
                           void* stream);
 
+/* ---- next: BackdoorAttack._attack_grads without its training loop (backdoor.py:52-65) -- */
+/* out = original_params - lr * grads_mean: the parameters the malicious network starts     */
+/* from (backdoor.py:54).  fp32, numpy's operation order.                                   */
+int byz_backdoor_initial_params_dev(byz_ctx* ctx, const float* original_params_dev,
+                                    const float* grads_mean_dev, int64_t n, float learning_rate,
+                                    float* out_dev, void* stream);
+/* new_grads = ((params - lr*mean) - (mal_net_params + lr*mean)) / lr, clipped to            */
+/* mean +- num_std * std (backdoor.py:57-63); np.clip's NaN behaviour.  Bit-identical to    */
+/* numpy fp32 on the same inputs.                                                           */
+int byz_backdoor_clip_dev(byz_ctx* ctx, const float* grads_mean_dev, const float* grads_stdev_dev,
+                          const float* original_params_dev, const float* mal_net_params_dev,
+                          int64_t n, float learning_rate, float num_std, float* out_dev,
+                          void* stream);
+
+/* ---- next: gradient assembly (user.py:92 np.concatenate + server.py:81-83 row copy) ----- */
+/* Row `row` of the device-resident G = the concatenation of n_segments device tensors      */
+/* (segments_dev: HOST array of device pointers, lengths: HOST array of element counts,     */
+/* summing to n_cols), one launch per 32 tensors.  The _host form takes the client's        */
+/* already-concatenated numpy vector (what usr.grads is in the reference).                  */
+int byz_assemble_row_dev(byz_ctx* ctx, float* G_dev, int64_t n_rows, int64_t n_cols, int64_t ld,
+                         int64_t row, int64_t n_segments, const float* const* segments_dev,
+                         const int64_t* lengths, void* stream);
+int byz_assemble_row_host(byz_ctx* ctx, float* G_dev, int64_t n_rows, int64_t n_cols, int64_t ld,
+                          int64_t row, const float* grads_host, void* stream);
+
 /* ---- host-pointer convenience (what the numpy drop-in uses) ---------------------------- */
 /* G_host is the reference's C-contiguous np.float32 users_grads.  name: 0 NoDefense, 1 Krum, */
 /* 2 TrimmedMean, 3 Bulyan (the keys of defences.defend, defences.py:73-75).  out_host: n_cols */

@@ -171,3 +171,28 @@ def drift_vector(rows, num_std):
         return None
     mean[:] -= num_std * stdev[:]
     return mean
+
+
+# ---- the steps either side of the path ------------------------------------
+
+def backdoor_initial_params(original_params, learning_rate, grads_mean):
+    """backdoor.py:54 -- where the malicious network starts: the parameters after the honest mean step.
+    `learning_rate` is a Python float, so numpy keeps the arithmetic in fp32 (weak scalar)."""
+    return original_params - learning_rate * grads_mean
+
+
+def backdoor_attack_grads(grads_mean, grads_stdev, original_params, learning_rate, num_std, mal_net_params):
+    """backdoor.py:52-65 with the training loop's result (`mal_net_params`, backdoor.py:56) handed in:
+    the gradient that moves the parameters to the malicious network's, clipped to mean +- num_std * std."""
+    start = backdoor_initial_params(original_params, learning_rate, grads_mean)
+    wanted_params = mal_net_params + learning_rate * grads_mean          # backdoor.py:59
+    wanted_grads = (start - wanted_params) / learning_rate               # backdoor.py:60
+    band = num_std * grads_stdev
+    return np.clip(wanted_grads, grads_mean - band, grads_mean + band)   # backdoor.py:62-63
+
+
+def assemble_row(users_grads, idx, tensors):
+    """user.py:92 then server.py:83 -- a client's per-parameter gradients, flattened and concatenated in
+    parameter order, become row `idx` of the server's matrix."""
+    users_grads[idx, :] = np.concatenate([np.asarray(t).flatten() for t in tensors])
+    return users_grads

@@ -3,7 +3,9 @@
 
     PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py
 
-Reads  /root/reference/{defences,malicious}.py (imported, never copied).
+Reads  /root/reference/{defences,malicious,backdoor,server}.py (imported, never copied; the modules those
+two import that are absent from this image -- tensorflow, torchvision via data_sets, user -- are stubbed,
+none of their code is on the lines exercised here).
 Writes tests/golden/reference_vectors.npz: for each case the seeded input matrix
 and whatever the reference returned.  The reference ships no fixtures of its own
 (SURVEY.md section 4), so "the reference's output in this image" (numpy 2.2.6,
@@ -21,6 +23,21 @@ import defences as ref_defences  # noqa: E402
 import malicious as ref_malicious  # noqa: E402
 
 HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def import_reference_neighbours():
+    """backdoor.py and server.py import packages this image lacks; stub exactly those and import the rest."""
+    import types
+    for name, attrs in (('data_sets', {'MNIST': 'MNIST', 'CIFAR10': 'CIFAR10'}),
+                        ('user', {'flatten_params': None, 'row_into_parameters': None, 'cycle': None}),
+                        ('tensorflow', {})):
+        if name not in sys.modules:
+            mod = types.ModuleType(name)
+            mod.__dict__.update(attrs)
+            sys.modules[name] = mod
+    import backdoor as ref_backdoor
+    import server as ref_server
+    return ref_backdoor, ref_server
 
 
 def gaussian(seed, n, d):
@@ -140,6 +157,39 @@ def main():
         att.attack(users)
         put(name, G=g, z=z, stored_mean=att.grads_mean, stored_stdev=att.grads_stdev,
             user0=users[0].grads, aliased=int(all(u.grads is users[0].grads for u in users)))
+
+    # --- neighbours of the path: backdoor hook, gradient assembly --------------------
+    ref_backdoor, ref_server = import_reference_neighbours()
+    for name, d, z, lr, spread in [('backdoor_300_z1.5', 300, 1.5, 0.1, 0.3),
+                                   ('backdoor_1000_z0.5_faded_lr', 1000, 0.5, 0.1 * 10 / (3 + 10), 2.0),
+                                   ('backdoor_64_z0', 64, 0.0, 0.05, 1.0)]:
+        rng = np.random.default_rng(60 + d)
+        mean = rng.standard_normal(d).astype(np.float32)
+        stdev = np.abs(rng.standard_normal(d)).astype(np.float32)
+        params = rng.standard_normal(d).astype(np.float32)
+        mal = (params + spread * rng.standard_normal(d)).astype(np.float32)
+        att = object.__new__(ref_backdoor.BackdoorAttack)   # __init__ builds data loaders; the hook needs none
+        att.num_std = z
+        seen = {}
+
+        def train(start, _mal=mal, _seen=seen):   # stands in for backdoor.py:56's training loop
+            _seen['start'] = start.copy()
+            return _mal
+        att.train_malicious_network = train
+        out_vec = att._attack_grads(mean.copy(), stdev.copy(), params.copy(), lr)
+        put(name, mean=mean, stdev=stdev, params=params, mal=mal, z=z, lr=lr, start=seen['start'], out=out_vec)
+
+    class FakeServer:
+        pass
+    srv = FakeServer()
+    rng = np.random.default_rng(71)
+    shapes = [(20, 7), (20,), (3, 5, 2), (1,), (13,)]
+    per_user = [[rng.standard_normal(sh).astype(np.float32) for sh in shapes] for _ in range(4)]
+    srv.users = [FakeUser(np.concatenate([t.flatten() for t in tensors])) for tensors in per_user]   # user.py:92
+    srv.users_grads = np.empty((4, srv.users[0].grads.size), dtype=np.float32)                       # server.py:35
+    ref_server.Server.collect_gradients(srv)
+    put('assemble_4x%d' % srv.users_grads.shape[1], G=srv.users_grads,
+        **{'u%d_t%d' % (u, t): per_user[u][t] for u in range(4) for t in range(len(shapes))})
 
     path = os.path.join(HERE, 'reference_vectors.npz')
     np.savez_compressed(path, **out)

@@ -76,3 +76,27 @@ def test_attack(golden, case):
         v64, _, s64 = ideal.drift_vector(g, z)
         assert np.allclose(v64, vec, rtol=1e-5, atol=1e-5)
         assert np.allclose(s64, stdev, rtol=1e-5, atol=1e-6)
+
+
+# ---- the steps either side of the path ---------------------------------------------
+BACKDOOR_CASES = ['backdoor_300_z1.5', 'backdoor_1000_z0.5_faded_lr', 'backdoor_64_z0']
+
+
+@pytest.mark.parametrize('case', BACKDOOR_CASES)
+def test_backdoor_hook(golden, case):
+    c = golden[case]
+    lr, z = float(c['lr']), float(c['z'])
+    assert same(faithful.backdoor_initial_params(c['params'], lr, c['mean']), c['start'])
+    out = faithful.backdoor_attack_grads(c['mean'], c['stdev'], c['params'], lr, z, c['mal'])
+    assert out.dtype == np.float32 and same(out, c['out'])
+    # the clip really binds in these cases (otherwise they would not pin it)
+    band = np.float32(z) * c['stdev']
+    assert np.any(out == c['mean'] - band) and np.any(out == c['mean'] + band)
+
+
+def test_gradient_assembly(golden):
+    c = golden['assemble_4x204']
+    g = np.empty_like(c['G'])
+    for u in range(4):
+        faithful.assemble_row(g, u, [c['u%d_t%d' % (u, t)] for t in range(5)])
+    assert same(g, c['G'])

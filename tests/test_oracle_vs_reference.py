@@ -99,3 +99,48 @@ def test_attack(reference_modules, m, d, z):
     else:
         assert np.array_equal(vec, users[0].grads)
     assert np.array_equal(faithful.attack_statistics(g)[1], att.grads_stdev)
+
+
+@pytest.fixture(scope='module')
+def reference_backdoor(reference_modules):
+    """backdoor.py imports `malicious` (the reference's, handed in here), plus `data_sets` and `user`, which
+    need torchvision: those two are stubbed for the duration of the import and none of their code runs."""
+    import importlib.util
+    import os
+    import sys
+    import types
+    path = os.path.join('/root/reference', 'backdoor.py')
+    saved = {name: sys.modules.get(name) for name in ('malicious', 'data_sets', 'user')}
+    try:
+        sys.modules['malicious'] = reference_modules['malicious']
+        for name, attrs in (('data_sets', {'MNIST': 'MNIST', 'CIFAR10': 'CIFAR10'}),
+                            ('user', {'flatten_params': None, 'row_into_parameters': None, 'cycle': None})):
+            mod = types.ModuleType(name)
+            mod.__dict__.update(attrs)
+            sys.modules[name] = mod
+        spec = importlib.util.spec_from_file_location('reference_backdoor', path)
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+    finally:
+        for name, old in saved.items():
+            if old is None:
+                sys.modules.pop(name, None)
+            else:
+                sys.modules[name] = old
+    return mod
+
+
+@pytest.mark.parametrize('d,z,lr', [(1, 1.5, 0.1), (257, 1.5, 0.1), (1000, 0.3, 0.1 * 10 / 13), (4096, 3.0, 0.01)])
+def test_backdoor_hook(reference_backdoor, d, z, lr):
+    rng = np.random.default_rng(900 + d)
+    mean = rng.standard_normal(d).astype(np.float32)
+    stdev = np.abs(rng.standard_normal(d)).astype(np.float32)
+    params = rng.standard_normal(d).astype(np.float32)
+    mal = (params + rng.standard_normal(d)).astype(np.float32)
+    att = object.__new__(reference_backdoor.BackdoorAttack)   # the constructor builds data loaders
+    att.num_std = z
+    starts = []
+    att.train_malicious_network = lambda start: (starts.append(start.copy()), mal)[1]
+    want = att._attack_grads(mean.copy(), stdev.copy(), params.copy(), lr)
+    assert np.array_equal(starts[0], faithful.backdoor_initial_params(params, lr, mean))
+    assert np.array_equal(want, faithful.backdoor_attack_grads(mean, stdev, params, lr, z, mal), equal_nan=True)
