@@ -34,5 +34,9 @@ class GradientMatrix:
         for idx, usr in enumerate(users):
             self.set_row(idx, usr.grads)
 
+    def set_all(self, batched_grads):
+        """All rows from a batched client step: one device tensor (n_users, *shape) per model parameter."""
+        self.engine.assemble_columns(self.data, batched_grads)
+
     def numpy(self):
         return self.data.cpu().numpy() if hasattr(self.data, 'cpu') else self.data.numpy()

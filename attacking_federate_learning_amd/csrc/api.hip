@@ -382,6 +382,14 @@ int byz_assemble_row_dev(byz_ctx* ctx, float* G, int64_t n_rows, int64_t n_cols,
     return launch_assemble_row(ctx, G + row * ld, n_cols, n_segments, segments_dev, lengths, as_stream(stream));
 }
 
+int byz_assemble_columns_dev(byz_ctx* ctx, float* G, int64_t n_rows, int64_t n_cols, int64_t ld, int64_t n_segments,
+                             const float* const* segments_dev, const int64_t* lengths, void* stream) {
+    BYZ_TRY(enter(ctx));
+    BYZ_TRY(check_matrix(G, n_rows, n_cols, ld, "assemble_columns"));
+    BYZ_REQUIRE(n_segments > 0 && segments_dev && lengths, "assemble_columns: no segments");
+    return launch_assemble_columns(ctx, G, n_rows, n_cols, ld, n_segments, segments_dev, lengths, as_stream(stream));
+}
+
 int byz_assemble_row_host(byz_ctx* ctx, float* G, int64_t n_rows, int64_t n_cols, int64_t ld, int64_t row,
                           const float* grads_host, void* stream) {
     BYZ_TRY(enter(ctx));

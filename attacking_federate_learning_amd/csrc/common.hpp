@@ -181,6 +181,8 @@ int launch_backdoor_clip(byz_ctx* ctx, const float* mean, const float* stdev, co
                          int64_t n, float lr, float z, float* out, hipStream_t stream);
 int launch_assemble_row(byz_ctx* ctx, float* row, int64_t n_cols, int64_t n_segments, const float* const* segments,
                         const int64_t* lengths, hipStream_t stream);
+int launch_assemble_columns(byz_ctx* ctx, float* G, int64_t n_rows, int64_t n_cols, int64_t ld, int64_t n_segments,
+                            const float* const* segments, const int64_t* lengths, hipStream_t stream);
 
 int launch_gram(byz_ctx* ctx, const float* G, int64_t n_rows, int64_t n_cols, int64_t ld, double* gram,
                 hipStream_t stream);

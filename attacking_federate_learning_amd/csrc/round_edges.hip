@@ -98,14 +98,10 @@ struct SegmentTable {
     int64_t start[kMaxSegments + 1];   // first column of every segment, and the end of the last one
 };
 
-__global__ __launch_bounds__(kThreads) void assemble_row_kernel(SegmentTable table, float* __restrict__ row) {
-    const int seg = blockIdx.y;
-    const float* __restrict__ src = table.src[seg];
-    const int64_t begin = table.start[seg], len = table.start[seg + 1] - begin;
-    float* __restrict__ dst = row + begin;
-    const int64_t stride = static_cast<int64_t>(gridDim.x) * kThreads;
-    const int64_t first = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x;
-    // 16-byte moves when source and destination agree on alignment; the ragged head and tail go one by one
+// dst[0 .. len) = src[0 .. len), cooperatively: thread `first` of `stride`.  16-byte moves when source and destination
+// agree on alignment; the ragged head and tail go one by one.
+__device__ __forceinline__ void copy_span(const float* __restrict__ src, float* __restrict__ dst, int64_t len,
+                                          int64_t first, int64_t stride) {
     const uintptr_t sa = reinterpret_cast<uintptr_t>(src), da = reinterpret_cast<uintptr_t>(dst);
     if (((sa ^ da) & 15u) == 0 && len >= 8) {
         const int64_t head = ((16 - (sa & 15u)) & 15u) / 4;
@@ -118,6 +114,25 @@ __global__ __launch_bounds__(kThreads) void assemble_row_kernel(SegmentTable tab
     } else {
         for (int64_t k = first; k < len; k += stride) dst[k] = src[k];
     }
+}
+
+// One client: segment s is that client's gradient of parameter s.  blockIdx.y = segment.
+__global__ __launch_bounds__(kThreads) void assemble_row_kernel(SegmentTable table, float* __restrict__ row) {
+    const int seg = blockIdx.y;
+    const int64_t begin = table.start[seg], len = table.start[seg + 1] - begin;
+    copy_span(table.src[seg], row + begin, len, static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x,
+              static_cast<int64_t>(gridDim.x) * kThreads);
+}
+
+// All clients at once: segment s is the (n_rows x len_s) row-major gradient of parameter s for every client (what a
+// batched client step produces).  blockIdx.y = client row, blockIdx.z = segment.
+__global__ __launch_bounds__(kThreads) void assemble_columns_kernel(SegmentTable table, float* __restrict__ G,
+                                                                    int64_t ld) {
+    const int seg = blockIdx.z;
+    const int64_t r = blockIdx.y;
+    const int64_t begin = table.start[seg], len = table.start[seg + 1] - begin;
+    copy_span(table.src[seg] + r * len, G + r * ld + begin, len,
+              static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x, static_cast<int64_t>(gridDim.x) * kThreads);
 }
 
 bool aligned16(const void* p) { return reinterpret_cast<uintptr_t>(p) % 16 == 0; }
@@ -146,15 +161,17 @@ int launch_backdoor_clip(byz_ctx* ctx, const float* mean, const float* stdev, co
     return check_launch("backdoor_clip_kernel");
 }
 
-int launch_assemble_row(byz_ctx* ctx, float* row, int64_t n_cols, int64_t n_segments, const float* const* segments,
-                        const int64_t* lengths, hipStream_t stream) {
+// rows == 0: one client (`dst` is its row); rows > 0: every client (`dst` is G, segments are rows x len blocks)
+static int assemble(byz_ctx* ctx, float* dst, int64_t rows, int64_t ld, int64_t n_cols, int64_t n_segments,
+                    const float* const* segments, const int64_t* lengths, hipStream_t stream) {
     int64_t total = 0;
     for (int64_t s = 0; s < n_segments; ++s) {
-        BYZ_REQUIRE(segments[s] && lengths[s] >= 0, "assemble_row: bad segment %lld", (long long)s);
+        BYZ_REQUIRE(segments[s] && lengths[s] >= 0, "assemble: bad segment %lld", (long long)s);
         total += lengths[s];
     }
-    BYZ_REQUIRE(total == n_cols, "assemble_row: segments hold %lld values, the row %lld", (long long)total,
+    BYZ_REQUIRE(total == n_cols, "assemble: segments hold %lld values per client, a row %lld", (long long)total,
                 (long long)n_cols);
+    BYZ_REQUIRE(rows <= 65535, "assemble: at most 65535 clients per call, got %lld", (long long)rows);
     KernelTimer t(ctx, BYZ_K_MISC, stream);
     int64_t column = 0;
     for (int64_t s0 = 0; s0 < n_segments; s0 += kMaxSegments) {
@@ -174,10 +191,24 @@ int launch_assemble_row(byz_ctx* ctx, float* row, int64_t n_cols, int64_t n_segm
         int64_t blocks = ceil_div(longest, static_cast<int64_t>(kThreads) * 4);
         const int64_t cap = static_cast<int64_t>(ctx->num_cus) * 8;
         if (blocks > cap) blocks = cap;
-        assemble_row_kernel<<<dim3(static_cast<unsigned>(blocks), static_cast<unsigned>(count)), kThreads, 0, stream>>>(table, row);
-        BYZ_TRY(check_launch("assemble_row_kernel"));
+        if (rows > 0) {
+            assemble_columns_kernel<<<dim3(static_cast<unsigned>(blocks), static_cast<unsigned>(rows), static_cast<unsigned>(count)), kThreads, 0, stream>>>(table, dst, ld);
+        } else {
+            assemble_row_kernel<<<dim3(static_cast<unsigned>(blocks), static_cast<unsigned>(count)), kThreads, 0, stream>>>(table, dst);
+        }
+        BYZ_TRY(check_launch("assemble kernel"));
     }
     return BYZ_OK;
+}
+
+int launch_assemble_row(byz_ctx* ctx, float* row, int64_t n_cols, int64_t n_segments, const float* const* segments,
+                        const int64_t* lengths, hipStream_t stream) {
+    return assemble(ctx, row, 0, 0, n_cols, n_segments, segments, lengths, stream);
+}
+
+int launch_assemble_columns(byz_ctx* ctx, float* G, int64_t n_rows, int64_t n_cols, int64_t ld, int64_t n_segments,
+                            const float* const* segments, const int64_t* lengths, hipStream_t stream) {
+    return assemble(ctx, G, n_rows, ld, n_cols, n_segments, segments, lengths, stream);
 }
 
 }  // namespace byz

@@ -487,6 +487,33 @@ class Engine:
                                               host.ctypes.data_as(ctypes.c_void_p), _vp(m.stream)))
         self.synchronize(m.stream)   # `host` may be a temporary
 
+    def assemble_columns(self, g, batched_grads):
+        """Every client at once: `batched_grads[s]` is the device tensor (n_clients, *shape_s) holding parameter
+        s's gradient for all clients (a batched client step); `g[:, start_s:start_s + len_s]` := its rows."""
+        m = self._device_matrix(g)
+        if m is None:
+            raise ValueError('assemble_columns() fills a device-resident matrix')
+        ptrs, lens, keep = [], [], []
+        for t in batched_grads:
+            if isinstance(t, DeviceBuffer):
+                assert t.dtype == np.float32 and t.shape[0] == m.rows
+                ptrs.append(t.ptr)
+                lens.append(int(np.prod(t.shape[1:])))
+            elif _is_torch(t) and t.is_cuda:
+                import torch
+                if t.dtype != torch.float32 or t.shape[0] != m.rows:
+                    raise ValueError('batched gradients must be float32 with one leading row per client')
+                t = t if t.is_contiguous() else t.contiguous()
+                ptrs.append(t.data_ptr())
+                lens.append(t.numel() // m.rows)
+            else:
+                raise ValueError('batched gradients must be device tensors')
+            keep.append(t)
+        table = (ctypes.c_void_p * len(ptrs))(*ptrs)
+        lengths = (ctypes.c_int64 * len(lens))(*lens)
+        _check(self.lib.byz_assemble_columns_dev(self.ctx, _vp(m.ptr), m.rows, m.cols, m.ld, len(ptrs), table, lengths,
+                                                 _vp(m.stream)))
+
     # ---- timing ------------------------------------------------------------------------------
     def timing(self, on=True):
         _check(self.lib.byz_timing_enable(self.ctx, int(bool(on))))

@@ -237,26 +237,34 @@ class Assembly(Workload):
     """N clients' per-parameter device gradients -> rows of the device-resident matrix."""
     name, defence = 'assembly', 'collect_gradients'
 
-    def __init__(self, torch, eng, n, shapes, device, seed):
+    def __init__(self, torch, eng, n, shapes, device, seed, batched=False):
         from attacking_federate_learning_amd.assembly import GradientMatrix
         self.eng, self.n = eng, n
         self.d = sum(int(np.prod(sh)) for sh in shapes)
         gen = torch.Generator(device=device).manual_seed(seed)
         self.grads = [torch.randn(sh, device=device, generator=gen) for sh in shapes]   # one client's .grad tensors
         self.matrix = GradientMatrix(n, self.d, engine=eng, torch_device=device)
+        self.batched = None
+        if batched:   # what a batched client step hands over: (n, *shape) per parameter
+            self.batched = [torch.randn((n,) + tuple(sh), device=device, generator=gen) for sh in shapes]
 
     def step(self):
+        if self.batched is not None:
+            self.matrix.set_all(self.batched)
+            return
         for idx in range(self.n):
             self.matrix.set_row(idx, self.grads)
 
-    def dominant(self):   # one launch per client: its row read once, written once
-        return {'kernel': 'misc', 'bound': 'hbm', 'work': 8.0 * self.d, 'peak': PEAK_HBM, 'unit': 'GB/s', 'scale': 1e9}
+    def dominant(self):   # per launch: the rows it fills are read once and written once
+        rows = self.n if self.batched is not None else 1
+        return {'kernel': 'misc', 'bound': 'hbm', 'work': 8.0 * self.d * rows, 'peak': PEAK_HBM, 'unit': 'GB/s', 'scale': 1e9}
 
     def at_profiled_size(self):
         return False
 
     def config(self):
-        return {'workload': 'gradient assembly: %d clients x %d tensors -> device matrix, D=%d' % (self.n, len(self.grads), self.d),
+        return {'workload': 'gradient assembly (%s): %d clients x %d tensors -> device matrix, D=%d' % (
+                    'one launch, batched gradients' if self.batched is not None else 'one launch per client', self.n, len(self.grads), self.d),
                 'clients': self.n, 'params': self.d}
 
 
@@ -475,11 +483,14 @@ def main():
                          lambda: AttackOnly(torch, eng, 2400, 1_000_000, device, 1238),
                          # the steps either side of the path; MnistNet's parameter shapes
                          lambda: BackdoorHook(torch, eng, 10_000_000, device, 1239),
-                         lambda: Assembly(torch, eng, 100, [(100, 784), (100,), (10, 100), (10,)], device, 1240)):
+                         lambda: Assembly(torch, eng, 100, [(100, 784), (100,), (10, 100), (10,)], device, 1240),
+                         lambda: Assembly(torch, eng, 100, [(100, 784), (100,), (10, 100), (10,)], device, 1241, batched=True)):
                 w2 = make()
                 k2 = 20
                 e2, pk2 = timed_steps(torch, dist, w2, eng, k2, 3, 1)
                 key = '%s_D%d' % (w2.name, w2.d)
+                if key in extras:
+                    key += '_batched'
                 extras[key] = {'config': w2.config(), 'value': k2 / e2, 'unit': 'rounds/s',
                                'ms_per_step': e2 / k2 * 1e3, 'roofline': roofline_of(w2, pk2, traffic),
                                'kernels': kernel_table(pk2, k2)}

@@ -155,6 +155,12 @@ int byz_backdoor_clip_dev(byz_ctx* ctx, const float* grads_mean_dev, const float
 int byz_assemble_row_dev(byz_ctx* ctx, float* G_dev, int64_t n_rows, int64_t n_cols, int64_t ld,
                          int64_t row, int64_t n_segments, const float* const* segments_dev,
                          const int64_t* lengths, void* stream);
+/* Every client at once (what a batched client step produces): segment s is the row-major    */
+/* (n_rows x lengths[s]) gradient of parameter s for all clients; G[:, start_s:start_s+len_s] */
+/* := that block.  One launch per 32 parameters.                                             */
+int byz_assemble_columns_dev(byz_ctx* ctx, float* G_dev, int64_t n_rows, int64_t n_cols, int64_t ld,
+                             int64_t n_segments, const float* const* segments_dev,
+                             const int64_t* lengths, void* stream);
 int byz_assemble_row_host(byz_ctx* ctx, float* G_dev, int64_t n_rows, int64_t n_cols, int64_t ld,
                           int64_t row, const float* grads_host, void* stream);
 

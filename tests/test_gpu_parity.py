@@ -418,6 +418,15 @@ def test_gradient_assembly_from_torch_parameters(eng):
     assert np.array_equal(gm.numpy(), want)
     with pytest.raises(ValueError):
         gm.set_row(0, [tensors[0]])                       # too few values for the row
+    # every client at once, from batched per-parameter gradients (n_clients, *shape)
+    shapes = [(100, 784), (100,), (10, 100), (10,), (3,), (1,)]
+    batched = [torch.from_numpy(rng.standard_normal((5,) + sh).astype(np.float32)).cuda() for sh in shapes]
+    gm5 = GradientMatrix(5, sum(int(np.prod(sh)) for sh in shapes), engine=eng, torch_device='cuda')
+    gm5.set_all(batched)
+    want5 = np.empty(gm5.shape, dtype=np.float32)
+    for u in range(5):
+        faithful.assemble_row(want5, u, [b[u].cpu().numpy() for b in batched])
+    assert np.array_equal(gm5.numpy(), want5)
     # the assembled matrix feeds the defences directly
     assert close(eng.no_defense(gm.data).cpu().numpy(), np.mean(want, axis=0))
 
