@@ -268,6 +268,46 @@ class Assembly(Workload):
                 'clients': self.n, 'params': self.d}
 
 
+class ClientStep(Workload):
+    """every client's forward/backward from the same weights in one batched pass
+    (torch.func.vmap; rocBLAS batched GEMMs, not a libbyzagg kernel) + assembly into the device matrix."""
+    name, defence = 'client_step', 'dispatch_weights+collect_gradients'
+
+    def __init__(self, torch, eng, n, batch, device, seed):
+        from attacking_federate_learning_amd.assembly import GradientMatrix
+        self.eng, self.n, self.batch, self.d = eng, n, batch, 79510
+
+        class Net(torch.nn.Module):   # the shape of the reference's MnistNet (data_sets.py:13-23)
+            def __init__(self):
+                super().__init__()
+                self.fc1, self.fc2 = torch.nn.Linear(784, 100), torch.nn.Linear(100, 10)
+
+            def forward(self, x):
+                return torch.log_softmax(self.fc2(torch.relu(self.fc1(x))), dim=1)
+
+        torch.manual_seed(seed)
+        self.net = Net().to(device)
+        gen = torch.Generator(device=device).manual_seed(seed)
+        self.weights = 0.05 * torch.randn(self.d, device=device, generator=gen)
+        self.data = torch.randn((n, batch, 784), device=device, generator=gen)
+        self.target = torch.randint(0, 10, (n, batch), device=device, generator=gen)
+        self.matrix = GradientMatrix(n, self.d, engine=eng, torch_device=device)
+
+    def step(self):
+        from attacking_federate_learning_amd.clients import collect_batched
+        collect_batched(self.matrix, self.net, self.weights, self.data, self.target)
+
+    def dominant(self):   # the libbyzagg part of the step is the one assembly launch
+        return {'kernel': 'misc', 'bound': 'hbm', 'work': 8.0 * self.d * self.n, 'peak': PEAK_HBM, 'unit': 'GB/s', 'scale': 1e9}
+
+    def at_profiled_size(self):
+        return False
+
+    def config(self):
+        return {'workload': 'batched client step: %d MnistNet clients x batch %d, gradients into the device matrix' % (self.n, self.batch),
+                'clients': self.n, 'params': self.d}
+
+
 # ---- timing ---------------------------------------------------------------------------------------
 def timed_steps(torch, dist, wl, eng, steps, warmup, world):
     for _ in range(warmup):
@@ -484,7 +524,8 @@ def main():
                          # the steps either side of the path; MnistNet's parameter shapes
                          lambda: BackdoorHook(torch, eng, 10_000_000, device, 1239),
                          lambda: Assembly(torch, eng, 100, [(100, 784), (100,), (10, 100), (10,)], device, 1240),
-                         lambda: Assembly(torch, eng, 100, [(100, 784), (100,), (10, 100), (10,)], device, 1241, batched=True)):
+                         lambda: Assembly(torch, eng, 100, [(100, 784), (100,), (10, 100), (10,)], device, 1241, batched=True),
+                         lambda: ClientStep(torch, eng, 100, 83, device, 1242)):
                 w2 = make()
                 k2 = 20
                 e2, pk2 = timed_steps(torch, dist, w2, eng, k2, 3, 1)

@@ -26,18 +26,42 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 
 
 def import_reference_neighbours():
-    """backdoor.py and server.py import packages this image lacks; stub exactly those and import the rest."""
+    """backdoor.py and server.py import packages this image lacks; stub exactly those for the duration of the import."""
     import types
-    for name, attrs in (('data_sets', {'MNIST': 'MNIST', 'CIFAR10': 'CIFAR10'}),
-                        ('user', {'flatten_params': None, 'row_into_parameters': None, 'cycle': None}),
-                        ('tensorflow', {})):
-        if name not in sys.modules:
-            mod = types.ModuleType(name)
-            mod.__dict__.update(attrs)
-            sys.modules[name] = mod
-    import backdoor as ref_backdoor
-    import server as ref_server
+    stubs = {'data_sets': {'MNIST': 'MNIST', 'CIFAR10': 'CIFAR10'},
+             'user': {'flatten_params': None, 'row_into_parameters': None, 'cycle': None},
+             'tensorflow': {}}
+    for name, attrs in stubs.items():
+        mod = types.ModuleType(name)
+        mod.__dict__.update(attrs)
+        sys.modules[name] = mod
+    try:
+        import backdoor as ref_backdoor
+        import server as ref_server
+    finally:
+        for name in stubs:
+            del sys.modules[name]
     return ref_backdoor, ref_server
+
+
+def import_reference_clients():
+    """user.py and data_sets.py with torchvision (absent here) stubbed: the networks and `User.step` need none of it."""
+    import types
+    tv = types.ModuleType('torchvision')
+    tv.datasets = types.ModuleType('torchvision.datasets')
+    tv.transforms = types.ModuleType('torchvision.transforms')
+    stubs = {'torchvision': tv, 'torchvision.datasets': tv.datasets, 'torchvision.transforms': tv.transforms}
+    sys.modules.update(stubs)
+    try:
+        import data_sets as ref_data_sets
+        import user as ref_user
+    finally:
+        for name in stubs:
+            del sys.modules[name]
+    return ref_data_sets, ref_user
+
+
+CLIENT_SAMPLE_ROWS = (0, 57)   # hidden units whose fc1.weight gradient rows are stored in full
 
 
 def gaussian(seed, n, d):
@@ -190,6 +214,29 @@ def main():
     ref_server.Server.collect_gradients(srv)
     put('assemble_4x%d' % srv.users_grads.shape[1], G=srv.users_grads,
         **{'u%d_t%d' % (u, t): per_user[u][t] for u in range(4) for t in range(len(shapes))})
+
+    # --- the client step (user.py:76-92), 3 clients of MnistNet from the same weights ------------------
+    import types
+    import torch
+    ref_data_sets, ref_user = import_reference_clients()
+    rng = np.random.default_rng(81)
+    n_clients, batch = 3, 5
+    weights = (rng.integers(-128, 128, size=79510) / 1024.0).astype(np.float32)      # compressible, exact in fp32
+    data = (rng.integers(-64, 64, size=(n_clients, batch, 1, 28, 28)) / 32.0).astype(np.float32)
+    target = rng.integers(0, 10, size=(n_clients, batch)).astype(np.int64)
+    rows = []
+    for c in range(n_clients):
+        usr = types.SimpleNamespace(user_id=c, is_malicious=False, momentum=0.9, data_set=ref_data_sets.MNIST,
+                                    net=ref_data_sets.MnistNet(), criterion=torch.nn.NLLLoss(),
+                                    train_iterator=iter([(torch.from_numpy(data[c]), torch.from_numpy(target[c]))]))
+        usr.train = types.MethodType(ref_user.User.train, usr)
+        ref_user.User.step(usr, weights, 0.1)
+        rows.append(usr.grads)
+    rows = np.stack(rows)
+    w1 = rows[:, :78400].reshape(n_clients, 100, 784)
+    put('clients_mnist_3x5', weights=weights, data=data, target=target,
+        fc1_weight_rows=w1[:, CLIENT_SAMPLE_ROWS, :], tail=rows[:, 78400:],          # fc1.bias, fc2.weight, fc2.bias in full
+        row_sums=rows.astype(np.float64).sum(axis=1), row_norms=np.sqrt((rows.astype(np.float64) ** 2).sum(axis=1)))
 
     path = os.path.join(HERE, 'reference_vectors.npz')
     np.savez_compressed(path, **out)

@@ -431,6 +431,41 @@ def test_gradient_assembly_from_torch_parameters(eng):
     assert close(eng.no_defense(gm.data).cpu().numpy(), np.mean(want, axis=0))
 
 
+def test_batched_client_step_fills_the_device_matrix(eng, golden):
+    """all clients' gradients in one batched pass on the GPU, written straight into the
+    device-resident matrix, which the defences then consume -- against the golden vectors from the reference's
+    own User.step and, at the reference's batch size, against the per-client loop of the oracle."""
+    torch = pytest.importorskip('torch')
+    from oracle import clients as oracle_clients
+    from attacking_federate_learning_amd.assembly import GradientMatrix
+    from attacking_federate_learning_amd.clients import collect_batched
+    c = golden['clients_mnist_3x5']
+    net = oracle_clients.MnistNet().cuda()
+    gm = GradientMatrix(3, 79510, engine=eng, torch_device='cuda')
+    collect_batched(gm, net, c['weights'], torch.from_numpy(c['data']).view(3, 5, 784).cuda(),
+                    torch.from_numpy(c['target']).cuda())
+    rows = gm.numpy()
+    w1 = rows[:, :78400].reshape(3, 100, 784)
+    assert np.allclose(w1[:, (0, 57), :], c['fc1_weight_rows'], rtol=1e-5, atol=1e-6)
+    assert np.allclose(rows[:, 78400:], c['tail'], rtol=1e-5, atol=1e-6)
+    assert np.allclose(np.sqrt((rows.astype(np.float64) ** 2).sum(axis=1)), c['row_norms'], rtol=1e-5)
+    # N = 20 clients, batch 83 (main.py's default): the loop of the oracle on the host vs one batched pass
+    rng = np.random.default_rng(31)
+    n, batch = 20, 83
+    weights = (0.05 * rng.standard_normal(79510)).astype(np.float32)
+    data = rng.standard_normal((n, batch, 784)).astype(np.float32)
+    target = rng.integers(0, 10, size=(n, batch))
+    want = oracle_clients.all_client_gradients(oracle_clients.MnistNet(), weights, torch.from_numpy(data),
+                                               torch.from_numpy(target), flatten_input=False)
+    gm = GradientMatrix(n, 79510, engine=eng, torch_device='cuda')
+    collect_batched(gm, net, torch.from_numpy(weights).cuda(), torch.from_numpy(data).cuda(),
+                    torch.from_numpy(target).cuda())
+    assert np.allclose(gm.numpy(), want, rtol=1e-4, atol=1e-6)
+    # and the round goes on without leaving the GPU: Krum on the assembled matrix picks the oracle's client
+    f = 4
+    assert eng.krum(gm.data, n, f, return_index=True) == ideal.krum_index(ideal.distance_matrix(want), n, f)
+
+
 # ---- device-resident (torch) inputs: zero-copy path -------------------------------------------------
 def test_torch_device_tensors(eng):
     torch = pytest.importorskip('torch')

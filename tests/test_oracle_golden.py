@@ -100,3 +100,36 @@ def test_gradient_assembly(golden):
     for u in range(4):
         faithful.assemble_row(g, u, [c['u%d_t%d' % (u, t)] for t in range(5)])
     assert same(g, c['G'])
+
+
+def check_client_rows(rows, c, rtol=1e-5, atol=1e-7):
+    rows = np.asarray(rows)
+    n = rows.shape[0]
+    w1 = rows[:, :78400].reshape(n, 100, 784)
+    assert np.allclose(w1[:, (0, 57), :], c['fc1_weight_rows'], rtol=rtol, atol=atol)
+    assert np.allclose(rows[:, 78400:], c['tail'], rtol=rtol, atol=atol)
+    assert np.allclose(rows.astype(np.float64).sum(axis=1), c['row_sums'], rtol=1e-4, atol=1e-5)
+    assert np.allclose(np.sqrt((rows.astype(np.float64) ** 2).sum(axis=1)), c['row_norms'], rtol=1e-5)
+
+
+def test_client_step(golden):
+    """user.py:76-92 for three MnistNet clients (fp32 GEMMs: equal up to summation order, 1e-5)."""
+    torch = pytest.importorskip('torch')
+    from oracle import clients
+    c = golden['clients_mnist_3x5']
+    rows = clients.all_client_gradients(clients.MnistNet(), c['weights'], torch.from_numpy(c['data']),
+                                        torch.from_numpy(c['target']))
+    assert rows.shape == (3, 79510) and rows.dtype == np.float32
+    check_client_rows(rows, c)
+
+
+def test_batched_client_step_matches_on_cpu_tensors(golden):
+    """The vmap form (host-side torch plumbing, device agnostic) against the same golden vectors."""
+    torch = pytest.importorskip('torch')
+    from oracle import clients
+    from attacking_federate_learning_amd.clients import per_client_gradients
+    c = golden['clients_mnist_3x5']
+    data = torch.from_numpy(c['data']).view(3, 5, 784)
+    grads = per_client_gradients(clients.MnistNet(), c['weights'], data, torch.from_numpy(c['target']))
+    assert [tuple(g.shape) for g in grads] == [(3, 100, 784), (3, 100), (3, 10, 100), (3, 10)]
+    check_client_rows(np.concatenate([g.reshape(3, -1).numpy() for g in grads], axis=1), c)

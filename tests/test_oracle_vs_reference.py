@@ -144,3 +144,50 @@ def test_backdoor_hook(reference_backdoor, d, z, lr):
     want = att._attack_grads(mean.copy(), stdev.copy(), params.copy(), lr)
     assert np.array_equal(starts[0], faithful.backdoor_initial_params(params, lr, mean))
     assert np.array_equal(want, faithful.backdoor_attack_grads(mean, stdev, params, lr, z, mal), equal_nan=True)
+
+
+def test_client_step_against_user_step():
+    """oracle.clients against the reference's own User.step / MnistNet (torchvision stubbed for the import only)."""
+    import importlib.util
+    import os
+    import sys
+    import types
+    if not os.path.isfile('/root/reference/user.py'):
+        pytest.skip('reference checkout not present on this box')
+    torch = pytest.importorskip('torch')
+    from oracle import clients
+    tv = types.ModuleType('torchvision')
+    tv.datasets, tv.transforms = types.ModuleType('torchvision.datasets'), types.ModuleType('torchvision.transforms')
+    stubs = {'torchvision': tv, 'torchvision.datasets': tv.datasets, 'torchvision.transforms': tv.transforms}
+    saved = {name: sys.modules.get(name) for name in list(stubs) + ['data_sets']}
+    try:
+        sys.modules.update(stubs)
+        mods = {}
+        for name in ('data_sets', 'user'):
+            spec = importlib.util.spec_from_file_location(name if name == 'data_sets' else 'reference_user',
+                                                          os.path.join('/root/reference', name + '.py'))
+            mods[name] = importlib.util.module_from_spec(spec)
+            if name == 'data_sets':
+                sys.modules['data_sets'] = mods[name]      # user.py does `import data_sets`
+            spec.loader.exec_module(mods[name])
+    finally:
+        for name, old in saved.items():
+            if old is None:
+                sys.modules.pop(name, None)
+            else:
+                sys.modules[name] = old
+    ref_data_sets, ref_user = mods['data_sets'], mods['user']
+    rng = np.random.default_rng(7)
+    weights = (0.1 * rng.standard_normal(79510)).astype(np.float32)
+    data = rng.standard_normal((4, 9, 1, 28, 28)).astype(np.float32)
+    target = rng.integers(0, 10, size=(4, 9))
+    want = []
+    for c in range(4):
+        usr = types.SimpleNamespace(user_id=c, is_malicious=False, momentum=0.9, data_set=ref_data_sets.MNIST,
+                                    net=ref_data_sets.MnistNet(), criterion=torch.nn.NLLLoss(),
+                                    train_iterator=iter([(torch.from_numpy(data[c]), torch.from_numpy(target[c]))]))
+        usr.train = types.MethodType(ref_user.User.train, usr)
+        ref_user.User.step(usr, weights, 0.1)
+        want.append(usr.grads)
+    got = clients.all_client_gradients(clients.MnistNet(), weights, torch.from_numpy(data), torch.from_numpy(target))
+    assert np.array_equal(got, np.stack(want))      # same torch ops in the same order: bit-identical
