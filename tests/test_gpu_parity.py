@@ -466,6 +466,40 @@ def test_batched_client_step_fills_the_device_matrix(eng, golden):
     assert eng.krum(gm.data, n, f, return_index=True) == ideal.krum_index(ideal.distance_matrix(want), n, f)
 
 
+@pytest.mark.parametrize('defence', ['Krum', 'TrimmedMean', 'Bulyan', 'NoDefense'])
+def test_device_server_rounds_follow_the_host_loop(eng, defence):
+    """Three whole rounds on the GPU (batched client step -> drift attack -> defence -> momentum step, server.py:54-56,
+    81-90 and main.py:66-71) against the same rounds done on the host by the oracle."""
+    torch = pytest.importorskip('torch')
+    from oracle import clients as oracle_clients
+    from attacking_federate_learning_amd.server import DeviceServer
+    rng = np.random.default_rng(55)
+    n, batch, mal_prop, lr, momentum, z = 15, 16, 0.2, 0.1, 0.9, 1.5
+    f = int(n * mal_prop)
+    weights0 = (0.05 * rng.standard_normal(79510)).astype(np.float32)
+    data = rng.standard_normal((3, n, batch, 784)).astype(np.float32)
+    target = rng.integers(0, 10, size=(3, n, batch))
+    net = oracle_clients.MnistNet().cuda()
+    srv = DeviceServer(n, weights0, mal_prop, lr, momentum, engine=eng)
+    w, v = weights0.copy(), np.zeros_like(weights0)
+    host_net = oracle_clients.MnistNet()
+    for r in range(3):
+        srv.collect_batched(net, torch.from_numpy(data[r]).cuda(), torch.from_numpy(target[r]).cuda())
+        srv.attack(f, z)
+        srv.defend(defence, r)
+        # the same round on the host
+        g = oracle_clients.all_client_gradients(host_net, w, torch.from_numpy(data[r]), torch.from_numpy(target[r]),
+                                                flatten_input=False)
+        g[:f] = faithful.drift_vector(g[:f].copy(), z)
+        agg = {'Krum': faithful.krum, 'TrimmedMean': faithful.trimmed_mean, 'Bulyan': faithful.bulyan,
+               'NoDefense': faithful.no_defense}[defence](g, n, f)
+        v = np.float32(momentum) * v - np.float32(lr) * agg        # server.py:89
+        w = w + v                                                  # server.py:90
+        got = srv.current_weights.cpu().numpy()
+        assert np.allclose(got, w, rtol=1e-4, atol=1e-6), 'round %d' % r
+    assert np.allclose(srv.velocity.cpu().numpy(), v, rtol=1e-4, atol=1e-6)
+
+
 # ---- device-resident (torch) inputs: zero-copy path -------------------------------------------------
 def test_torch_device_tensors(eng):
     torch = pytest.importorskip('torch')
