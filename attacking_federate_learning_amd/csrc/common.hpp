@@ -101,6 +101,8 @@ struct byz_ctx {
     byz::Buffer gram_tickets;    // chunked Gram schedule: next chunk allowed to update a tile's slab
     std::vector<int32_t> tile_order_host;
     int64_t tile_order_T = -1;
+    const double* last_gram = nullptr;   // output of the last launch_gram and whether it used the exact arithmetic
+    bool last_gram_exact = false;
     byz::Buffer dist;            // n x n fp32 distances (when the caller does not pass one)
     byz::Buffer colstat_partials;  // row-split partial column sums
     byz::Buffer sorted_idx;      // n x n uint16: column index at every ascending rank

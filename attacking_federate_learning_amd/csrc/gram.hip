@@ -463,7 +463,9 @@ __global__ __launch_bounds__(256) void gram_reduce_kernel(const PartialT* __rest
     const int jl = threadIdx.x & 63, q = threadIdx.x >> 6;
     const int64_t j = static_cast<int64_t>(blockIdx.x) * 64 + jl;
     const int64_t i = Q == 1 ? static_cast<int64_t>(blockIdx.y) * 4 + q : static_cast<int64_t>(blockIdx.y);
-    const bool live = i < n && j < n;
+    // Q = 4 (few tiles): only the lower triangle is summed -- there the slab reads of consecutive j are consecutive
+    // addresses (the upper triangle reads the same slab entries 512 bytes apart) -- and the result is written twice.
+    const bool live = i < n && j < n && (Q == 1 || j <= i);
     double s = 0.0;
     if (live) {
         const int64_t hi = i > j ? i : j, lo = i > j ? j : i;
@@ -491,7 +493,11 @@ __global__ __launch_bounds__(256) void gram_reduce_kernel(const PartialT* __rest
     } else {
         part[threadIdx.x] = s;
         __syncthreads();
-        if (q == 0 && live) gram[i * n + j] = (part[jl] + part[64 + jl]) + (part[128 + jl] + part[192 + jl]);
+        if (q == 0 && live) {
+            const double total = (part[jl] + part[64 + jl]) + (part[128 + jl] + part[192 + jl]);
+            gram[i * n + j] = total;
+            gram[j * n + i] = total;
+        }
     }
 }
 
@@ -614,6 +620,10 @@ int launch_gram(byz_ctx* ctx, const float* G, int64_t n_rows, int64_t n_cols, in
             }
         }
     }
+    // one tile (N <= 128, the reference's own sizes): one workgroup per CU.  More slabs cost more in slab traffic
+    // and in the reduction than they gain in streaming parallelism (measured at N = 100, D = 79,510: 85 us per Krum
+    // round with 256 slabs, 100 us with 512, 97 us with 128)
+    if (n_tiles == 1 && splits > ctx->num_cus) splits = ctx->num_cus;
     const int forced = env_int("BYZ_GRAM_SPLITS", 0);
     if (forced > 0) splits = forced;
     if (splits < 1) splits = 1;
@@ -628,6 +638,8 @@ int launch_gram(byz_ctx* ctx, const float* G, int64_t n_rows, int64_t n_cols, in
     const std::string mode_s = mode_env ? mode_env : (n_tiles >= 4 ? "split" : "exact");
     const bool dma = (ld % 4 == 0) && (reinterpret_cast<uintptr_t>(G) % 16 == 0) && env_int("BYZ_GRAM_NO_DMA", 0) == 0;
     const bool split_mode = dma && mode_s == "split";
+    ctx->last_gram = gram;
+    ctx->last_gram_exact = !split_mode;
     // chunked schedule (see the kernel): many tiles and a long K
     const int64_t chunk_stages = env_int("BYZ_GRAM_CHUNK_COLS", 8192) / BK;
     const bool chunked = n_tiles >= 256 && stages > 2 * chunk_stages && env_int("BYZ_GRAM_NO_CHUNKS", 0) == 0 &&
@@ -714,7 +726,10 @@ int launch_distances_from_gram(byz_ctx* ctx, const double* gram, int64_t n, floa
     dim3 grid(static_cast<unsigned>(ceil_div(n, 64)), static_cast<unsigned>(ceil_div(n, 4)));
     distance_kernel<<<grid, 256, 0, stream>>>(gram, n, dist);
     BYZ_TRY(check_launch("distance_kernel"));
-    // exact ties for identical rows, whatever arithmetic produced the Gram (see duplicate_rep_kernel)
+    // exact ties for identical rows, whatever arithmetic produced the Gram (see duplicate_rep_kernel).  The exact
+    // arithmetic needs no help: identical rows meet identical operands in an identical order, products commute, so
+    // their Gram rows are bitwise equal already (three launches saved where launches are the cost: N <= 256).
+    if (gram == ctx->last_gram && ctx->last_gram_exact) return BYZ_OK;
     BYZ_TRY(ctx->dup_rep.ensure(static_cast<size_t>(n + 1) * sizeof(int32_t)));
     int32_t* rep = ctx->dup_rep.as<int32_t>();
     BYZ_HIP(hipMemsetAsync(rep + n, 0, sizeof(int32_t), stream));

@@ -780,7 +780,7 @@ __device__ __forceinline__ void finish_tile(float (&x)[NC][RPL], const float (&m
 template <int RPL, int NC, int WAVES>
 __global__ __launch_bounds__(64 * WAVES, (RPL * NC <= 64 || WAVES == 16 ? 4 : 2)) void median_window_kernel(
     const float* __restrict__ G, int n_rows, int64_t n_cols, int64_t ld, const int32_t* __restrict__ row_index,
-    int keep, float* __restrict__ out, int stagger_cycles) {
+    int keep, float* __restrict__ out) {
     constexpr int GS = RPL >= 4 ? 4 : RPL;                    // registers (64-row groups) per guard group
     constexpr int JC = GS;   // registers per transit chunk (512-row chunks cost a wave per SIMD of occupancy: 2.38 -> 2.96 ms)
     constexpr int NCH = RPL / JC;
@@ -802,17 +802,6 @@ __global__ __launch_bounds__(64 * WAVES, (RPL * NC <= 64 || WAVES == 16 ? 4 : 2)
     const int slots = groups * 64 * GS;
 
     if (tid < QUADS) nonfinite[tid] = 0;
-
-    // Phase stagger.  All workgroups of a CU start together and take equally long, so left alone they load together and
-    // then compute together, and load time and compute time add up.  The first generation of workgroups (one per
-    // resident slot; workgroups are dealt 8 XCDs x 32 CUs round-robin, so blockIdx >> 8 is the slot within the CU) is
-    // delayed by a quarter of a tile time per slot; every later workgroup starts when an earlier one ends, so the offsets
-    // persist and one slot's loads overlap the other slots' arithmetic.  Only speed depends on it.  (Measured on C3: no
-    // effect at any delay, so the default is off: the phases are not what keeps staging and selection from overlapping.)
-    if (stagger_cycles > 0 && blockIdx.x < 1024u) {
-        const int phase = static_cast<int>(blockIdx.x >> 8);
-        for (int i = 0; i < phase * stagger_cycles; i += 4096) __builtin_amdgcn_s_sleep(64);   // 64 x 64 cycles
-    }
 
     // ---- stage: global (128-byte row segments) -> LDS transit -> registers (4 columns x RPL rows per lane)
     const int ld_q = (tid % QUADS) * 4, ld_r = tid / QUADS;
@@ -892,111 +881,12 @@ __global__ __launch_bounds__(64 * WAVES, (RPL * NC <= 64 || WAVES == 16 ? 4 : 2)
     finish_tile<RPL, NC>(x, mn, mx, suspicious, groups, slots, n_rows, keep, lane, wave, strip, c_base, n_cols, out);
 }
 
-// Persistent LDS-DMA variant for up to 1024 rows (the trimmed-mean sizes of the reference: N <= 1000 clients).
-//
-// The kernel above loads a tile, then computes on it, and every workgroup of a CU does so in the same phase (they
-// start together and take equally long), so the load time and the compute time ADD: 1.15 ms + 1.7 ms at C3.  Here a
-// workgroup walks over many tiles, and while it computes on tile t (in registers) the whole of tile t + 1 is already
-// streaming into LDS by LDS-DMA: no VGPRs, no ds_write pass, 16 wave-instructions of 1 KiB each per wave in flight.
-//   LDS image: [row][16 floats]; `global_load_lds` writes wave-uniform base + 16 * lane, so a wave-instruction covers
-//   16 rows x 4 quads.  Reading one quad down 64 rows would hit four bank groups only; the quad index is XOR-ed with
-//   (row >> 2) & 3 on the DMA's source address and on the read.
-//   Rows past R are +inf, written once (masked lanes of the DMA never touch them).
-// Requires 16-byte aligned row segments (ld % 4 == 0, n_cols % 4 == 0, aligned base); anything else takes the kernel above.
-template <int RPL>
-__global__ __launch_bounds__(256, (RPL <= 8 ? 4 : 2)) void median_window_dma_kernel(
-    const float* __restrict__ G, int n_rows, int64_t n_cols, int64_t ld, const int32_t* __restrict__ row_index,
-    int keep, float* __restrict__ out, int64_t n_tiles) {
-    constexpr int NC = 4, WAVES = 4;
-    constexpr int GS = RPL >= 4 ? 4 : RPL;
-    constexpr int ROWS = 64 * RPL;
-    __shared__ __attribute__((aligned(16))) float tile[ROWS * 16 + WAVES * kWaveScratch];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    float* strip = tile + ROWS * 16 + wave * kWaveScratch;
-    const float pinf = __builtin_inff();
-    const int chunks = (n_rows + 64 * GS - 1) / (64 * GS);   // guard groups in use
-    const int slots = chunks * 64 * GS;
-
-    // padding rows, once
-    for (int i = n_rows * 4 + tid; i < slots * 4; i += 256)
-        *reinterpret_cast<f32x4*>(tile + i * 4) = f32x4{pinf, pinf, pinf, pinf};
-
-    const int64_t last_quad_col = n_cols - 4;
-    auto issue = [&](int64_t t) __attribute__((always_inline)) {
-        const int64_t c_base = t * kCols;
-        for (int r0 = wave * 16; r0 < n_rows; r0 += 64) {   // 16 rows per wave-instruction
-            const int row = r0 + (lane >> 2);
-            if (row < n_rows) {
-                const int64_t src = row_index ? row_index[row] : row;
-                const int quad = (lane & 3) ^ ((row >> 2) & 3);
-                int64_t col = c_base + 4 * quad;
-                if (col > last_quad_col) col = last_quad_col;   // ragged last tile: duplicates, never stored
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(G + src * ld + col),
-                                                 (__attribute__((address_space(3))) void*)(tile + r0 * 16), 16, 0, 0);
-            }
-        }
-    };
-
-    int64_t t = blockIdx.x;
-    if (t < n_tiles) issue(t);
-    for (; t < n_tiles; t += gridDim.x) {
-        __syncthreads();   // the DMA of this tile has landed (hipcc waits vmcnt(0) here) and is visible to every wave
-        float x[NC][RPL];
-        float mn[NC], mx[NC];
-        float poison = 0.0f;
-#pragma unroll
-        for (int c = 0; c < NC; ++c) {
-            mn[c] = pinf;
-            mx[c] = -pinf;
-        }
-#pragma unroll
-        for (int g = 0; g < RPL / GS; ++g) {
-            if (g < chunks) {
-                const bool last_group = g == chunks - 1;
-#pragma unroll
-                for (int jj = 0; jj < GS; ++jj) {
-                    const int row = 64 * (g * GS + jj) + lane;
-                    const f32x4 v4 = *reinterpret_cast<const f32x4*>(tile + row * 16 + ((wave ^ ((row >> 2) & 3)) << 2));
-                    const bool real = !last_group || row < n_rows;
-                    const float val[4] = {v4.x, v4.y, v4.z, v4.w};
-                    poison = __builtin_fmaf(real ? (v4.x + v4.y) + (v4.z + v4.w) : 0.0f, 0.0f, poison);
-#pragma unroll
-                    for (int c = 0; c < NC; ++c) {
-                        const float e = val[c];
-                        x[c][g * GS + jj] = e;
-                        mn[c] = __builtin_fminf(mn[c], e);
-                        mx[c] = __builtin_fmaxf(mx[c], real ? e : -pinf);
-                    }
-                }
-            }
-        }
-        const bool suspicious = __ballot(poison != poison) != 0ull;
-        __syncthreads();   // every wave holds its values: the LDS tile is free again
-        if (t + gridDim.x < n_tiles) issue(t + gridDim.x);
-        finish_tile<RPL, NC>(x, mn, mx, suspicious, chunks, slots, n_rows, keep, lane, wave, strip, t * kCols, n_cols, out);
-    }
-}
-
-template <int RPL>
-int launch_dma(byz_ctx* ctx, const float* G, int64_t n_rows, int64_t n_cols, int64_t ld, const int32_t* row_index,
-               int64_t keep, float* out, hipStream_t stream) {
-    const int64_t n_tiles = ceil_div(n_cols, kCols);
-    const int per_cu = RPL <= 8 ? 4 : 2;
-    int64_t grid = static_cast<int64_t>(ctx->num_cus) * per_cu;
-    if (grid > n_tiles) grid = n_tiles;
-    median_window_dma_kernel<RPL><<<static_cast<unsigned>(grid), 256, 0, stream>>>(
-        G, static_cast<int>(n_rows), n_cols, ld, row_index, static_cast<int>(keep), out, n_tiles);
-    return check_launch("median_window_dma_kernel");
-}
-
 template <int RPL, int NC, int WAVES>
 int launch_rpl(const float* G, int64_t n_rows, int64_t n_cols, int64_t ld, const int32_t* row_index, int64_t keep,
                float* out, hipStream_t stream) {
     const int64_t n_tiles = ceil_div(n_cols, static_cast<int64_t>(WAVES * NC));
     median_window_kernel<RPL, NC, WAVES><<<static_cast<unsigned>(n_tiles), 64 * WAVES, 0, stream>>>(
-        G, static_cast<int>(n_rows), n_cols, ld, row_index, static_cast<int>(keep), out,
-        std::getenv("BYZ_TM_STAGGER") ? std::atoi(std::getenv("BYZ_TM_STAGGER")) : 0);   // measured: no effect, off
+        G, static_cast<int>(n_rows), n_cols, ld, row_index, static_cast<int>(keep), out);
     return check_launch("median_window_kernel");
 }
 
@@ -1019,19 +909,10 @@ int launch_trimmed_mean(byz_ctx* ctx, const float* G, int64_t n_rows, int64_t n_
         if (rpl >= from && rpl <= 64) return launch_rpl<64, 1, 16>(G, n_rows, n_cols, ld, row_index, keep, out, stream);
     }
     if (rpl > 88) return launch_trimmed_mean_sorted(ctx, G, n_rows, n_cols, ld, row_index, keep, out, stream);
-    // 16-byte aligned row segments and at most 1024 rows: the persistent LDS-DMA kernel
-    const bool dma_ok = (ld % 4 == 0) && (n_cols % 4 == 0) && (reinterpret_cast<uintptr_t>(G) % 16 == 0) && rpl <= 16 &&
-                        std::getenv("BYZ_TM_DMA") != nullptr;   // measured slower than the staggered kernel (2 waves per SIMD)
-    if (dma_ok) {
-        if (rpl <= 4) return launch_dma<4>(ctx, G, n_rows, n_cols, ld, row_index, keep, out, stream);
-        if (rpl <= 8) return launch_dma<8>(ctx, G, n_rows, n_cols, ld, row_index, keep, out, stream);
-        return launch_dma<16>(ctx, G, n_rows, n_cols, ld, row_index, keep, out, stream);
-    }
     if (rpl <= 1) return launch_rpl<1, 4, 4>(G, n_rows, n_cols, ld, row_index, keep, out, stream);
     if (rpl <= 2) return launch_rpl<2, 4, 4>(G, n_rows, n_cols, ld, row_index, keep, out, stream);
     if (rpl <= 4) return launch_rpl<4, 4, 4>(G, n_rows, n_cols, ld, row_index, keep, out, stream);
     if (rpl <= 8) return launch_rpl<8, 4, 4>(G, n_rows, n_cols, ld, row_index, keep, out, stream);
-    if (rpl <= 16 && std::getenv("BYZ_TM_W8")) return launch_rpl<16, 4, 8>(G, n_rows, n_cols, ld, row_index, keep, out, stream);
     if (rpl <= 16) return launch_rpl<16, 4, 4>(G, n_rows, n_cols, ld, row_index, keep, out, stream);
     if (rpl <= 24) return launch_rpl<24, 4, 4>(G, n_rows, n_cols, ld, row_index, keep, out, stream);
     if (rpl <= 32) return launch_rpl<32, 4, 4>(G, n_rows, n_cols, ld, row_index, keep, out, stream);
