@@ -138,6 +138,10 @@ void byz_ctx_destroy(byz_ctx* ctx) {
     ctx->tile_order.release();
     ctx->gram_tickets.release();
     ctx->dup_rep.release();
+    ctx->row_signature.release();
+    ctx->unique_rows.release();
+    ctx->row_map.release();
+    ctx->gram_compact.release();
     ctx->dist.release();
     ctx->colstat_partials.release();
     ctx->sorted_idx.release();

@@ -99,6 +99,10 @@ struct byz_ctx {
     byz::Buffer tile_order;      // (ti, tj) of every lower-triangle tile, in XCD-friendly order
     byz::Buffer dup_rep;         // representative row of every group of identical rows (+ one flag word)
     byz::Buffer gram_tickets;    // chunked Gram schedule: next chunk allowed to update a tile's slab
+    byz::Buffer row_signature;   // dedup: 64-bit signature of every row
+    byz::Buffer unique_rows;     // dedup: the unique rows, ascending
+    byz::Buffer row_map;         // dedup: position of every row's representative among the unique rows (+ scratch)
+    byz::Buffer gram_compact;    // dedup: Gram of the unique rows
     std::vector<int32_t> tile_order_host;
     int64_t tile_order_T = -1;
     const double* last_gram = nullptr;   // output of the last launch_gram and whether it used the exact arithmetic
@@ -188,6 +192,11 @@ int launch_assemble_columns(byz_ctx* ctx, float* G, int64_t n_rows, int64_t n_co
 
 int launch_gram(byz_ctx* ctx, const float* G, int64_t n_rows, int64_t n_cols, int64_t ld, double* gram,
                 hipStream_t stream);
+// dedup.hip: identical rows found before the Gram
+int find_unique_rows(byz_ctx* ctx, const float* G, int64_t n_rows, int64_t n_cols, int64_t ld, hipStream_t stream,
+                     int64_t* n_unique_host);
+int launch_gram_expand(byz_ctx* ctx, const double* compact, int64_t n_unique, int64_t n_rows, double* gram,
+                       hipStream_t stream);
 int launch_distances_from_gram(byz_ctx* ctx, const double* gram, int64_t n, float* dist,
                                hipStream_t stream);
 

@@ -108,7 +108,8 @@ __global__ __launch_bounds__(THREADS, 2) void gram_tile_kernel(const float* __re
                                                                int64_t stages_per_split,
                                                                PartialT* __restrict__ partial, int n_tiles,
                                                                const int2* __restrict__ tile_order, int per_xcd, int n_splits,
-                                                               int* __restrict__ tickets, int round_size) {
+                                                               int* __restrict__ tickets, int round_size,
+                                                               const int32_t* __restrict__ row_index) {
     __shared__ __attribute__((aligned(16))) float lds[2 * 2 * TILE_FLOATS];  // [2 buffers][A | B][TM][row]
 
     // Workgroup -> (tile, K split).  Workgroups are dealt to the 8 XCDs round-robin (observed; only speed
@@ -174,6 +175,7 @@ __global__ __launch_bounds__(THREADS, 2) void gram_tile_kernel(const float* __re
     auto row_ptr = [&](int tile_row0, int local_row) {
         int64_t r = static_cast<int64_t>(tile_row0) * TM + local_row;
         if (r > n_rows - 1) r = n_rows - 1;
+        if (row_index != nullptr) r = row_index[r];   // logical row r of the (deduplicated) matrix is G[row_index[r]]
         return G + r * ld;
     };
     // register staging (the whole loop without DMA, the ragged K tail with it): 8 lanes cover one 128-byte
@@ -581,8 +583,9 @@ int env_int(const char* name, int fallback) {
 
 }  // namespace
 
-int launch_gram(byz_ctx* ctx, const float* G, int64_t n_rows, int64_t n_cols, int64_t ld, double* gram,
-                hipStream_t stream) {
+// Gram of the n_rows logical rows G[row_index[r]] (row_index == nullptr: the rows themselves)
+static int launch_gram_rows(byz_ctx* ctx, const float* G, int64_t n_rows, int64_t n_cols, int64_t ld,
+                            const int32_t* row_index, double* gram, hipStream_t stream) {
     BYZ_REQUIRE(G && gram && n_rows > 0 && n_cols > 0 && ld >= n_cols, "gram: bad shape %lld x %lld ld %lld",
                 (long long)n_rows, (long long)n_cols, (long long)ld);
     const int64_t T = ceil_div(n_rows, TM);
@@ -690,7 +693,7 @@ int launch_gram(byz_ctx* ctx, const float* G, int64_t n_rows, int64_t n_cols, in
 #define BYZ_GRAM(T, D, S)                                                                                     \
     gram_tile_kernel<T, D, S><<<grid, THREADS, 0, stream>>>(G, n_rows, n_cols, ld, stages_per_split,           \
                                                             ctx->gram_partials.as<T>(), (int)n_tiles, order,    \
-                                                            (int)per_xcd, (int)splits, tickets, round_size)
+                                                            (int)per_xcd, (int)splits, tickets, round_size, row_index)
         if (wide) {
             if (split_mode) BYZ_GRAM(double, true, true);
             else if (dma) BYZ_GRAM(double, true, false);
@@ -718,6 +721,27 @@ int launch_gram(byz_ctx* ctx, const float* G, int64_t n_rows, int64_t n_cols, in
         BYZ_TRY(check_launch("gram_reduce_kernel"));
     }
     return BYZ_OK;
+}
+
+int launch_gram(byz_ctx* ctx, const float* G, int64_t n_rows, int64_t n_cols, int64_t ld, double* gram,
+                hipStream_t stream) {
+    BYZ_REQUIRE(G && gram && n_rows > 0 && n_cols > 0 && ld >= n_cols, "gram: bad shape %lld x %lld ld %lld",
+                (long long)n_rows, (long long)n_cols, (long long)ld);
+    // Identical rows first (dedup.hip): worth a look once the Gram is compute bound and a 4-byte read-back does not
+    // show (N >= 512); used when it removes at least one row of tiles.
+    if (n_rows >= 512 && n_rows <= 16384 && env_int("BYZ_GRAM_DEDUP", 1) != 0) {
+        int64_t n_unique = n_rows;
+        BYZ_TRY(find_unique_rows(ctx, G, n_rows, n_cols, ld, stream, &n_unique));
+        if (ceil_div(n_unique, TM) < ceil_div(n_rows, TM)) {
+            BYZ_TRY(ctx->gram_compact.ensure(static_cast<size_t>(n_unique) * n_unique * sizeof(double)));
+            double* compact = ctx->gram_compact.as<double>();
+            BYZ_TRY(launch_gram_rows(ctx, G, n_unique, n_cols, ld, ctx->unique_rows.as<int32_t>(), compact, stream));
+            BYZ_TRY(launch_gram_expand(ctx, compact, n_unique, n_rows, gram, stream));
+            ctx->last_gram = gram;
+            return BYZ_OK;
+        }
+    }
+    return launch_gram_rows(ctx, G, n_rows, n_cols, ld, nullptr, gram, stream);
 }
 
 int launch_distances_from_gram(byz_ctx* ctx, const double* gram, int64_t n, float* dist, hipStream_t stream) {

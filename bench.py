@@ -128,7 +128,10 @@ class BulyanSharded(Workload):
     def dominant(self):
         # the Gram: N^2 * D_local flops per launch (half Gram, 2 flop per MAC) -- SURVEY.md 8(d).  The peak is the
         # dense fp32-input MFMA peak: the algorithmic flops are fp32 flops, whatever instructions carry them.
-        return {'kernel': 'gram_tile', 'bound': 'mfma', 'work': float(self.n) ** 2 * self.d_local,
+        # under the attack rows 0..f-1 are one vector and the engine runs the Gram over the unique rows only: the
+        # kernel's work is (N - f + 1)^2 * D_local, not N^2 * D_local
+        rows = self.n - self.f + 1 if self.with_attack and self.n >= 512 else self.n
+        return {'kernel': 'gram_tile', 'bound': 'mfma', 'work': float(rows) ** 2 * self.d_local,
                 'peak': PEAK_MFMA_F32, 'unit': 'TFLOP/s', 'scale': 1e12,
                 'issued_factor': 6.0 if self.n > 256 else 1.0, 'issued_peak': 2.5e15 if self.n > 256 else PEAK_MFMA_F32}
 

@@ -169,6 +169,47 @@ def test_distances_chunked_schedule_large_n(eng):
     assert torch.equal(dist, again)
 
 
+def test_identical_rows_are_found_before_the_gram(eng):
+    """Under the attack a quarter of the rows are one vector (malicious.py:26-27).  From N = 512 the engine finds
+    identical rows first (signature of sampled columns -> full bitwise verification) and runs the Gram over the
+    unique rows only.  A row that differs from the group in ONE unsampled column has the group's signature and must be
+    rejected by the verification; everything must equal the path without the shortcut."""
+    import os
+    n, d = 700, 40000
+    rng = np.random.default_rng(123)
+    g = scaled(124, n, d)
+    group = np.sort(rng.choice(n, size=300, replace=False))
+    g[group] = g[group[0]]
+    near = int(np.setdiff1d(np.arange(n), group)[17])
+    g[near] = g[group[0]]
+    g[near, 3000] += 1.0                        # column 3000 lies in none of the eight sampled segments
+    with_shortcut = eng.pairwise_distances(g).numpy()
+    os.environ['BYZ_GRAM_DEDUP'] = '0'
+    try:
+        without = eng.pairwise_distances(g).numpy()
+    finally:
+        del os.environ['BYZ_GRAM_DEDUP']
+    off = ~np.eye(n, dtype=bool)
+    sub = with_shortcut[np.ix_(group, group)]
+    assert np.all(sub[~np.eye(len(group), dtype=bool)] == 0.0)
+    others = np.setdiff1d(np.arange(n), group)
+    assert all(np.array_equal(with_shortcut[group[0], others], with_shortcut[i, others]) for i in group[1:])
+    assert 0.9 < with_shortcut[near, group[0]] < 1.1 and with_shortcut[near, group[5]] == with_shortcut[near, group[0]]
+    assert np.array_equal(with_shortcut, with_shortcut.T)
+    # pairs of distinct rows meet the same operands in the same order either way
+    rest = np.ix_(others, others)
+    assert np.allclose(with_shortcut[rest][off[rest]], without[rest][off[rest]], rtol=1e-6, atol=0.0)
+    assert np.allclose(with_shortcut[off], without[off], rtol=1e-5, atol=2e-2)   # near-duplicate: cancellation in d^2
+    want = ideal.distance_matrix(g)
+    far = want > 1.5
+    assert np.allclose(with_shortcut[far], want[far], rtol=2e-6)
+    # selection on top of it: the copies tie exactly and the reference's visit order decides, with or without
+    f = 150
+    assert eng.krum_select(with_shortcut, n, f) == eng.krum_select(without, n, f) == \
+        faithful.krum_pick(with_shortcut, faithful.visit_order(n), n, f)
+    assert np.array_equal(eng.bulyan_select(with_shortcut, n, f), eng.bulyan_select(without, n, f))
+
+
 def test_identical_rows_have_zero_distance_and_tie_exactly(eng):
     g = gaussian(7, 50, 33333)
     g[:12] = g[3]
