@@ -210,6 +210,23 @@ def test_identical_rows_are_found_before_the_gram(eng):
     assert np.array_equal(eng.bulyan_select(with_shortcut, n, f), eng.bulyan_select(without, n, f))
 
 
+def test_gram_over_very_few_unique_rows(eng):
+    """N >= 512 rows that are all one vector, or two vectors: the Gram runs over 1 or 2 rows and is expanded."""
+    n, d = 600, 5000
+    base = gaussian(31, 2, d)
+    g = np.tile(base[0], (n, 1))
+    dist = eng.pairwise_distances(g).numpy()
+    assert np.all(dist[~np.eye(n, dtype=bool)] == 0.0)
+    assert eng.krum_select(dist, n, 100) == 1                      # every score ties: visit order 1, 0, 2, ...
+    g[::3] = base[1]
+    dist = eng.pairwise_distances(g).numpy()
+    want = np.float32(np.linalg.norm(base[0].astype(np.float64) - base[1].astype(np.float64)))
+    same = (np.arange(n)[:, None] % 3 == 0) == (np.arange(n)[None, :] % 3 == 0)
+    off = ~np.eye(n, dtype=bool)
+    assert np.all(dist[same & off] == 0.0)
+    assert np.allclose(dist[~same], want, rtol=1e-5) and len(np.unique(dist[~same])) == 1
+
+
 def test_identical_rows_have_zero_distance_and_tie_exactly(eng):
     g = gaussian(7, 50, 33333)
     g[:12] = g[3]
