@@ -102,9 +102,8 @@ def free_port():
         return s.getsockname()[1]
 
 
-@pytest.mark.parametrize('n,d,f', [(23, 157, 5), (12, 64, 2)])
-def test_two_ranks_equal_the_unsharded_oracle(n, d, f):
-    world = 2
+@pytest.mark.parametrize('world,n,d,f', [(2, 23, 157, 5), (2, 12, 64, 2), (4, 23, 157, 5), (3, 12, 64, 2)])
+def test_ranks_equal_the_unsharded_oracle(world, n, d, f):
     with mp.Manager() as manager:
         results = manager.dict()
         mp.spawn(worker, args=(world, free_port(), n, d, f, results), nprocs=world, join=True)
