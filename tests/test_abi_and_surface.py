@@ -29,6 +29,52 @@ def test_library_exports_every_declared_symbol():
     assert lib.byz_kernel_name(1) == b'gram_tile'
 
 
+def declared_prototypes():
+    """name -> list of C parameter types, parsed from include/byzagg.h."""
+    text = open(os.path.join(ROOT, 'include', 'byzagg.h')).read()
+    text = re.sub(r'/\*.*?\*/', '', text, flags=re.S)
+    protos = {}
+    for ret, name, args in re.findall(r'\b(int|const char\*|void)\s+(byz_[a-z0-9_]+)\s*\(([^;{]*?)\)\s*;', text, flags=re.S):
+        args = ' '.join(args.split())
+        protos[name] = [] if args in ('', 'void') else [a.strip() for a in args.split(',')]
+    return protos
+
+
+def test_ctypes_table_matches_the_header_argument_by_argument():
+    """A ctypes prototype that disagrees with the header corrupts a call silently: compare count and kind."""
+    import ctypes
+    from attacking_federate_learning_amd import _native
+    protos = declared_prototypes()
+    assert sorted(protos) == sorted(_native.EXPORTED_SYMBOLS)
+
+    def kind(c_type):   # how the C declaration must look for this ctypes argument type
+        if c_type in (ctypes.c_int64,):
+            return 'int64'
+        if c_type in (ctypes.c_int, ctypes.c_int32):
+            return 'int'
+        if c_type is ctypes.c_float:
+            return 'float'
+        return 'pointer'
+
+    def c_kind(decl):
+        base = decl.rsplit(' ', 1)[0] if ' ' in decl else decl
+        if '*' in decl:
+            return 'pointer'
+        if 'int64_t' in base:
+            return 'int64'
+        if 'float' in base:
+            return 'float'
+        if re.search(r'\bint(32_t)?\b', base):
+            return 'int'
+        raise AssertionError('unrecognised parameter %r' % decl)
+
+    for name, argtypes in _native._PROTOTYPES.items():
+        decl = protos[name]
+        assert len(decl) == len(argtypes), (name, decl, argtypes)
+        for position, (d, a) in enumerate(zip(decl, argtypes)):
+            assert c_kind(d) == kind(a), (name, position, d, a)
+
+
 def test_limits_are_reported_without_a_gpu():
     import ctypes
     from attacking_federate_learning_amd import _native
