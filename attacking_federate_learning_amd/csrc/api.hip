@@ -42,10 +42,33 @@ int read_i32(byz_ctx* ctx, const int32_t* dev, int32_t* host, int64_t count, hip
     return BYZ_OK;
 }
 
+// The device-side scalars (common.hpp: layout of ctx->small) in one read-back; the sticky status word is checked and
+// cleared here, so that every entry point that synchronises anyway also reports what a kernel could only flag.
+int read_small(byz_ctx* ctx, int32_t (&words)[32], hipStream_t stream) {
+    BYZ_TRY(read_i32(ctx, ctx->small.as<int32_t>(), words, 32, stream));
+    const int32_t sticky = words[16];
+    if (sticky != 0) {
+        BYZ_HIP(hipMemsetAsync(device_status_word(ctx), 0, sizeof(int32_t), stream));
+        if (sticky & 1) {
+            set_error("gram: a K chunk never received its tile's ticket (workgroups dispatched out of order or the GPU is "
+                      "shared); the distance matrix of this call is invalid");
+            return BYZ_E_HIP;
+        }
+        if (sticky & 4) {
+            set_error("distances: two rows have bitwise equal Gram entries but differ; their near-duplicate pairs were not "
+                      "re-evaluated (please report the input)");
+            return BYZ_E_UNSUPPORTED;
+        }
+        set_error("distances: %d near-duplicate pairs exceed the list capacity (BYZ_NEAR_PAIR_CAPACITY); their distances "
+                  "were not re-evaluated", words[17]);
+        return BYZ_E_UNSUPPORTED;
+    }
+    return BYZ_OK;
+}
+
 int ensure_distance_workspaces(byz_ctx* ctx, int64_t n) {
     BYZ_TRY(ctx->gram.ensure(static_cast<size_t>(n) * n * sizeof(double)));
     BYZ_TRY(ctx->dist.ensure(static_cast<size_t>(n) * n * sizeof(float)));
-    BYZ_TRY(ctx->small.ensure(256));
     return BYZ_OK;
 }
 
@@ -79,13 +102,18 @@ int bulyan_select(byz_ctx* ctx, const float* dist, int64_t n, int64_t users_coun
     int64_t drop = (n - 1) - users_count + corrupted;
     if (drop < 0) drop = 0;
     if (drop > n - 1) drop = n - 1;
-    BYZ_TRY(ctx->small.ensure(256));
     BYZ_TRY(launch_row_sort(ctx, dist, n, 0, drop, true, stream));
     int32_t* status_dev = ctx->small.as<int32_t>() + 8;
-    BYZ_TRY(launch_bulyan_loop(ctx, dist, n, theta, drop, selection_dev, status_dev, stream));
-    int32_t status = 0;
-    BYZ_TRY(read_i32(ctx, status_dev, &status, 1, stream));
-    if (status != 0) {
+    BYZ_TRY(launch_bulyan_loop(ctx, dist, n, theta, drop, users_count, corrupted, selection_dev, status_dev, stream));
+    int32_t words[32];
+    BYZ_TRY(read_small(ctx, words, stream));
+    const int32_t status[2] = {words[8], words[9]};
+    ctx->bulyan_rescored = status[1];
+    if (status[0] == 2) {
+        set_error("bulyan: the selection loop's workgroups lost contact with each other (exchange timed out)");
+        return BYZ_E_HIP;
+    }
+    if (status[0] != 0) {
         set_error("bulyan: no row scored below 1e20 (the reference raises KeyError(-1) here)");
         return BYZ_E_NO_WINNER;
     }
@@ -124,6 +152,11 @@ int byz_ctx_create(int device, byz_ctx** out) {
     byz_ctx* ctx = new byz_ctx();
     ctx->device = device;
     ctx->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    if (ctx->small.ensure(256) != BYZ_OK || hipMemset(ctx->small.ptr, 0, 256) != hipSuccess) {
+        delete ctx;
+        set_error("byz_ctx_create: cannot allocate the device scalars");
+        return BYZ_E_HIP;
+    }
     *out = ctx;
     return BYZ_OK;
 }
@@ -136,6 +169,7 @@ void byz_ctx_destroy(byz_ctx* ctx) {
     ctx->gram_partials.release();
     ctx->gram.release();
     ctx->tile_order.release();
+    ctx->tile_owned.release();
     ctx->gram_tickets.release();
     ctx->dup_rep.release();
     ctx->row_signature.release();
@@ -143,6 +177,10 @@ void byz_ctx_destroy(byz_ctx* ctx) {
     ctx->row_map.release();
     ctx->gram_compact.release();
     ctx->dist.release();
+    ctx->near_pairs.release();
+    ctx->gram_rep.release();
+    ctx->near_sq.release();
+    ctx->near_partial.release();
     ctx->colstat_partials.release();
     ctx->sorted_idx.release();
     ctx->rank_t.release();
@@ -150,6 +188,8 @@ void byz_ctx_destroy(byz_ctx* ctx) {
     ctx->row_top.release();
     ctx->scores.release();
     ctx->selection.release();
+    ctx->twin_class.release();
+    ctx->xchg.release();
     ctx->small.release();
     ctx->stage_in.release();
     ctx->stage_out.release();
@@ -240,9 +280,61 @@ int byz_gram_dev(byz_ctx* ctx, const float* G, int64_t n_rows, int64_t n_cols, i
     return launch_gram(ctx, G, n_rows, n_cols, ld, gram, as_stream(stream));
 }
 
+int byz_gram_share_dev(byz_ctx* ctx, const float* G, int64_t n_rows, int64_t n_cols, int64_t ld,
+                       const int32_t* row_index, int share_count, int share_index, double* gram, void* stream) {
+    BYZ_TRY(enter(ctx));
+    // with row_index the logical matrix has n_rows rows taken from anywhere in G: only the pointer and ld are checkable
+    BYZ_REQUIRE(G && n_rows > 0 && n_cols > 0 && ld >= n_cols, "gram_share: bad matrix");
+    return launch_gram_share(ctx, G, n_rows, n_cols, ld, row_index, share_count, share_index, gram, as_stream(stream));
+}
+
 int byz_distances_from_gram_dev(byz_ctx* ctx, const double* gram, int64_t n_rows, float* dist, void* stream) {
     BYZ_TRY(enter(ctx));
-    return launch_distances_from_gram(ctx, gram, n_rows, dist, as_stream(stream));
+    ctx->row_map_rows = 0;   // an external Gram: nothing is known about its rows
+    return launch_distances_from_gram(ctx, gram, n_rows, dist, as_stream(stream), nullptr, 0, 0);
+}
+
+int byz_near_pairs_count(byz_ctx* ctx, int64_t* count_host, void* stream) {
+    BYZ_TRY(enter(ctx));
+    BYZ_REQUIRE(count_host, "near_pairs_count: null output");
+    int32_t words[32];
+    BYZ_TRY(read_small(ctx, words, as_stream(stream)));
+    *count_host = words[17];
+    if (words[17] > ctx->near_pair_capacity) {
+        set_error("distances: %d near-duplicate pairs exceed the list capacity %lld (BYZ_NEAR_PAIR_CAPACITY)", words[17],
+                  (long long)ctx->near_pair_capacity);
+        return BYZ_E_UNSUPPORTED;
+    }
+    return BYZ_OK;
+}
+
+int byz_near_pairs_sqdist_dev(byz_ctx* ctx, const float* G, int64_t n_rows, int64_t n_cols, int64_t ld,
+                              const int32_t* row_index, double* sq_dev, void* stream) {
+    BYZ_TRY(enter(ctx));
+    BYZ_TRY(check_matrix(G, n_rows, n_cols, ld, "near_pairs_sqdist"));
+    BYZ_REQUIRE(sq_dev && ctx->near_pair_capacity > 0, "near_pairs_sqdist: no pair list (call byz_distances_from_gram_dev first)");
+    return launch_near_pair_sqdist(ctx, G, n_cols, ld, row_index, sq_dev, as_stream(stream));
+}
+
+int byz_near_pairs_apply_dev(byz_ctx* ctx, const double* sq_dev, int64_t n_rows, float* dist, void* stream) {
+    BYZ_TRY(enter(ctx));
+    BYZ_REQUIRE(sq_dev && dist && n_rows > 0 && ctx->near_pair_capacity > 0, "near_pairs_apply: bad arguments");
+    return launch_near_pair_apply(ctx, sq_dev, n_rows, dist, as_stream(stream));
+}
+
+int byz_ctx_check(byz_ctx* ctx, void* stream) {
+    BYZ_TRY(enter(ctx));
+    int32_t words[32];
+    return read_small(ctx, words, as_stream(stream));
+}
+
+int byz_bulyan_rescored(const byz_ctx* ctx, int64_t* rows_host) {
+    if (!ctx || !rows_host) {
+        set_error("bulyan_rescored: null argument");
+        return BYZ_E_INVALID;
+    }
+    *rows_host = ctx->bulyan_rescored;
+    return BYZ_OK;
 }
 
 int byz_pairwise_distances_dev(byz_ctx* ctx, const float* G, int64_t n_rows, int64_t n_cols, int64_t ld,
@@ -252,20 +344,23 @@ int byz_pairwise_distances_dev(byz_ctx* ctx, const float* G, int64_t n_rows, int
     BYZ_REQUIRE(dist, "pairwise_distances: null output");
     BYZ_TRY(ctx->gram.ensure(static_cast<size_t>(n_rows) * n_rows * sizeof(double)));
     BYZ_TRY(launch_gram(ctx, G, n_rows, n_cols, ld, ctx->gram.as<double>(), as_stream(stream)));
-    return launch_distances_from_gram(ctx, ctx->gram.as<double>(), n_rows, dist, as_stream(stream));
+    return launch_distances_from_gram(ctx, ctx->gram.as<double>(), n_rows, dist, as_stream(stream), G, n_cols, ld);
 }
 
 int byz_krum_select_dev(byz_ctx* ctx, const float* dist, int64_t n_rows, int64_t users_count,
                         int64_t corrupted_count, int32_t* index_host, float* scores_dev, void* stream) {
     BYZ_TRY(enter(ctx));
     BYZ_REQUIRE(dist && n_rows > 0, "krum_select: bad arguments");
-    BYZ_TRY(ctx->small.ensure(256));
     hipStream_t s = as_stream(stream);
     BYZ_TRY(krum_select(ctx, dist, n_rows, users_count, corrupted_count, ctx->small.as<int32_t>(), s));
     if (scores_dev)
         BYZ_HIP(hipMemcpyAsync(scores_dev, ctx->scores.ptr, static_cast<size_t>(n_rows) * sizeof(float),
                                hipMemcpyDeviceToDevice, s));
-    if (index_host) BYZ_TRY(read_i32(ctx, ctx->small.as<int32_t>(), index_host, 1, s));
+    if (index_host) {
+        int32_t words[32];
+        BYZ_TRY(read_small(ctx, words, s));
+        *index_host = words[0];
+    }
     return BYZ_OK;
 }
 
@@ -281,11 +376,15 @@ int byz_krum_dev(byz_ctx* ctx, const float* G, int64_t n_rows, int64_t n_cols, i
     hipStream_t s = as_stream(stream);
     BYZ_TRY(ensure_distance_workspaces(ctx, n_rows));
     BYZ_TRY(launch_gram(ctx, G, n_rows, n_cols, ld, ctx->gram.as<double>(), s));
-    BYZ_TRY(launch_distances_from_gram(ctx, ctx->gram.as<double>(), n_rows, ctx->dist.as<float>(), s));
+    BYZ_TRY(launch_distances_from_gram(ctx, ctx->gram.as<double>(), n_rows, ctx->dist.as<float>(), s, G, n_cols, ld));
     int32_t* winner = ctx->small.as<int32_t>();
     BYZ_TRY(krum_select(ctx, ctx->dist.as<float>(), n_rows, users_count, corrupted_count, winner, s));
     if (out_row) BYZ_TRY(launch_copy_row(ctx, G, ld, n_rows, n_cols, winner, out_row, s));
-    if (index_host) BYZ_TRY(read_i32(ctx, winner, index_host, 1, s));
+    if (index_host) {
+        int32_t words[32];
+        BYZ_TRY(read_small(ctx, words, s));
+        *index_host = words[0];
+    }
     return BYZ_OK;
 }
 
@@ -320,7 +419,7 @@ int byz_bulyan_dev(byz_ctx* ctx, const float* G, int64_t n_rows, int64_t n_cols,
     BYZ_TRY(ensure_distance_workspaces(ctx, n_rows));
     BYZ_TRY(ctx->selection.ensure(static_cast<size_t>(n_rows) * sizeof(int32_t)));
     BYZ_TRY(launch_gram(ctx, G, n_rows, n_cols, ld, ctx->gram.as<double>(), s));
-    BYZ_TRY(launch_distances_from_gram(ctx, ctx->gram.as<double>(), n_rows, ctx->dist.as<float>(), s));
+    BYZ_TRY(launch_distances_from_gram(ctx, ctx->gram.as<double>(), n_rows, ctx->dist.as<float>(), s, G, n_cols, ld));
     int32_t* sel = ctx->selection.as<int32_t>();
     BYZ_TRY(bulyan_select(ctx, ctx->dist.as<float>(), n_rows, users_count, corrupted_count, sel, s));
     if (selection_out)

@@ -105,8 +105,14 @@ struct byz_ctx {
     byz::Buffer gram_compact;    // dedup: Gram of the unique rows
     std::vector<int32_t> tile_order_host;
     int64_t tile_order_T = -1;
-    const double* last_gram = nullptr;   // output of the last launch_gram and whether it used the exact arithmetic
-    bool last_gram_exact = false;
+    int64_t tile_order_share = 1 * 65536 + 0;   // share_count * 65536 + share_index the list was built for
+    byz::Buffer tile_owned;      // one byte per lower-triangle tile: 1 = in this launch's share
+    int64_t row_map_rows = 0;    // dedup: row count the row_map currently describes (0: none)
+    byz::Buffer gram_rep;        // first row with bitwise equal Gram entries (candidate identical row), per row
+    byz::Buffer near_pairs;      // near-duplicate pairs (int2) whose distance is re-evaluated on the difference
+    byz::Buffer near_sq;         // their squared distances (fp64)
+    byz::Buffer near_partial;    // per (pair, column chunk) partial sums
+    int64_t near_pair_capacity = 0;
     byz::Buffer dist;            // n x n fp32 distances (when the caller does not pass one)
     byz::Buffer colstat_partials;  // row-split partial column sums
     byz::Buffer sorted_idx;      // n x n uint16: column index at every ascending rank
@@ -114,6 +120,9 @@ struct byz_ctx {
     byz::Buffer row_total;       // n fp64: sum of a row's finite distances
     byz::Buffer row_top;         // n fp64: sum of a row's largest `drop` distances
     byz::Buffer scores;          // n fp32 Krum scores
+    byz::Buffer twin_class;      // 2n int32: twin class of every row (scratch, then final)
+    byz::Buffer xchg;            // Bulyan grid loop: tagged 8-byte granules the workgroups exchange
+    int64_t bulyan_rescored = 0; // rows the last Bulyan loop re-scored in the reference's fp32 arithmetic
     byz::Buffer selection;       // theta int32
     byz::Buffer small;           // misc device scalars (winner index, status words)
     byz::Buffer stage_in;        // device copy of a host matrix
@@ -127,6 +136,14 @@ struct byz_ctx {
 namespace byz {
 
 inline hipStream_t as_stream(void* s) { return static_cast<hipStream_t>(s); }
+
+// ctx->small (256 bytes, allocated and zeroed with the context) holds the device-side scalars:
+//   [0] Krum winner   [8] Bulyan loop status   [9] rows the Bulyan loop re-scored
+//   [16] sticky device status (bit 0: a Gram chunk lost its ticket, bit 1: near-duplicate pair list overflowed,
+//        bit 2: two rows with bitwise equal Gram entries turned out to differ)
+//   [17] number of near-duplicate pairs listed by the last distance kernel
+inline int32_t* device_status_word(byz_ctx* ctx) { return ctx->small.as<int32_t>() + 16; }
+inline int32_t* near_pair_count_word(byz_ctx* ctx) { return ctx->small.as<int32_t>() + 17; }
 
 // Brackets one kernel launch with events when timing is on (bench.py's roofline leg).
 struct KernelTimer {
@@ -192,19 +209,25 @@ int launch_assemble_columns(byz_ctx* ctx, float* G, int64_t n_rows, int64_t n_co
 
 int launch_gram(byz_ctx* ctx, const float* G, int64_t n_rows, int64_t n_cols, int64_t ld, double* gram,
                 hipStream_t stream);
+int launch_gram_share(byz_ctx* ctx, const float* G, int64_t n_rows, int64_t n_cols, int64_t ld, const int32_t* row_index,
+                      int share_count, int share_index, double* gram, hipStream_t stream);
 // dedup.hip: identical rows found before the Gram
 int find_unique_rows(byz_ctx* ctx, const float* G, int64_t n_rows, int64_t n_cols, int64_t ld, hipStream_t stream,
                      int64_t* n_unique_host);
 int launch_gram_expand(byz_ctx* ctx, const double* compact, int64_t n_unique, int64_t n_rows, double* gram,
                        hipStream_t stream);
-int launch_distances_from_gram(byz_ctx* ctx, const double* gram, int64_t n, float* dist,
-                               hipStream_t stream);
+int launch_distances_from_gram(byz_ctx* ctx, const double* gram, int64_t n, float* dist, hipStream_t stream,
+                               const float* G, int64_t n_cols, int64_t ld);
+int launch_near_pair_sqdist(byz_ctx* ctx, const float* G, int64_t n_cols, int64_t ld, const int32_t* row_index,
+                            double* sq_dev, hipStream_t stream);
+int launch_near_pair_apply(byz_ctx* ctx, const double* sq_dev, int64_t n, float* dist, hipStream_t stream);
 
 int launch_row_sort(byz_ctx* ctx, const float* dist, int64_t n, int64_t prefix_len, int64_t drop_count,
                     bool want_tables, hipStream_t stream);
 int launch_krum_argmin(byz_ctx* ctx, int64_t n, int32_t* winner_dev, hipStream_t stream);
 int launch_bulyan_loop(byz_ctx* ctx, const float* dist, int64_t n, int64_t theta, int64_t drop_count,
-                       int32_t* selection_dev, int32_t* status_dev, hipStream_t stream);
+                       int64_t users_count, int64_t corrupted, int32_t* selection_dev, int32_t* status_dev,
+                       hipStream_t stream);
 
 int launch_trimmed_mean(byz_ctx* ctx, const float* G, int64_t n_rows, int64_t n_cols, int64_t ld,
                         const int32_t* row_index, int64_t keep, float* out, hipStream_t stream);

@@ -48,6 +48,9 @@ constexpr int THREADS = 256;
 constexpr int kFlushK = 2048;        // longest fp32 accumulation chain
 constexpr int kLevel1 = 8;           // level-0 chains per level-1 fp32 sum
 constexpr int TILE_FLOATS = TM * LDS_STRIDE;
+constexpr int kStatusLostTicket = 1;     // bits of the context's sticky device status word
+constexpr int kStatusPairOverflow = 2;
+constexpr int kStatusFalseTwin = 4;
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -106,10 +109,11 @@ template <typename PartialT, bool DMA, bool SPLIT>
 __global__ __launch_bounds__(THREADS, 2) void gram_tile_kernel(const float* __restrict__ G, int64_t n_rows,
                                                                int64_t n_cols, int64_t ld,
                                                                int64_t stages_per_split,
-                                                               PartialT* __restrict__ partial, int n_tiles,
+                                                               PartialT* __restrict__ partial, int n_tiles, int slab_tiles,
                                                                const int2* __restrict__ tile_order, int per_xcd, int n_splits,
                                                                int* __restrict__ tickets, int round_size,
-                                                               const int32_t* __restrict__ row_index) {
+                                                               const int32_t* __restrict__ row_index,
+                                                               int32_t* __restrict__ device_status) {
     __shared__ __attribute__((aligned(16))) float lds[2 * 2 * TILE_FLOATS];  // [2 buffers][A | B][TM][row]
 
     // Workgroup -> (tile, K split).  Workgroups are dealt to the 8 XCDs round-robin (observed; only speed
@@ -132,7 +136,7 @@ __global__ __launch_bounds__(THREADS, 2) void gram_tile_kernel(const float* __re
             // starts together and its members walk K in step: that is what makes them hit each other's operand
             // lines in the XCD's L2 (staggered starts left the hit rate at 28%).  Only scheduling depends on this:
             // earlier workgroups never wait for later ones, and the wait is bounded.
-            int* done = tickets + n_tiles + xcd;
+            int* done = tickets + slab_tiles + xcd;
             const int round = round_size > 0 ? seq / round_size : 0;   // 0 disables the gate
             if (round > 0 && threadIdx.x == 0) {
                 unsigned spins = 0;
@@ -274,7 +278,7 @@ __global__ __launch_bounds__(THREADS, 2) void gram_tile_kernel(const float* __re
     //   share their 8 + 8 operand row blocks in its L2: with split-K over 322,000 columns (N = 4000, D = 1e7) they
     //   drifted apart and the L2 hit rate was 5% (5.0 TB of fabric reads for a 160 GB matrix).
     const bool chunked = tickets != nullptr;
-    PartialT* out = partial + (chunked ? static_cast<int64_t>(tile) : static_cast<int64_t>(split) * n_tiles + tile) * (TM * TM);
+    PartialT* out = partial + (chunked ? static_cast<int64_t>(tile) : static_cast<int64_t>(split) * slab_tiles + tile) * (TM * TM);
     int level1 = 0;          // level-0 chains summed into acc2 since the last slab update
     bool slab_live = false;  // the slab already holds a partial sum
 
@@ -415,19 +419,29 @@ __global__ __launch_bounds__(THREADS, 2) void gram_tile_kernel(const float* __re
             // wait for the previous chunk of this tile (dispatched earlier, so it is running or done), then
             // read-modify-write the slab, then pass the ticket on.  Release/acquire at agent scope: the slab lines
             // may sit in another CU's L1 or be dirty in L2 (MI355X_MICROARCH.md, inter-workgroup visibility).
+            bool lost = false;
             if (split > 0) {
                 if (tid == 0) {
                     unsigned spins = 0;
                     while (__hip_atomic_load(tickets + tile, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != split) {
                         __builtin_amdgcn_s_sleep(8);
-                        if (++spins > (1u << 26)) break;   // bounded: a lost ticket must not hang the device
+                        if (++spins > (1u << 26)) {   // bounded: a lost ticket must not hang the device ...
+                            lost = true;
+                            break;
+                        }
                     }
                     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
                 }
-                __syncthreads();
+                // ... and must not be papered over either: without the ticket the slab is not ours to update.  The
+                // launch is marked failed (the host turns the word into BYZ_E_HIP) and this chunk is dropped.
+                lost = __syncthreads_or(lost ? 1 : 0) != 0;
                 slab_live = true;
             }
-            to_slab(true);
+            if (lost) {
+                if (tid == 0) atomicOr(device_status, kStatusLostTicket);
+            } else {
+                to_slab(true);
+            }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
             if (tid == 0) {
@@ -435,7 +449,7 @@ __global__ __launch_bounds__(THREADS, 2) void gram_tile_kernel(const float* __re
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __hip_atomic_store(tickets + tile, split + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 if (per_xcd > 0)
-                    __hip_atomic_fetch_add(tickets + n_tiles + (blockIdx.x & 7), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_fetch_add(tickets + slab_tiles + (blockIdx.x & 7), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         } else {
             to_slab(true);
@@ -460,7 +474,8 @@ __global__ __launch_bounds__(THREADS, 2) void gram_tile_kernel(const float* __re
 // The order of the fp64 additions is fixed either way: the result is deterministic.
 template <typename PartialT, int Q>
 __global__ __launch_bounds__(256) void gram_reduce_kernel(const PartialT* __restrict__ partial, int n_tiles,
-                                                          int splits, int64_t n, double* __restrict__ gram) {
+                                                          int splits, int64_t n, double* __restrict__ gram,
+                                                          const uint8_t* __restrict__ tile_owned) {
     __shared__ double part[Q == 1 ? 1 : 256];
     const int jl = threadIdx.x & 63, q = threadIdx.x >> 6;
     const int64_t j = static_cast<int64_t>(blockIdx.x) * 64 + jl;
@@ -475,7 +490,9 @@ __global__ __launch_bounds__(256) void gram_reduce_kernel(const PartialT* __rest
         const int tile = ti * (ti + 1) / 2 + tj;
         const int64_t off = static_cast<int64_t>(tile) * (TM * TM) + (hi % TM) * TM + (lo % TM);
         const int64_t slab = static_cast<int64_t>(n_tiles) * (TM * TM);
-        if (Q == 1) {
+        if (tile_owned != nullptr && !tile_owned[tile]) {
+            // a tile of another rank's share: this rank contributes zero to the all-reduced Gram
+        } else if (Q == 1) {
             for (int sp = 0; sp < splits; ++sp) s += static_cast<double>(partial[sp * slab + off]);
         } else {
             double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
@@ -503,8 +520,46 @@ __global__ __launch_bounds__(256) void gram_reduce_kernel(const PartialT* __rest
     }
 }
 
+// d_ij from the Gram, and the list of pairs the Gram identity cannot resolve.
+//
+// c_ii + c_jj - 2 c_ij loses relative accuracy as the rows approach each other: the Gram entries carry ~1e-7 of
+// (c_ii + c_jj), so d^2 < eps (c_ii + c_jj) leaves d with a relative error of ~1e-7 / (2 eps).  The reference never has
+// that problem, it takes the norm of the difference (defences.py:20).  So every pair i > j below the threshold
+// (eps = 1/16: cosine similarity above 0.94) is listed and re-evaluated on the difference itself
+// (near_pair_partial_kernel).  After that step a distance is 0 only for rows whose fp32 difference is 0 in every column.
+//
+// Identical rows would flood that list (the attack makes f of the N clients one vector: f^2 / 2 pairs), so they are
+// folded first.  Bitwise identical rows have bitwise identical Gram entries c_ii == c_jj == c_ij (same operands, same
+// order, in either arithmetic and through an all-reduce), so rep[i] = the first j < i with that property nominates i's
+// representative; ONE pair (i, rep[i]) per folded row goes on the list as the proof, only representatives are paired
+// with each other, and the folded rows take their representative's distances afterwards (canonicalise_duplicates).
+// A nomination the proof refutes (three doubles equal by coincidence) is reported through the status word.
+constexpr double kNearEps = 1.0 / 16.0;
+
+__global__ __launch_bounds__(256) void gram_rep_kernel(const double* __restrict__ gram, int64_t n,
+                                                       int32_t* __restrict__ rep) {
+    const int64_t i = static_cast<int64_t>(blockIdx.x) * 4 + (threadIdx.x >> 6);   // one wave per row
+    const int lane = threadIdx.x & 63;
+    if (i >= n) return;
+    const unsigned long long* bits = reinterpret_cast<const unsigned long long*>(gram);
+    const unsigned long long cii = bits[i * n + i];
+    int best = static_cast<int>(i);
+    for (int64_t j0 = 0; j0 < i; j0 += 64) {
+        const int64_t j = j0 + lane;
+        const bool hit = j < i && bits[i * n + j] == cii && bits[j * n + j] == cii;
+        const unsigned long long m = __ballot(hit);
+        if (m) {
+            best = static_cast<int>(j0) + __builtin_ctzll(m);
+            break;
+        }
+    }
+    if (lane == 0) rep[i] = best;
+}
+
 __global__ __launch_bounds__(256) void distance_kernel(const double* __restrict__ gram, int64_t n,
-                                                       float* __restrict__ dist) {
+                                                       float* __restrict__ dist, const int32_t* __restrict__ rep,
+                                                       int2* __restrict__ pairs, int32_t* __restrict__ pair_count,
+                                                       int pair_capacity) {
     const int64_t j = static_cast<int64_t>(blockIdx.x) * 64 + (threadIdx.x & 63);
     const int64_t i = static_cast<int64_t>(blockIdx.y) * 4 + (threadIdx.x >> 6);
     if (i >= n || j >= n) return;
@@ -512,11 +567,105 @@ __global__ __launch_bounds__(256) void distance_kernel(const double* __restrict_
     if (i == j) {
         d = __builtin_inff();  // the reference keeps no self-distance (defences.py:18-20)
     } else {
-        const double d2 = gram[i * n + i] + gram[j * n + j] - 2.0 * gram[i * n + j];
+        const double cii = gram[i * n + i], cjj = gram[j * n + j];
+        const double d2 = cii + cjj - 2.0 * gram[i * n + j];
         // rounding can leave a tiny negative value for near-identical rows; NaN (poisoned input) must stay NaN
         d = static_cast<float>(sqrt(d2 < 0.0 ? 0.0 : d2));
+        if (i > j && d2 < kNearEps * (cii + cjj)) {
+            const int ri = rep[i], rj = rep[j];
+            // representatives pair with each other; a folded row only with its representative (the proof of identity)
+            const bool listed = (ri == i && rj == j) || ri == j;
+            if (listed) {
+                const int slot = atomicAdd(pair_count, 1);
+                if (slot < pair_capacity) pairs[slot] = make_int2(static_cast<int>(i), static_cast<int>(j));
+            }
+        }
     }
     dist[i * n + j] = d;
+}
+
+// sum over a column chunk of (g_i - g_j)^2: the difference in fp32 as the reference forms it, squares and sums in
+// fp64.  Work item w = pair * n_chunks + chunk, persistent grid, one partial per item (fixed order: reproducible).
+constexpr int kPairChunk = 32768;
+__global__ __launch_bounds__(256) void near_pair_partial_kernel(const float* __restrict__ G, int64_t n_cols, int64_t ld,
+                                                                const int32_t* __restrict__ row_index,
+                                                                const int2* __restrict__ pairs,
+                                                                const int32_t* __restrict__ pair_count, int pair_capacity,
+                                                                int n_chunks, int64_t item_capacity,
+                                                                double* __restrict__ partial, int32_t* __restrict__ status) {
+    __shared__ double red[256];
+    int count = *pair_count;
+    if (count > pair_capacity || static_cast<int64_t>(count) * n_chunks > item_capacity) {
+        if (blockIdx.x == 0 && threadIdx.x == 0) atomicOr(status, kStatusPairOverflow);
+        return;   // the caller gets an error, not a half-patched matrix
+    }
+    const int64_t items = static_cast<int64_t>(count) * n_chunks;
+    const bool vec = (ld % 4 == 0) && (reinterpret_cast<uintptr_t>(G) % 16 == 0);
+    for (int64_t w = blockIdx.x; w < items; w += gridDim.x) {
+        const int2 pr = pairs[w / n_chunks];
+        const int64_t k0 = (w % n_chunks) * kPairChunk;
+        const int64_t k1 = k0 + kPairChunk < n_cols ? k0 + kPairChunk : n_cols;
+        const float* a = G + static_cast<int64_t>(row_index ? row_index[pr.x] : pr.x) * ld;
+        const float* b = G + static_cast<int64_t>(row_index ? row_index[pr.y] : pr.y) * ld;
+        double acc = 0.0;
+        if (vec) {
+            const int64_t kv = k0 + ((k1 - k0) & ~static_cast<int64_t>(3));
+            for (int64_t k = k0 + 4 * threadIdx.x; k < kv; k += 4 * 256) {
+                const f32x4 x = *reinterpret_cast<const f32x4*>(a + k), y = *reinterpret_cast<const f32x4*>(b + k);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const double df = static_cast<double>(__fsub_rn(x[e], y[e]));
+                    acc = fma(df, df, acc);
+                }
+            }
+            for (int64_t k = kv + threadIdx.x; k < k1; k += 256) {
+                const double df = static_cast<double>(__fsub_rn(a[k], b[k]));
+                acc = fma(df, df, acc);
+            }
+        } else {
+            for (int64_t k = k0 + threadIdx.x; k < k1; k += 256) {
+                const double df = static_cast<double>(__fsub_rn(a[k], b[k]));
+                acc = fma(df, df, acc);
+            }
+        }
+        red[threadIdx.x] = acc;
+        __syncthreads();
+        for (int st = 128; st > 0; st >>= 1) {
+            if (threadIdx.x < st) red[threadIdx.x] += red[threadIdx.x + st];
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) partial[w] = red[0];
+        __syncthreads();
+    }
+}
+
+// sq[p] = sum of the pair's chunk partials, in chunk order
+__global__ __launch_bounds__(256) void near_pair_sum_kernel(const double* __restrict__ partial,
+                                                            const int32_t* __restrict__ pair_count, int pair_capacity,
+                                                            int n_chunks, int64_t item_capacity, double* __restrict__ sq) {
+    const int count = *pair_count;
+    if (count > pair_capacity || static_cast<int64_t>(count) * n_chunks > item_capacity) return;
+    for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < count; p += gridDim.x * blockDim.x) {
+        double s = 0.0;
+        for (int c = 0; c < n_chunks; ++c) s += partial[static_cast<int64_t>(p) * n_chunks + c];
+        sq[p] = s;
+    }
+}
+
+__global__ __launch_bounds__(256) void near_pair_apply_kernel(const double* __restrict__ sq, const int2* __restrict__ pairs,
+                                                              const int32_t* __restrict__ pair_count, int pair_capacity,
+                                                              int64_t n, float* __restrict__ dist,
+                                                              const int32_t* __restrict__ rep, int32_t* __restrict__ status) {
+    const int count = *pair_count;
+    if (count > pair_capacity) return;
+    for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < count; p += gridDim.x * blockDim.x) {
+        const int2 pr = pairs[p];
+        const float d = static_cast<float>(sqrt(sq[p]));
+        // a row folded into pr.y whose difference from it is not zero after all: its other pairs were never listed
+        if (rep[pr.x] == pr.y && sq[p] != 0.0) atomicOr(status, kStatusFalseTwin);
+        dist[static_cast<int64_t>(pr.x) * n + pr.y] = d;
+        dist[static_cast<int64_t>(pr.y) * n + pr.x] = d;
+    }
 }
 
 // Identical rows (every malicious client submits the same vector, malicious.py:26-27) must keep bitwise identical
@@ -584,15 +733,27 @@ int env_int(const char* name, int fallback) {
 }  // namespace
 
 // Gram of the n_rows logical rows G[row_index[r]] (row_index == nullptr: the rows themselves)
+// share_count / share_index: this launch computes only every share_count-th tile of the (XCD-friendly) tile list,
+// starting with share_index, and writes zeros for the others: W ranks that hold the same rows each take one share and
+// the sum of their outputs is the Gram (the client-sharded multi-GPU path, sharded.py).
 static int launch_gram_rows(byz_ctx* ctx, const float* G, int64_t n_rows, int64_t n_cols, int64_t ld,
-                            const int32_t* row_index, double* gram, hipStream_t stream) {
+                            const int32_t* row_index, double* gram, hipStream_t stream, int share_count = 1,
+                            int share_index = 0) {
     BYZ_REQUIRE(G && gram && n_rows > 0 && n_cols > 0 && ld >= n_cols, "gram: bad shape %lld x %lld ld %lld",
                 (long long)n_rows, (long long)n_cols, (long long)ld);
+    BYZ_REQUIRE(share_count >= 1 && share_index >= 0 && share_index < share_count, "gram: bad share %d of %d",
+                share_index, share_count);
     const int64_t T = ceil_div(n_rows, TM);
-    const int64_t n_tiles = T * (T + 1) / 2;
-    if (n_tiles > 0x7fffffff) {
+    const int64_t n_tiles_all = T * (T + 1) / 2;
+    if (n_tiles_all > 0x7fffffff) {
         set_error("gram: too many tiles");
         return BYZ_E_UNSUPPORTED;
+    }
+    // tiles of this share: list positions share_index, share_index + share_count, ...
+    const int64_t n_tiles = (n_tiles_all - share_index + share_count - 1) / share_count;
+    if (n_tiles <= 0) {   // more ranks than tiles: nothing to compute here
+        BYZ_HIP(hipMemsetAsync(gram, 0, static_cast<size_t>(n_rows) * n_rows * sizeof(double), stream));
+        return BYZ_OK;
     }
     const int64_t stages = ceil_div(n_cols, BK);
     // split-K.  Two workgroups fit a CU (LDS), so the chip runs `slots` workgroups at a time; the grid is
@@ -641,8 +802,6 @@ static int launch_gram_rows(byz_ctx* ctx, const float* G, int64_t n_rows, int64_
     const std::string mode_s = mode_env ? mode_env : (n_tiles >= 4 ? "split" : "exact");
     const bool dma = (ld % 4 == 0) && (reinterpret_cast<uintptr_t>(G) % 16 == 0) && env_int("BYZ_GRAM_NO_DMA", 0) == 0;
     const bool split_mode = dma && mode_s == "split";
-    ctx->last_gram = gram;
-    ctx->last_gram_exact = !split_mode;
     // chunked schedule (see the kernel): many tiles and a long K
     const int64_t chunk_stages = env_int("BYZ_GRAM_CHUNK_COLS", 8192) / BK;
     const bool chunked = n_tiles >= 256 && stages > 2 * chunk_stages && env_int("BYZ_GRAM_NO_CHUNKS", 0) == 0 &&
@@ -653,30 +812,38 @@ static int launch_gram_rows(byz_ctx* ctx, const float* G, int64_t n_rows, int64_
     // the fp32 slab format is only for K ranges that fit ONE level-0 chain
     const bool wide = chunked || stages_per_split * BK > (split_mode ? 256 : kFlushK);
     const size_t slab = static_cast<size_t>(TM) * TM * (wide ? sizeof(double) : sizeof(float));
-    BYZ_TRY(ctx->gram_partials.ensure(static_cast<size_t>(chunked ? 1 : splits) * n_tiles * slab));
+    BYZ_TRY(ctx->gram_partials.ensure(static_cast<size_t>(chunked ? 1 : splits) * n_tiles_all * slab));
     int* tickets = nullptr;
     if (chunked) {
-        BYZ_TRY(ctx->gram_tickets.ensure(static_cast<size_t>(n_tiles + 8) * sizeof(int)));   // + one finished-count per XCD
+        BYZ_TRY(ctx->gram_tickets.ensure(static_cast<size_t>(n_tiles_all + 8) * sizeof(int)));   // + one finished-count per XCD
         tickets = ctx->gram_tickets.as<int>();
-        BYZ_HIP(hipMemsetAsync(tickets, 0, static_cast<size_t>(n_tiles + 8) * sizeof(int), stream));
+        BYZ_HIP(hipMemsetAsync(tickets, 0, static_cast<size_t>(n_tiles_all + 8) * sizeof(int), stream));
     }
-    // tile list in 8 x 8 super-block order (see the kernel); rebuilt only when the tile count changes
-    if (ctx->tile_order_T != T) {
+    // tile list in 8 x 8 super-block order (see the kernel); rebuilt only when the tile count or the share changes
+    if (ctx->tile_order_T != T || ctx->tile_order_share != share_count * 65536 + share_index) {
         ctx->tile_order_host.clear();
+        std::vector<uint8_t> owned(static_cast<size_t>(n_tiles_all), 0);
         const int64_t S = ceil_div(T, 8);
+        int64_t position = 0;
         for (int64_t I = 0; I < S; ++I)
             for (int64_t J = 0; J <= I; ++J)
                 for (int64_t ti = I * 8; ti < I * 8 + 8 && ti < T; ++ti)
                     for (int64_t tj = J * 8; tj < J * 8 + 8 && tj <= ti; ++tj) {
+                        if (position++ % share_count != share_index) continue;
                         ctx->tile_order_host.push_back(static_cast<int32_t>(ti));
                         ctx->tile_order_host.push_back(static_cast<int32_t>(tj));
+                        owned[static_cast<size_t>(ti * (ti + 1) / 2 + tj)] = 1;
                     }
         BYZ_TRY(ctx->tile_order.ensure(ctx->tile_order_host.size() * sizeof(int32_t)));
+        BYZ_TRY(ctx->tile_owned.ensure(owned.size()));
         BYZ_HIP(hipMemcpyAsync(ctx->tile_order.ptr, ctx->tile_order_host.data(),
                                ctx->tile_order_host.size() * sizeof(int32_t), hipMemcpyHostToDevice, stream));
-        BYZ_HIP(hipStreamSynchronize(stream));   // the host vector is pageable; once per matrix height
+        BYZ_HIP(hipMemcpyAsync(ctx->tile_owned.ptr, owned.data(), owned.size(), hipMemcpyHostToDevice, stream));
+        BYZ_HIP(hipStreamSynchronize(stream));   // the host vectors are pageable; once per matrix height and share
         ctx->tile_order_T = T;
+        ctx->tile_order_share = share_count * 65536 + share_index;
     }
+    const uint8_t* tile_owned = share_count > 1 ? ctx->tile_owned.as<uint8_t>() : nullptr;
     // XCD-partitioned order only when every XCD gets enough tiles for its shares to be even (<= 3% apart)
     const bool partitioned = n_tiles >= 256;
     const int64_t per_xcd = partitioned ? ceil_div(n_tiles, 8) : 0;
@@ -692,8 +859,10 @@ static int launch_gram_rows(byz_ctx* ctx, const float* G, int64_t n_rows, int64_
         const unsigned grid = static_cast<unsigned>(grid_wgs);   // (dma: global_load_lds moves 16 bytes per lane, so every row segment must be 16-byte aligned)
 #define BYZ_GRAM(T, D, S)                                                                                     \
     gram_tile_kernel<T, D, S><<<grid, THREADS, 0, stream>>>(G, n_rows, n_cols, ld, stages_per_split,           \
-                                                            ctx->gram_partials.as<T>(), (int)n_tiles, order,    \
-                                                            (int)per_xcd, (int)splits, tickets, round_size, row_index)
+                                                            ctx->gram_partials.as<T>(), (int)n_tiles,           \
+                                                            (int)n_tiles_all, order,                             \
+                                                            (int)per_xcd, (int)splits, tickets, round_size, row_index,   \
+                                                            device_status_word(ctx))
         if (wide) {
             if (split_mode) BYZ_GRAM(double, true, true);
             else if (dma) BYZ_GRAM(double, true, false);
@@ -711,7 +880,7 @@ static int launch_gram_rows(byz_ctx* ctx, const float* G, int64_t n_rows, int64_
         // four threads per entry only when entries alone cannot fill the chip (the 128 x 128 of one tile)
         const bool many = !chunked && splits >= 16 && n_rows * n_rows <= (1 << 18);
         dim3 grid(static_cast<unsigned>(ceil_div(n_rows, 64)), static_cast<unsigned>(many ? n_rows : ceil_div(n_rows, 4)));
-#define BYZ_REDUCE(T, Q) gram_reduce_kernel<T, Q><<<grid, 256, 0, stream>>>(ctx->gram_partials.as<T>(), (int)n_tiles, (int)(chunked ? 1 : splits), n_rows, gram)
+#define BYZ_REDUCE(T, Q) gram_reduce_kernel<T, Q><<<grid, 256, 0, stream>>>(ctx->gram_partials.as<T>(), (int)n_tiles_all, (int)(chunked ? 1 : splits), n_rows, gram, tile_owned)
         if (wide) {
             if (many) BYZ_REDUCE(double, 4); else BYZ_REDUCE(double, 1);
         } else {
@@ -727,33 +896,33 @@ int launch_gram(byz_ctx* ctx, const float* G, int64_t n_rows, int64_t n_cols, in
                 hipStream_t stream) {
     BYZ_REQUIRE(G && gram && n_rows > 0 && n_cols > 0 && ld >= n_cols, "gram: bad shape %lld x %lld ld %lld",
                 (long long)n_rows, (long long)n_cols, (long long)ld);
+    ctx->row_map_rows = 0;
     // Identical rows first (dedup.hip): worth a look once the Gram is compute bound and a 4-byte read-back does not
     // show (N >= 512); used when it removes at least one row of tiles.
     if (n_rows >= 512 && n_rows <= 16384 && env_int("BYZ_GRAM_DEDUP", 1) != 0) {
         int64_t n_unique = n_rows;
         BYZ_TRY(find_unique_rows(ctx, G, n_rows, n_cols, ld, stream, &n_unique));
+        ctx->row_map_rows = n_rows;   // row_map[i] == row_map[j]  <=>  rows i and j are bitwise identical
         if (ceil_div(n_unique, TM) < ceil_div(n_rows, TM)) {
             BYZ_TRY(ctx->gram_compact.ensure(static_cast<size_t>(n_unique) * n_unique * sizeof(double)));
             double* compact = ctx->gram_compact.as<double>();
             BYZ_TRY(launch_gram_rows(ctx, G, n_unique, n_cols, ld, ctx->unique_rows.as<int32_t>(), compact, stream));
             BYZ_TRY(launch_gram_expand(ctx, compact, n_unique, n_rows, gram, stream));
-            ctx->last_gram = gram;
             return BYZ_OK;
         }
     }
     return launch_gram_rows(ctx, G, n_rows, n_cols, ld, nullptr, gram, stream);
 }
 
-int launch_distances_from_gram(byz_ctx* ctx, const double* gram, int64_t n, float* dist, hipStream_t stream) {
-    BYZ_REQUIRE(gram && dist && n > 0, "distances: bad arguments");
-    KernelTimer t(ctx, BYZ_K_DISTANCES, stream);
-    dim3 grid(static_cast<unsigned>(ceil_div(n, 64)), static_cast<unsigned>(ceil_div(n, 4)));
-    distance_kernel<<<grid, 256, 0, stream>>>(gram, n, dist);
-    BYZ_TRY(check_launch("distance_kernel"));
-    // exact ties for identical rows, whatever arithmetic produced the Gram (see duplicate_rep_kernel).  The exact
-    // arithmetic needs no help: identical rows meet identical operands in an identical order, products commute, so
-    // their Gram rows are bitwise equal already (three launches saved where launches are the cost: N <= 256).
-    if (gram == ctx->last_gram && ctx->last_gram_exact) return BYZ_OK;
+int launch_gram_share(byz_ctx* ctx, const float* G, int64_t n_rows, int64_t n_cols, int64_t ld, const int32_t* row_index,
+                      int share_count, int share_index, double* gram, hipStream_t stream) {
+    ctx->row_map_rows = 0;
+    return launch_gram_rows(ctx, G, n_rows, n_cols, ld, row_index, gram, stream, share_count, share_index);
+}
+
+// Identical rows must end up with bitwise identical distance rows, because the reference resolves their exactly tied
+// scores by visit order: rep[i] = the smallest j with d_ij == 0, every member of a group takes the group's first row.
+static int canonicalise_duplicates(byz_ctx* ctx, int64_t n, float* dist, hipStream_t stream) {
     BYZ_TRY(ctx->dup_rep.ensure(static_cast<size_t>(n + 1) * sizeof(int32_t)));
     int32_t* rep = ctx->dup_rep.as<int32_t>();
     BYZ_HIP(hipMemsetAsync(rep + n, 0, sizeof(int32_t), stream));
@@ -761,8 +930,80 @@ int launch_distances_from_gram(byz_ctx* ctx, const double* gram, int64_t n, floa
     BYZ_TRY(check_launch("duplicate_rep_kernel"));
     duplicate_compress_kernel<<<1, 1024, 0, stream>>>(n, rep, rep + n);
     BYZ_TRY(check_launch("duplicate_compress_kernel"));
+    const dim3 grid(static_cast<unsigned>(ceil_div(n, 64)), static_cast<unsigned>(ceil_div(n, 4)));
     duplicate_copy_kernel<<<grid, 256, 0, stream>>>(dist, n, rep, rep + n);
     return check_launch("duplicate_copy_kernel");
+}
+
+static int near_pair_chunks(int64_t n_cols) { return static_cast<int>(ceil_div(n_cols, kPairChunk)); }
+
+static int ensure_pair_buffers(byz_ctx* ctx, int64_t n) {
+    // the list is capped: beyond kPairCapacity near-duplicate pairs the call fails loudly (status word) instead of
+    // working through what is by then an O(N^2 D) problem -- the reference's own cost
+    int64_t cap = n * (n - 1) / 2;
+    const int64_t limit = env_int("BYZ_NEAR_PAIR_CAPACITY", 1 << 20);
+    if (cap > limit) cap = limit;
+    if (cap < 1) cap = 1;
+    BYZ_TRY(ctx->near_pairs.ensure(static_cast<size_t>(cap) * sizeof(int2)));
+    BYZ_TRY(ctx->near_sq.ensure(static_cast<size_t>(cap) * sizeof(double)));
+    ctx->near_pair_capacity = cap;
+    return BYZ_OK;
+}
+
+// sq_dev[p] = sum over THIS matrix's columns of (g_i - g_j)^2 for every listed pair (the column-sharded path adds the
+// ranks' vectors up before applying them)
+int launch_near_pair_sqdist(byz_ctx* ctx, const float* G, int64_t n_cols, int64_t ld, const int32_t* row_index,
+                            double* sq_dev, hipStream_t stream) {
+    const int n_chunks = near_pair_chunks(n_cols);
+    const int64_t item_capacity = static_cast<int64_t>(1) << 22;
+    BYZ_TRY(ctx->near_partial.ensure(static_cast<size_t>(item_capacity) * sizeof(double)));
+    KernelTimer t(ctx, BYZ_K_DISTANCES, stream);
+    near_pair_partial_kernel<<<static_cast<unsigned>(ctx->num_cus * 8), 256, 0, stream>>>(
+        G, n_cols, ld, row_index, ctx->near_pairs.as<int2>(), near_pair_count_word(ctx), (int)ctx->near_pair_capacity, n_chunks,
+        item_capacity, ctx->near_partial.as<double>(), device_status_word(ctx));
+    BYZ_TRY(check_launch("near_pair_partial_kernel"));
+    near_pair_sum_kernel<<<64, 256, 0, stream>>>(ctx->near_partial.as<double>(), near_pair_count_word(ctx),
+                                                 (int)ctx->near_pair_capacity, n_chunks, item_capacity, sq_dev);
+    return check_launch("near_pair_sum_kernel");
+}
+
+int launch_near_pair_apply(byz_ctx* ctx, const double* sq_dev, int64_t n, float* dist, hipStream_t stream) {
+    {
+        KernelTimer t(ctx, BYZ_K_DISTANCES, stream);
+        near_pair_apply_kernel<<<64, 256, 0, stream>>>(sq_dev, ctx->near_pairs.as<int2>(), near_pair_count_word(ctx),
+                                                       (int)ctx->near_pair_capacity, n, dist, ctx->gram_rep.as<int32_t>(),
+                                                       device_status_word(ctx));
+        BYZ_TRY(check_launch("near_pair_apply_kernel"));
+    }
+    return canonicalise_duplicates(ctx, n, dist, stream);
+}
+
+// Distances from a Gram matrix.  With G (the rows the Gram was taken over) the near-duplicate pairs are re-evaluated
+// on the difference itself and the result matches the reference's norm-of-difference to fp32 rounding for every pair;
+// without G (the column-sharded path: a rank sees only its slice) the pairs are listed in the context and the caller
+// finishes with launch_near_pair_sqdist / an all-reduce / launch_near_pair_apply.
+// rows_canonical: the caller guarantees identical rows already have bitwise identical distance rows and exact zeros
+// between them (exact-arithmetic Gram of this very call, no near pairs possible to list without G) -- NEVER inferred.
+int launch_distances_from_gram(byz_ctx* ctx, const double* gram, int64_t n, float* dist, hipStream_t stream,
+                               const float* G, int64_t n_cols, int64_t ld) {
+    BYZ_REQUIRE(gram && dist && n > 0, "distances: bad arguments");
+    BYZ_TRY(ensure_pair_buffers(ctx, n));
+    BYZ_TRY(ctx->gram_rep.ensure(static_cast<size_t>(n) * sizeof(int32_t)));
+    BYZ_HIP(hipMemsetAsync(near_pair_count_word(ctx), 0, sizeof(int32_t), stream));
+    {
+        KernelTimer t(ctx, BYZ_K_DISTANCES, stream);
+        gram_rep_kernel<<<static_cast<unsigned>(ceil_div(n, 4)), 256, 0, stream>>>(gram, n, ctx->gram_rep.as<int32_t>());
+        BYZ_TRY(check_launch("gram_rep_kernel"));
+        dim3 grid(static_cast<unsigned>(ceil_div(n, 64)), static_cast<unsigned>(ceil_div(n, 4)));
+        distance_kernel<<<grid, 256, 0, stream>>>(gram, n, dist, ctx->gram_rep.as<int32_t>(), ctx->near_pairs.as<int2>(),
+                                                  near_pair_count_word(ctx), (int)ctx->near_pair_capacity);
+        BYZ_TRY(check_launch("distance_kernel"));
+    }
+    if (G != nullptr) {
+        BYZ_TRY(launch_near_pair_sqdist(ctx, G, n_cols, ld, nullptr, ctx->near_sq.as<double>(), stream));
+        return launch_near_pair_apply(ctx, ctx->near_sq.as<double>(), n, dist, stream);
+    }
+    return canonicalise_duplicates(ctx, n, dist, stream);
 }
 
 }  // namespace byz

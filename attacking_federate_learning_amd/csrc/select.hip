@@ -14,17 +14,19 @@
 // reference's visit order 1, 0, 2, 3, ... with a strict '<' (a tie keeps the earlier visitor), against a
 // running minimum that starts at 1e20 (no score below it -> index -1).
 //
-// bulyan_loop_kernel: one persistent 1024-thread workgroup runs all theta picks on the device, no host
-// round trips.  Re-sorting every remaining row per pick, as the reference does, costs O(theta N^2 log N);
-// here each row keeps two running fp64 sums: T = sum of its distances to the rows still present, and
-// Top = sum of the `drop` largest of them (drop = f - 1 when users_count == N).  The reference's score,
-// "sum of the n_t - f smallest of the n_t - 1 remaining distances", is T - Top, and removing the winner w
-// updates both in O(1) per row through the precomputed rank table.  All the terms are fp32 values, so
-// the fp64 sums are exact for any realistic spread of magnitudes: rows with identical distance multisets
-// (the identical malicious vectors) keep bitwise identical scores and tie exactly as in the reference,
-// where the visit order decides.  Versus the reference's fp32 sequential sums the scores differ by fp32
-// rounding noise (~1e-6 relative at N = 1e4); DESIGN.md states the parity protocol for that.
+// bulyan_grid_kernel: all theta picks in one launch, rows spread over ceil(n / 256) workgroups that exchange
+// 8-byte tagged granules once per pick.  Re-sorting every remaining row per pick, as the reference does, costs
+// O(theta N^2 log N); here each row keeps two running fp64 sums: T = sum of its distances to the rows still
+// present, and Top = sum of the `drop` largest of them (drop = f - 1 when users_count == N).  The exact value of
+// the reference's score, "sum of the n_t - f smallest of the n_t - 1 remaining distances", is T - Top, and
+// removing the winner w updates both in O(1) per row through the precomputed rank table.  The reference itself
+// forms that sum sequentially in fp32; whenever more than one twin class lies within the rounding band of such a
+// sum, the contenders are re-scored in exactly that arithmetic (reference_score), so that given the same distance
+// matrix the selection is the reference's, pick for pick -- not a more accurate one.
 #include "common.hpp"
+
+#include <cstdlib>
+#include <cstring>
 
 namespace byz {
 namespace {
@@ -179,88 +181,374 @@ __global__ __launch_bounds__(1024) void krum_argmin_kernel(const float* __restri
 }
 
 // ---------------------------------------------------------------------------------------------------
-template <int Q>  // rows per thread: thread t owns rows t, t + 1024, ...
-__global__ __launch_bounds__(1024) void bulyan_loop_kernel(const float* __restrict__ dist, int n, int theta,
-                                                           int drop, const uint16_t* __restrict__ sorted_idx,
-                                                           const uint16_t* __restrict__ rank_t,
-                                                           const double* __restrict__ row_total,
-                                                           const double* __restrict__ row_top,
-                                                           int32_t* __restrict__ selection,
-                                                           int32_t* __restrict__ status) {
-    __shared__ Candidate slots[16];
-    __shared__ uint32_t removed[kMaxSelectRows / 32];
-    const int tid = threadIdx.x;
-    for (int i = tid; i < kMaxSelectRows / 32; i += 1024) removed[i] = 0u;
-
-    double tot[Q], top[Q];
-    int ptr[Q];
-    bool alive[Q];
-#pragma unroll
-    for (int q = 0; q < Q; ++q) {
-        const int u = tid + q * 1024;
-        alive[q] = u < n;
-        tot[q] = alive[q] ? row_total[u] : 0.0;
-        top[q] = (alive[q] && drop > 0) ? row_top[u] : 0.0;
-        ptr[q] = n - 1 - drop;
+// Twin classes.  Two rows u, v are twins when d(u, v) == 0 and d(u, x) == d(v, x) bitwise for every other x:
+// what two clients that submitted the same vector look like (malicious.py:26-27 rebinds every malicious
+// client's gradient to ONE array).  Twins keep identical live distance multisets through every removal, so in
+// the reference their scores are identical floats at every pick and only the visit order separates them.
+// cls[u] = the smallest row of u's class.  One wave per row: the first zero in the row nominates, a full
+// bitwise comparison of the two rows decides (an arbitrary caller-supplied matrix need not be a metric).
+__global__ __launch_bounds__(256) void twin_class_kernel(const float* __restrict__ dist, int n,
+                                                         int32_t* __restrict__ cls) {
+    const int u = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (u >= n) return;
+    const uint32_t* row = reinterpret_cast<const uint32_t*>(dist) + static_cast<int64_t>(u) * n;
+    int cand = -1;
+    for (int j0 = 0; j0 < u; j0 += 64) {
+        const int j = j0 + lane;
+        const unsigned long long m = __ballot(j < u && (row[j] << 1) == 0u);   // +0.0 or -0.0
+        if (m) {
+            cand = j0 + __builtin_ctzll(m);
+            break;
+        }
     }
+    int result = u;
+    if (cand >= 0) {
+        const uint32_t* other = reinterpret_cast<const uint32_t*>(dist) + static_cast<int64_t>(cand) * n;
+        bool same = true;
+        for (int x = lane; x < n; x += 64)
+            if (x != u && x != cand && row[x] != other[x]) same = false;
+        if ((other[u] << 1) != 0u) same = false;
+        if (__ballot(!same) == 0ull) result = cand;
+    }
+    if (lane == 0) cls[u] = result;
+}
+
+// a class root must be its own root (always true for genuine twins; an inconsistent matrix falls back to singletons)
+__global__ __launch_bounds__(256) void twin_class_fix_kernel(const int32_t* __restrict__ cls, int n,
+                                                             int32_t* __restrict__ out) {
+    const int u = blockIdx.x * blockDim.x + threadIdx.x;
+    if (u >= n) return;
+    const int r = cls[u];
+    out[u] = (cls[r] == r) ? r : u;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Bulyan's pick-and-remove loop (defences.py:59-68) across workgroups.
+//
+// Workgroup g of W = ceil(n / 256) owns rows 256 g .. 256 g + 255, one row per thread.  Every row keeps two fp64
+// running sums: T (its distances to the rows still present) and Top (the `drop` largest of them); T - Top is
+// the EXACT value of the sum the reference forms in fp32 at that pick.  Each pick:
+//
+//   1. every workgroup finds its best row (smallest T - Top, then earliest in the visit order 1, 0, 2, ...) and
+//      the best score among its rows of any OTHER twin class, and publishes both as 8-byte tagged granules
+//      (one relaxed agent-scope store each: the payload carries its own tag, so no fence and no flag);
+//   2. wave 0 of every workgroup gathers all W granules.  The reference decides by SEQUENTIAL fp32 sums, whose
+//      rounding error is at most delta = u (m + 1) / 2 relative for m ascending positive terms (u = 2^-24):
+//      a row whose exact score exceeds the minimum by more than ~2.2 delta cannot win in the reference either.
+//      If every row within that band belongs to one twin class, the winner is that class's earliest member in
+//      the visit order -- no fp32 arithmetic needed (this is every pick of well-separated data, and every pick
+//      among the attack's identical rows);
+//   3. otherwise (round 2) the contenders ARE re-scored the reference's way -- ascending live distances, a
+//      left-to-right fp32 sum of the first n_t - f (defences.py:33-34) -- one wave per contender, one
+//      contender per twin class and workgroup, in parallel across the workgroups; the fp32 scores are
+//      gathered the same way and the smallest, earliest one wins: bit for bit the reference's decision.
+//   4. everybody removes the winner: O(1) per row through the rank table.
+//
+// All workgroups must be resident (W <= 64 of 256 CUs); every wait is bounded and a timeout is reported through
+// the status word, never papered over.
+constexpr int kGridThreads = 256;
+constexpr int kGridMaxWgs = kMaxSelectRows / kGridThreads;   // 64: one lane of the gathering wave per workgroup
+constexpr unsigned kSpinLimit = 1u << 22;
+constexpr uint32_t kNoRow = 0x3fffu;
+constexpr uint32_t kInfBits = 0x7f800000u;
+
+__device__ __forceinline__ void granule_store(unsigned long long* p, unsigned long long v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ unsigned long long granule_load(const unsigned long long* p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// largest float <= d (d >= 0 or +inf; NaN -> +inf, "no candidate")
+__device__ __forceinline__ float float_below(double d) {
+    if (!(d == d)) return __builtin_inff();
+    float f = static_cast<float>(d);
+    if (static_cast<double>(f) > d) {
+        const uint32_t b = __float_as_uint(f);
+        f = __uint_as_float((b & 0x7fffffffu) == 0u ? 0x80000001u : ((b & 0x80000000u) ? b + 1u : b - 1u));
+    }
+    return f;
+}
+__device__ __forceinline__ double double_above(float f) {   // an upper bound of every double that rounds down to f
+    const uint32_t b = __float_as_uint(f);
+    if ((b & 0x7f800000u) == 0x7f800000u) return static_cast<double>(f);
+    const float up = (b & 0x80000000u) ? ((b & 0x7fffffffu) == 0u ? __uint_as_float(1u) : __uint_as_float(b - 1u))
+                                       : __uint_as_float(b + 1u);
+    return static_cast<double>(up);
+}
+
+// wave 0 only: lane l < n_wgs waits for workgroup l's granule of this pick; false on timeout
+__device__ __forceinline__ bool gather_granules(const unsigned long long* slots, int n_wgs, uint32_t tag_mask,
+                                                uint32_t tag, int lane, unsigned long long none,
+                                                unsigned long long& mine) {
+    unsigned long long v = none;
+    bool ok = lane >= n_wgs;
+    for (unsigned spins = 0;; ++spins) {
+        if (!ok) {
+            v = granule_load(slots + lane);
+            ok = (static_cast<uint32_t>(v) & tag_mask) == tag;
+        }
+        if (__ballot(!ok) == 0ull) break;
+        if (spins > kSpinLimit) return false;
+        __builtin_amdgcn_s_sleep(1);
+    }
+    mine = v;
+    return true;
+}
+
+// The reference's score of row u at this pick (defences.py:33-34): ascending live distances, sequential fp32 sum of
+// the first `take`.  One wave; the result is wave-uniform.  Adding +0.0 for a skipped entry is exact.
+__device__ __forceinline__ float reference_score(const float* __restrict__ dist, const uint16_t* __restrict__ sorted_idx,
+                                                 const uint32_t* removed, int n, int u, int take, int lane) {
+    const uint16_t* order = sorted_idx + static_cast<int64_t>(u) * n;
+    const float* drow = dist + static_cast<int64_t>(u) * n;
+    float s = 0.0f;
+    int got = 0;
+    for (int r0 = 0; r0 < n && got < take; r0 += 64) {
+        const int r = r0 + lane;
+        bool live = false;
+        float v = 0.0f;
+        if (r < n) {
+            const int col = order[r];
+            live = col != u && !((removed[col >> 5] >> (col & 31)) & 1u);
+            if (live) v = drow[col];
+        }
+        const unsigned long long m = __ballot(live);
+        if (m == 0ull) continue;
+        const int before = __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(m >> 32),
+                                                     __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(m), 0));
+        if (!live || got + before >= take) v = 0.0f;   // past the prefix the reference sums
+        got += __popcll(m);
+        const int vb = __float_as_int(v);
+#pragma unroll
+        for (int l = 0; l < 64; ++l) s = __fadd_rn(s, __int_as_float(__builtin_amdgcn_readlane(vb, l)));
+    }
+    return s;
+}
+
+struct GridDecision {
+    int mode;        // 0 winner known, 1 round 2, 2 no candidate, 3 exchange timed out
+    int winner;
+    double threshold;
+};
+
+__global__ __launch_bounds__(kGridThreads) void bulyan_grid_kernel(
+    const float* __restrict__ dist, int n, int theta, int drop, int users_count, int corrupted,
+    const uint16_t* __restrict__ sorted_idx, const uint16_t* __restrict__ rank_t,
+    const double* __restrict__ row_total, const double* __restrict__ row_top, const int32_t* __restrict__ cls,
+    unsigned long long* __restrict__ xchg, float band_scale, int32_t* __restrict__ selection,
+    int32_t* __restrict__ status, int32_t* __restrict__ rescored) {
+    __shared__ Candidate slots[kGridThreads / 64];
+    __shared__ double second_slots[kGridThreads / 64];
+    __shared__ uint32_t removed[kMaxSelectRows / 32];
+    __shared__ GridDecision decision;
+    __shared__ unsigned long long class_leader[256];
+    __shared__ int leaders[kGridThreads];
+    __shared__ int n_leaders;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n_wgs = gridDim.x, wg = blockIdx.x;
+    const int u = wg * kGridThreads + tid;
+    for (int i = tid; i < kMaxSelectRows / 32; i += kGridThreads) removed[i] = 0u;
+
+    bool alive = u < n;
+    double tot = alive ? row_total[u] : 0.0;
+    double top = (alive && drop > 0) ? row_top[u] : 0.0;
+    int ptr = n - 1 - drop;
+    const int my_class = alive ? cls[u] : 0;
+    const int my_pos = visit_position(u);
+    int n_rescored = 0;
     __syncthreads();
 
-    int failed = 0;
+    // exchange slots: [parity][kind A, B, R][workgroup]
+    auto slot = [&](int parity, int kind) { return xchg + (parity * 3 + kind) * kGridMaxWgs; };
+    const unsigned long long none_a = (static_cast<unsigned long long>(kInfBits) << 32) | (static_cast<unsigned long long>(kNoRow) << 18);
+
+    int result = 0;
     for (int t = 0; t < theta; ++t) {
+        // granule A is rewritten at every pick, so a 4-bit tag tells pick t from pick t - 2 in the same slot; B and the
+        // round-2 granule R (written only at picks that need it) carry the pick number itself
+        const uint32_t tag = static_cast<uint32_t>((t >> 1) & 7) + 1u;
+        const uint32_t tag18 = static_cast<uint32_t>(t + 1);
+        const int parity = t & 1;
+        // the prefix the reference sums at this pick: sorted(...)[: users_count - t - f] of the n - t - 1 live entries
+        const int live_entries = n - t - 1;
+        const int keep = users_count - t - corrupted;
+        const int take = keep >= 0 ? (keep < live_entries ? keep : live_entries)
+                                   : (live_entries + keep > 0 ? live_entries + keep : 0);
+        // ---- 1. the workgroup's best row, and its best score outside that row's twin class
+        const double score = tot - top;
+        const bool candidate = alive && score < static_cast<double>(kKrumInit);   // false for NaN
         Candidate c{static_cast<double>(kKrumInit), 0x7fffffff, -1};
+        if (candidate) c = Candidate{score, my_pos, u};
+        const Candidate best = block_best(c, slots);
+        const int best_class = best.row >= 0 ? cls[best.row] : -1;
+        double second = (candidate && my_class != best_class) ? score : __builtin_inf();
 #pragma unroll
-        for (int q = 0; q < Q; ++q) {
-            if (alive[q]) {
-                const int u = tid + q * 1024;
-                const double s = tot[q] - top[q];
-                if (s < static_cast<double>(kKrumInit)) {
-                    Candidate o{s, visit_position(u), u};
-                    if (better(o, c)) c = o;
+        for (int m = 32; m > 0; m >>= 1) second = fmin(second, __shfl_xor(second, m, 64));
+        if (lane == 0) second_slots[wave] = second;
+        __syncthreads();
+        if (wave == 0) {
+            // ---- 2. publish, gather, decide (all 64 lanes of wave 0 compute the same decision)
+            double sec = second_slots[0];
+#pragma unroll
+            for (int w = 1; w < kGridThreads / 64; ++w) sec = fmin(sec, second_slots[w]);
+            const float a_lb = best.row >= 0 ? float_below(best.score) : __builtin_inff();
+            const float b_lb = float_below(sec);
+            unsigned long long ga = best.row >= 0
+                ? (static_cast<unsigned long long>(__float_as_uint(a_lb)) << 32) | (static_cast<unsigned long long>(best.row) << 18) |
+                  (static_cast<unsigned long long>(best_class) << 4)
+                : none_a;
+            unsigned long long gb = static_cast<unsigned long long>(__float_as_uint(b_lb)) << 32;
+            bool ok = true;
+            if (n_wgs > 1) {
+                if (lane == 0) {
+                    granule_store(slot(parity, 0) + wg, ga | tag);
+                    granule_store(slot(parity, 1) + wg, gb | tag18);
+                }
+                unsigned long long va = none_a, vb = static_cast<unsigned long long>(kInfBits) << 32;
+                ok = gather_granules(slot(parity, 0), n_wgs, 15u, tag, lane, none_a, va);
+                ok = ok && gather_granules(slot(parity, 1), n_wgs, 0x3ffffu, tag18, lane,
+                                           static_cast<unsigned long long>(kInfBits) << 32, vb);
+                ga = va;
+                gb = vb;
+            } else if (lane != 0) {
+                ga = none_a;
+                gb = static_cast<unsigned long long>(kInfBits) << 32;
+            }
+            // lane l now holds workgroup l's granules
+            const float a = __uint_as_float(static_cast<uint32_t>(ga >> 32));
+            const float b = __uint_as_float(static_cast<uint32_t>(gb >> 32));
+            const int a_row = static_cast<int>((ga >> 18) & 0x3fffu);
+            const int a_cls = static_cast<int>((ga >> 4) & 0x3fffu);
+            float m1 = a;
+#pragma unroll
+            for (int m = 32; m > 0; m >>= 1) m1 = __builtin_fminf(m1, __shfl_xor(m1, m, 64));
+            GridDecision d{0, -1, 0.0};
+            if (!ok) {
+                d.mode = 3;
+            } else if (!(m1 < __builtin_inff())) {
+                d.mode = 2;
+            } else {
+                // every row whose exact score lies within the band of the smallest one may be the reference's winner
+                // band_scale >= 0: the rigorous bound 2.2 delta, delta = u (m + 1) / 2 (x band_scale);
+                // band_scale <  0: |band_scale| u sqrt(m + 1), the random-walk size of the same error (not a bound)
+                const double u24 = 5.9604644775390625e-08;
+                const double band = (band_scale >= 0.0f ? static_cast<double>(band_scale) * 1.1 * u24 * static_cast<double>(take + 1)
+                                                        : -static_cast<double>(band_scale) * u24 * sqrt(static_cast<double>(take + 1))) + 1e-9;
+                const double thr = take <= 1 ? double_above(m1) * (1.0 + 1e-12) : double_above(m1) * (1.0 + band);
+                d.threshold = thr;
+                const bool in_a = static_cast<double>(a) <= thr;
+                const bool in_b = static_cast<double>(b) <= thr;
+                const unsigned long long first = __ballot(a == m1);
+                const int lead_cls = __builtin_amdgcn_readlane(a_cls, __builtin_ctzll(first));
+                const bool one_class = __ballot(in_b) == 0ull && __ballot(in_a && a_cls != lead_cls) == 0ull;
+                if (one_class) {
+                    int pos = in_a ? visit_position(a_row) : 0x7fffffff;
+#pragma unroll
+                    for (int m = 32; m > 0; m >>= 1) pos = min(pos, __shfl_xor(pos, m, 64));
+                    d.winner = pos == 0 ? 1 : (pos == 1 ? 0 : pos);   // visit_position is its own inverse
+                } else {
+                    d.mode = 1;
                 }
             }
+            if (lane == 0) decision = d;
         }
-        const Candidate best = block_best(c, slots);
-        // a single-row matrix has an empty distance dict in the reference (nothing to visit); a last
-        // survivor of a larger matrix is still visited with an empty list, scores 0 and is picked
-        const int w = (n < 2) ? -1 : best.row;
-        if (w < 0) {
-            failed = 1;
-            break;  // uniform: every thread sees the same broadcast
+        if (tid < 256) class_leader[tid] = ~0ull;
+        if (tid == 0) n_leaders = 0;
+        __syncthreads();
+        GridDecision d = decision;
+        if (d.mode == 1) {
+            // ---- 3. round 2: the contenders scored in the reference's own arithmetic
+            const bool contender = candidate && score <= d.threshold;
+            const unsigned long long key = (static_cast<unsigned long long>(my_pos) << 32) | static_cast<uint32_t>(my_class);
+            if (contender) atomicMin(&class_leader[my_class & 255], key);
+            __syncthreads();
+            bool leader = false;
+            if (contender) {
+                const unsigned long long held = class_leader[my_class & 255];
+                // the class's earliest local member scores for the class; a class that lost its slot to another one
+                // (hash collision) scores every member: redundant, never wrong
+                leader = static_cast<int>(held & 0xffffffffu) != my_class || held == key;
+            }
+            if (leader) leaders[atomicAdd(&n_leaders, 1)] = tid;
+            __syncthreads();
+            const int n_lead = n_leaders;
+            Candidate r{static_cast<double>(kKrumInit), 0x7fffffff, -1};
+            for (int k = wave; k < n_lead; k += kGridThreads / 64) {
+                const int row = wg * kGridThreads + leaders[k];
+                const float s32 = reference_score(dist, sorted_idx, removed, n, row, take, lane);
+                if (s32 < kKrumInit) {
+                    Candidate o{static_cast<double>(s32), visit_position(row), row};
+                    if (better(o, r)) r = o;
+                }
+            }
+            if (wave == 0 && lane == 0) n_rescored += n_lead;
+            const Candidate local = block_best(r, slots);   // every lane of a wave holds the same r
+            if (wave == 0) {
+                unsigned long long gr = local.row >= 0
+                    ? (static_cast<unsigned long long>(__float_as_uint(static_cast<float>(local.score))) << 32) |
+                      (static_cast<unsigned long long>(local.row) << 18)
+                    : none_a;
+                bool ok = true;
+                if (n_wgs > 1) {
+                    if (lane == 0) granule_store(slot(parity, 2) + wg, gr | tag18);
+                    unsigned long long vr = none_a;
+                    ok = gather_granules(slot(parity, 2), n_wgs, 0x3ffffu, tag18, lane, none_a, vr);
+                    gr = vr;
+                } else if (lane != 0) {
+                    gr = none_a;
+                }
+                const int r_row = static_cast<int>((gr >> 18) & 0x3fffu);
+                Candidate g{static_cast<double>(kKrumInit), 0x7fffffff, -1};
+                if (r_row != static_cast<int>(kNoRow))
+                    g = Candidate{static_cast<double>(__uint_as_float(static_cast<uint32_t>(gr >> 32))), visit_position(r_row), r_row};
+                g = wave_best(g);
+                if (lane == 0) {
+                    decision.mode = !ok ? 3 : (g.row < 0 ? 2 : 0);
+                    decision.winner = g.row;
+                }
+            }
+            __syncthreads();
+            d = decision;
         }
+        if (d.mode != 0 || (n < 2)) {
+            result = (n < 2) ? 1 : (d.mode == 3 ? 2 : 1);
+            break;   // uniform across the grid: every workgroup reaches the same decision (or times out)
+        }
+        const int w = d.winner;
         if (tid == 0) {
-            selection[t] = w;
+            if (wg == 0) selection[t] = w;
             removed[w >> 5] |= 1u << (w & 31);
         }
         __syncthreads();
-        const float* drow = dist + static_cast<int64_t>(w) * n;        // symmetric: d[w][u] == d[u][w]
-        const uint16_t* rrow = rank_t + static_cast<int64_t>(w) * n;   // rank of column w inside row u
-#pragma unroll
-        for (int q = 0; q < Q; ++q) {
-            const int u = tid + q * 1024;
-            if (!alive[q]) continue;
+        // ---- 4. remove the winner from every row still present
+        if (alive) {
             if (u == w) {
-                alive[q] = false;
-                continue;
-            }
-            const double d = static_cast<double>(drow[u]);
-            const int r = rrow[u];
-            tot[q] -= d;
-            if (drop > 0 && r >= ptr[q]) {
-                // w was one of this row's `drop` largest: the largest survivor below the boundary joins them
-                top[q] -= d;
-                int p = ptr[q] - 1;
-                const uint16_t* order = sorted_idx + static_cast<int64_t>(u) * n;
-                while (p >= 0) {
-                    const int col = order[p];
-                    if (!((removed[col >> 5] >> (col & 31)) & 1u)) break;
-                    --p;
+                alive = false;
+            } else {
+                const double dw = static_cast<double>(dist[static_cast<int64_t>(w) * n + u]);   // symmetric: d[w][u] == d[u][w]
+                const int r = rank_t[static_cast<int64_t>(w) * n + u];                          // rank of column w inside row u
+                tot -= dw;
+                if (drop > 0 && r >= ptr) {
+                    // w was one of this row's `drop` largest: the largest survivor below the boundary joins them
+                    top -= dw;
+                    int p = ptr - 1;
+                    const uint16_t* order = sorted_idx + static_cast<int64_t>(u) * n;
+                    while (p >= 0) {
+                        const int col = order[p];
+                        if (!((removed[col >> 5] >> (col & 31)) & 1u)) break;
+                        --p;
+                    }
+                    if (p >= 0) top += static_cast<double>(dist[static_cast<int64_t>(u) * n + order[p]]);
+                    ptr = p;
                 }
-                if (p >= 0) top[q] += static_cast<double>(dist[static_cast<int64_t>(u) * n + order[p]]);
-                ptr[q] = p;
             }
         }
     }
-    if (tid == 0) *status = failed;
+    if (tid == 0) {
+        if (result != 0) atomicMax(status, result);
+        if (n_rescored) atomicAdd(rescored, n_rescored);
+    }
 }
 
 }  // namespace
@@ -311,23 +599,34 @@ int launch_krum_argmin(byz_ctx* ctx, int64_t n, int32_t* winner_dev, hipStream_t
 }
 
 int launch_bulyan_loop(byz_ctx* ctx, const float* dist, int64_t n, int64_t theta, int64_t drop_count,
-                       int32_t* selection_dev, int32_t* status_dev, hipStream_t stream) {
+                       int64_t users_count, int64_t corrupted, int32_t* selection_dev, int32_t* status_dev,
+                       hipStream_t stream) {
     BYZ_REQUIRE(dist && selection_dev && status_dev && n > 0 && theta >= 0 && theta <= n,
                 "bulyan loop: bad arguments (n=%lld theta=%lld)", (long long)n, (long long)theta);
+    BYZ_TRY(ctx->twin_class.ensure(static_cast<size_t>(2 * n) * sizeof(int32_t)));
+    BYZ_TRY(ctx->xchg.ensure(static_cast<size_t>(2 * 3 * kGridMaxWgs) * sizeof(unsigned long long)));
+    int32_t* cls_tmp = ctx->twin_class.as<int32_t>();
+    int32_t* cls = cls_tmp + n;
+    // which arithmetic decides a pick whose contenders lie within rounding of each other (see bulyan_grid_kernel):
+    //   BYZ_BULYAN_BAND unset / "rigorous"  every row that CAN beat the minimum in sequential fp32 is re-scored
+    //   BYZ_BULYAN_BAND=<x> (x > 0)          the rigorous band scaled by x; (x < 0) |x| u sqrt(m): statistical, not a bound
+    float band_scale = 1.0f;
+    if (const char* e = std::getenv("BYZ_BULYAN_BAND")) {
+        if (std::strcmp(e, "rigorous") != 0) band_scale = static_cast<float>(std::atof(e));
+    }
+    BYZ_HIP(hipMemsetAsync(ctx->xchg.ptr, 0, static_cast<size_t>(2 * 3 * kGridMaxWgs) * sizeof(unsigned long long), stream));
+    BYZ_HIP(hipMemsetAsync(status_dev, 0, 2 * sizeof(int32_t), stream));
     KernelTimer t(ctx, BYZ_K_BULYAN_LOOP, stream);
-    const uint16_t* si = ctx->sorted_idx.as<uint16_t>();
-    const uint16_t* rt = ctx->rank_t.as<uint16_t>();
-    const double* tot = ctx->row_total.as<double>();
-    const double* top = ctx->row_top.as<double>();
-    const int q = static_cast<int>(ceil_div(n, 1024));
-#define BYZ_LOOP(Q) bulyan_loop_kernel<Q><<<1, 1024, 0, stream>>>(dist, (int)n, (int)theta, (int)drop_count, si, rt, tot, top, selection_dev, status_dev)
-    if (q <= 1) BYZ_LOOP(1);
-    else if (q <= 2) BYZ_LOOP(2);
-    else if (q <= 4) BYZ_LOOP(4);
-    else if (q <= 8) BYZ_LOOP(8);
-    else BYZ_LOOP(16);
-#undef BYZ_LOOP
-    return check_launch("bulyan_loop_kernel");
+    twin_class_kernel<<<static_cast<unsigned>(ceil_div(n, 4)), 256, 0, stream>>>(dist, (int)n, cls_tmp);
+    BYZ_TRY(check_launch("twin_class_kernel"));
+    twin_class_fix_kernel<<<static_cast<unsigned>(ceil_div(n, 256)), 256, 0, stream>>>(cls_tmp, (int)n, cls);
+    BYZ_TRY(check_launch("twin_class_fix_kernel"));
+    const unsigned n_wgs = static_cast<unsigned>(ceil_div(n, kGridThreads));   // <= 64: all resident, they wait for each other
+    bulyan_grid_kernel<<<n_wgs, kGridThreads, 0, stream>>>(
+        dist, (int)n, (int)theta, (int)drop_count, (int)users_count, (int)corrupted, ctx->sorted_idx.as<uint16_t>(),
+        ctx->rank_t.as<uint16_t>(), ctx->row_total.as<double>(), ctx->row_top.as<double>(), cls,
+        ctx->xchg.as<unsigned long long>(), band_scale, selection_dev, status_dev, status_dev + 1);
+    return check_launch("bulyan_grid_kernel");
 }
 
 }  // namespace byz

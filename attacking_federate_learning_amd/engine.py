@@ -153,6 +153,10 @@ class Engine:
     def synchronize(self, stream=None):
         _check(self.lib.byz_stream_sync(self.ctx, _vp(stream)))
 
+    def check(self, stream=None):
+        """Synchronise and raise if a kernel of an asynchronous call flagged a failure on the device."""
+        _check(self.lib.byz_ctx_check(self.ctx, _vp(stream)))
+
     def _device_matrix(self, g):
         """torch CUDA tensor / DeviceBuffer -> _Matrix; None for host arrays."""
         if isinstance(g, DeviceBuffer):
@@ -164,6 +168,8 @@ class Engine:
                 return None
             if g.dtype != torch.float32 or g.dim() != 2 or g.stride(1) != 1:
                 raise ValueError('device matrices must be 2-D float32 with unit column stride')
+            if g.device.index != self.device:
+                raise ValueError('the matrix lives on %s, this engine drives cuda:%d' % (g.device, self.device))
             stream = torch.cuda.current_stream(g.device).cuda_stream
             return _Matrix(g.data_ptr(), g.shape[0], g.shape[1], g.stride(0), stream, g, torch_like=g)
         return None
@@ -218,7 +224,7 @@ class Engine:
         dist = DeviceBuffer(self, (m.rows, m.rows), np.float32)
         _check(self.lib.byz_pairwise_distances_dev(self.ctx, _vp(m.ptr), m.rows, m.cols, m.ld, _vp(dist.ptr),
                                                    _vp(m.stream)))
-        self.synchronize(m.stream)
+        self.check(m.stream)
         return Distances(dist, m.rows)
 
     def gram(self, g):
@@ -236,43 +242,128 @@ class Engine:
         _check(self.lib.byz_gram_dev(self.ctx, _vp(m.ptr), m.rows, m.cols, m.ld, _vp(ptr), _vp(m.stream)))
         return out
 
-    def distances_from_gram(self, gram, n, stream=None):
+    def gram_share(self, panel, row_index, share_count, share_index):
+        """This rank's share of the Gram tiles of `panel` (a device matrix every rank holds, e.g. an all-gathered column
+        panel): zeros outside the share, so the ranks' outputs SUM to the Gram.  `row_index` (int32, on the device, or
+        None): logical row r is panel[row_index[r]] -- skips the padding rows of an unevenly sharded gather."""
+        m = self._device_matrix(panel)
+        if m is None:
+            raise ValueError('gram_share() takes a device-resident matrix')
+        n_rows, idx_ptr, keep = m.rows, None, None
+        if row_index is not None:
+            idx_ptr, n_rows, keep = self._row_index(row_index, m, validate=False)
+        if m.torch_like is not None:
+            import torch
+            out = torch.empty((n_rows, n_rows), dtype=torch.float64, device=m.torch_like.device)
+            ptr = out.data_ptr()
+        else:
+            out = DeviceBuffer(self, (n_rows, n_rows), np.float64)
+            ptr = out.ptr
+        _check(self.lib.byz_gram_share_dev(self.ctx, _vp(m.ptr), int(n_rows), m.cols, m.ld, _vp(idx_ptr),
+                                           int(share_count), int(share_index), _vp(ptr), _vp(m.stream)))
+        if keep is not None and not _is_torch(keep):
+            self.synchronize(m.stream)
+        return out
+
+    def near_pairs_count(self, stream=None):
+        """Pairs the last distance kernel could not resolve through the Gram identity (synchronises)."""
+        count = ctypes.c_int64(0)
+        _check(self.lib.byz_near_pairs_count(self.ctx, ctypes.byref(count), _vp(stream)))
+        return int(count.value)
+
+    def near_pairs_sqdist(self, g, count, row_index=None):
+        """Per listed pair, the sum over g's columns of the squared fp32 difference (fp64): this rank's part."""
+        m = self._device_matrix(g)
+        if m is None:
+            raise ValueError('near_pairs_sqdist() takes a device-resident matrix')
+        idx_ptr, keep = None, None
+        if row_index is not None:
+            idx_ptr, _, keep = self._row_index(row_index, m, validate=False)
+        if m.torch_like is not None:
+            import torch
+            sq = torch.empty(int(count), dtype=torch.float64, device=m.torch_like.device)
+            sq_ptr = sq.data_ptr()
+        else:
+            sq = DeviceBuffer(self, (int(count),), np.float64)
+            sq_ptr = sq.ptr
+        _check(self.lib.byz_near_pairs_sqdist_dev(self.ctx, _vp(m.ptr), m.rows, m.cols, m.ld, _vp(idx_ptr), _vp(sq_ptr),
+                                                  _vp(m.stream)))
+        if keep is not None and not _is_torch(keep):
+            self.synchronize(m.stream)
+        return sq
+
+    def near_pairs_apply(self, sq, distances, stream=None):
+        """distances[i, j] = sqrt(sq[p]) for every listed pair, then identical rows are made to tie exactly again."""
+        ptr = sq.data_ptr() if _is_torch(sq) else sq.ptr
+        if _is_torch(sq):
+            import torch
+            stream = torch.cuda.current_stream(sq.device).cuda_stream
+        _check(self.lib.byz_near_pairs_apply_dev(self.ctx, _vp(ptr), int(distances.n), _vp(distances.ptr), _vp(stream)))
+        self.check(stream)
+
+    def distances_from_gram(self, gram, n, stream=None, local_columns=None, all_reduce=None):
+        """Distances from an (all-reduced) fp64 Gram.  The Gram identity cannot resolve nearly coincident rows, so the
+        kernel lists those pairs; with `local_columns` (this rank's column slice of G) they are re-evaluated on the
+        difference itself: per-rank sums of squared differences, `all_reduce(tensor)` over the ranks when given, then
+        applied -- the same result as the single-GPU path, which does all of it inside byz_pairwise_distances_dev.
+        Without `local_columns` the list is left for the caller (near_pairs_count / _sqdist / _apply)."""
         ptr = gram.data_ptr() if _is_torch(gram) else gram.ptr
         if _is_torch(gram):
             import torch
             stream = torch.cuda.current_stream(gram.device).cuda_stream
-        dist = DeviceBuffer(self, (n, n), np.float32)
+        dist = Distances(DeviceBuffer(self, (n, n), np.float32), n)
         _check(self.lib.byz_distances_from_gram_dev(self.ctx, _vp(ptr), int(n), _vp(dist.ptr), _vp(stream)))
-        self.synchronize(stream)
-        return Distances(dist, n)
+        if local_columns is None:
+            self.check(stream)
+            return dist
+        count = self.near_pairs_count(stream)
+        if count:
+            sq = self.near_pairs_sqdist(local_columns, count)
+            if all_reduce is not None:
+                all_reduce(sq)
+            self.near_pairs_apply(sq, dist, stream)
+        return dist
 
-    def _as_distances(self, distances, n_expected=None):
+    def _as_distances(self, distances):
+        """-> (Distances, keys): `keys[c]` is the reference's row index of row c of the dense matrix, or None when
+        they coincide.
+
+        A dict is what the reference's own loops pass around (defences.py:16-21, and :61-68 where Bulyan pops the
+        winner's row and column before the next `krum(..., distances, True)`): any subset of rows may be present,
+        in dict order.  The kernels visit rows in the order 1, 0, 2, 3, ..., which IS the dict order of a complete
+        dict; for a dict with rows removed the dense matrix lists the keys in dict order with the first two
+        swapped, so that the same kernel order walks them as the reference's `for user in distances.keys()` does."""
         if isinstance(distances, Distances):
-            return distances
+            return distances, None
         if isinstance(distances, dict):
-            n = len(distances)
             keys = list(distances.keys())
-            if keys != ([1, 0] + list(range(2, n)) if n >= 2 else []):
-                raise NotImplementedError('only complete distance dicts in creation order are supported')
-            dense = np.full((n, n), np.inf, dtype=np.float32)
-            for i, row in distances.items():
-                if len(row) != n - 1:
-                    raise NotImplementedError('distance dict with removed entries')
+            m = len(keys)
+            if m >= 2:
+                keys[0], keys[1] = keys[1], keys[0]
+            position = {k: c for c, k in enumerate(keys)}
+            dense = np.full((m, m), np.inf, dtype=np.float32)
+            for k, row in distances.items():
+                if len(row) != m - 1:
+                    raise ValueError('distance dict is not square: row %r has %d entries, %d rows present'
+                                     % (k, len(row), m))
+                c = position[k]
                 for j, v in row.items():
-                    dense[i, j] = v
-            distances = dense
+                    dense[c, position[j]] = v
+            plain = keys == list(range(m))
+            return Distances(self.to_device(dense), m), (None if plain else keys)
         dense = np.ascontiguousarray(distances, dtype=np.float32)
         if dense.ndim != 2 or dense.shape[0] != dense.shape[1]:
             raise ValueError('distances must be a square matrix')
-        return Distances(self.to_device(dense), dense.shape[0])
+        return Distances(self.to_device(dense), dense.shape[0]), None
 
     def krum_select(self, distances, users_count, corrupted_count):
         """The selection loop of defences.py:27-37 on a distance matrix; returns the index (or -1)."""
-        d = self._as_distances(distances)
+        d, keys = self._as_distances(distances)
         idx = ctypes.c_int32(-2)
         _check(self.lib.byz_krum_select_dev(self.ctx, _vp(d.ptr), d.n, int(users_count), int(corrupted_count),
                                             ctypes.byref(idx), None, None))
-        return int(idx.value)
+        idx = int(idx.value)
+        return idx if (keys is None or idx < 0) else keys[idx]
 
     def krum(self, g, users_count, corrupted_count, distances=None, return_index=False):
         if not return_index:
@@ -304,7 +395,38 @@ class Engine:
             return g.numpy()[idx]
         return g[idx]
 
-    def trimmed_mean(self, g, users_count=None, corrupted_count=0, row_index=None):
+    def _row_index(self, row_index, m, validate):
+        """row_index -> (device pointer, count, keepalive).  The kernel reads int32 indices straight from device
+        memory: anything else is converted here, and (unless the caller vouches for it) checked against the
+        matrix height, because an out-of-range index is an out-of-bounds read on the GPU."""
+        if isinstance(row_index, DeviceBuffer):
+            if row_index.dtype != np.int32:
+                raise ValueError('a DeviceBuffer row_index must hold int32')
+            return row_index.ptr, int(np.prod(row_index.shape)), row_index
+        if _is_torch(row_index):
+            import torch
+            if not row_index.is_cuda or (m.torch_like is not None and row_index.device != m.torch_like.device) \
+                    or row_index.device.index != self.device:
+                raise ValueError('row_index must live on the GPU of the matrix (cuda:%d), got %s'
+                                 % (self.device, row_index.device))
+            if row_index.dtype not in (torch.int32, torch.int64, torch.int16, torch.uint8):
+                raise ValueError('row_index must hold integers, got %s' % row_index.dtype)
+            idx = row_index.reshape(-1).to(torch.int32).contiguous()
+            if validate and idx.numel():
+                lo, hi = int(idx.min().item()), int(idx.max().item())
+                if lo < 0 or hi >= m.rows:
+                    raise ValueError('row_index out of range: [%d, %d] for %d rows' % (lo, hi, m.rows))
+            return idx.data_ptr(), idx.numel(), idx
+        host = np.asarray(row_index)
+        if host.dtype.kind not in 'iu':
+            raise ValueError('row_index must hold integers, got %s' % host.dtype)
+        host = host.reshape(-1)
+        if host.size and (host.min() < 0 or host.max() >= m.rows):
+            raise ValueError('row_index out of range: [%d, %d] for %d rows' % (host.min(), host.max(), m.rows))
+        keep = self.to_device(host.astype(np.int32))
+        return keep.ptr, keep.shape[0], keep
+
+    def trimmed_mean(self, g, users_count=None, corrupted_count=0, row_index=None, validate_index=True):
         m = self._device_matrix(g)
         if m is None:
             if row_index is not None:
@@ -312,27 +434,36 @@ class Engine:
             return self.defend_host('TrimmedMean', g, 0, corrupted_count)
         n_rows, idx_ptr, keep = m.rows, None, None
         if row_index is not None:
-            if _is_torch(row_index):
-                idx_ptr, n_rows, keep = row_index.data_ptr(), row_index.numel(), row_index
-            elif isinstance(row_index, DeviceBuffer):
-                idx_ptr, n_rows, keep = row_index.ptr, row_index.shape[0], row_index
-            else:
-                keep = self.to_device(np.asarray(row_index, dtype=np.int32))
-                idx_ptr, n_rows = keep.ptr, keep.shape[0]
+            idx_ptr, n_rows, keep = self._row_index(row_index, m, validate_index)
+            if n_rows == 0:
+                raise ValueError('row_index selects no rows')
         out, ptr = self._out_like(m, m.cols)
         _check(self.lib.byz_trimmed_mean_dev(self.ctx, _vp(m.ptr), int(n_rows), m.cols, m.ld, _vp(idx_ptr),
                                              int(corrupted_count), _vp(ptr), _vp(m.stream)))
-        if not (_is_torch(row_index) or row_index is None):
+        if keep is not None and not _is_torch(keep):
             self.synchronize(m.stream)  # the temporary index buffer must outlive the kernel
         return out
 
-    def bulyan_select(self, distances, users_count, corrupted_count):
-        d = self._as_distances(distances)
+    def bulyan_select(self, distances, users_count, corrupted_count, on_device=False):
+        """The pick-and-remove loop of defences.py:59-68: theta indices in selection order.  `on_device=True` leaves
+        them in a DeviceBuffer (int32) for `trimmed_mean(row_index=...)` -- no host round trip between the stages."""
+        d, keys = self._as_distances(distances)
         theta = int(users_count) - 2 * int(corrupted_count)
         sel = DeviceBuffer(self, (max(theta, 1),), np.int32)
         _check(self.lib.byz_bulyan_select_dev(self.ctx, _vp(d.ptr), d.n, int(users_count), int(corrupted_count),
                                               _vp(sel.ptr), None))
-        return sel.numpy()[:theta]
+        if on_device and keys is None:
+            sel.shape = (theta,)
+            sel.nbytes = theta * 4
+            return sel
+        picked = sel.numpy()[:theta]
+        return picked if keys is None else np.asarray([keys[i] for i in picked], dtype=np.int32)
+
+    def bulyan_rescored(self):
+        """Rows the last Bulyan loop re-scored with the reference's sequential fp32 sums (0: every pick was clear)."""
+        rows = ctypes.c_int64(0)
+        _check(self.lib.byz_bulyan_rescored(self.ctx, ctypes.byref(rows)))
+        return int(rows.value)
 
     def bulyan(self, g, users_count, corrupted_count, return_selection=False):
         assert users_count >= 4 * corrupted_count + 3  # defences.py:56

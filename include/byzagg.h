@@ -52,6 +52,11 @@ int byz_ctx_create(int device, byz_ctx** out);
 void byz_ctx_destroy(byz_ctx* ctx);
 int byz_ctx_reserve(byz_ctx* ctx, int64_t n_rows, int64_t n_cols);
 int byz_ctx_device(const byz_ctx* ctx);
+/* Synchronises `stream` and reports what a kernel of an asynchronous call could only flag on the device:  */
+/* BYZ_E_HIP when a Gram chunk never got its accumulation ticket (the distances of that call are invalid), */
+/* BYZ_E_UNSUPPORTED when the near-duplicate pair list overflowed.  Entry points with a host output do this */
+/* themselves.                                                                                             */
+int byz_ctx_check(byz_ctx* ctx, void* stream);
 /* largest supported row count for the selection kernels (rows of G), and for trimmed_mean */
 int byz_limits(int64_t* max_rows_select, int64_t* max_rows_trimmed);
 
@@ -78,8 +83,26 @@ int byz_pairwise_distances_dev(byz_ctx* ctx, const float* G_dev, int64_t n_rows,
 /* the Gram of its column slice in fp64, the host all-reduces it, then every rank converts.   */
 int byz_gram_dev(byz_ctx* ctx, const float* G_dev, int64_t n_rows, int64_t n_cols, int64_t ld,
                  double* gram_dev, void* stream);
+/* One rank's SHARE of a Gram, for ranks that all hold the same rows (the client-sharded path after an   */
+/* all-gather of a column panel): every share_count-th 128 x 128 tile of the lower triangle starting with */
+/* share_index is computed, the rest of gram_dev is written as zero, so that the SUM over the ranks is    */
+/* the panel's Gram.  row_index_dev (optional): logical row r is G[row_index[r]] (skips padding rows of   */
+/* the gathered panel).                                                                                    */
+int byz_gram_share_dev(byz_ctx* ctx, const float* G_dev, int64_t n_rows, int64_t n_cols, int64_t ld,
+                       const int32_t* row_index_dev, int share_count, int share_index, double* gram_dev,
+                       void* stream);
 int byz_distances_from_gram_dev(byz_ctx* ctx, const double* gram_dev, int64_t n_rows,
                                 float* dist_dev, void* stream);
+/* Near-duplicate pairs.  c_ii + c_jj - 2 c_ij cannot resolve rows that nearly coincide, the reference's  */
+/* norm of the difference (defences.py:20) can.  byz_pairwise_distances_dev (and krum / bulyan) therefore  */
+/* re-evaluate every pair with d^2 < (c_ii + c_jj)/16 on the difference itself.  A caller that only holds   */
+/* a column slice of G (byz_distances_from_gram_dev on an all-reduced Gram) finishes the same step itself:  */
+/* count -> per-rank sums of squared differences over the local columns -> (all-reduce) -> apply.           */
+int byz_near_pairs_count(byz_ctx* ctx, int64_t* count_host, void* stream);
+int byz_near_pairs_sqdist_dev(byz_ctx* ctx, const float* G_dev, int64_t n_rows, int64_t n_cols, int64_t ld,
+                              const int32_t* row_index_dev, double* sq_dev, void* stream);
+int byz_near_pairs_apply_dev(byz_ctx* ctx, const double* sq_dev, int64_t n_rows, float* dist_dev,
+                             void* stream);
 
 /* ---- defences.krum (reference defences.py:23-42) --------------------------------------- */
 /* Selection loop only: ascending sort of every row's distances, sequential fp32 sum of the */
@@ -106,10 +129,15 @@ int byz_trimmed_mean_dev(byz_ctx* ctx, const float* G_dev, int64_t n_rows, int64
 
 /* ---- defences.bulyan (reference defences.py:55-70) ------------------------------------- */
 /* Selection loop on a distance matrix: theta = users_count - 2*corrupted_count picks, each */
-/* the Krum winner among the rows still present, scores in fp64.            */
+/* the Krum winner among the rows still present.  Exact fp64 running scores pick the winner  */
+/* outright when it is clear; otherwise the contenders are re-scored with the reference's    */
+/* sequential fp32 sums (defences.py:33-34), so the selection is the reference's own.        */
 /* selection_dev: theta int32 indices in selection order.                                   */
 int byz_bulyan_select_dev(byz_ctx* ctx, const float* dist_dev, int64_t n_rows, int64_t users_count,
                           int64_t corrupted_count, int32_t* selection_dev, void* stream);
+/* Rows the last selection loop had to re-score in the reference's sequential fp32 arithmetic because   */
+/* their exact scores lay within that arithmetic's rounding band (0 for well separated clients).        */
+int byz_bulyan_rescored(const byz_ctx* ctx, int64_t* rows_host);
 /* Whole function (asserts users_count >= 4*corrupted_count + 3).  selection_dev optional.  */
 int byz_bulyan_dev(byz_ctx* ctx, const float* G_dev, int64_t n_rows, int64_t n_cols, int64_t ld,
                    int64_t users_count, int64_t corrupted_count, float* out_dev,

@@ -16,13 +16,7 @@ RTOL = ATOL = 1e-5
 
 
 @pytest.fixture(scope='module')
-def eng():
-    from attacking_federate_learning_amd.engine import get_engine
-    return get_engine()
-
-
-@pytest.fixture(scope='module')
-def defences():
+def defences(eng):
     from attacking_federate_learning_amd import defences
     return defences
 
@@ -100,7 +94,7 @@ def test_golden_bulyan(defences, eng, golden, case):
 
 
 @pytest.mark.parametrize('case', ['attack_5x300_z1.5', 'attack_24x100_z0.5', 'attack_3x64_z0'])
-def test_golden_attack(golden, case):
+def test_golden_attack(eng, golden, case):
     from attacking_federate_learning_amd import malicious
 
     class User:

@@ -1,0 +1,224 @@
+"""Parity at the sizes BASELINE.json's GPU configurations run (needs an MI355X).
+
+configs[3] is N = 4000 (f = 960, theta = 2080), configs[4] is N = 10000 (f = 2400, theta = 5200): the selection
+kernels then sort rows wider than one pass of the workgroup, the Bulyan loop spans many workgroups, and the
+second-stage trimmed mean reads 2080 / 5200 rows through the selection.  The oracle at these sizes is
+oracle/scale.py (C restatement of defences.py:26-37 and :59-68, pinned against oracle.faithful in
+tests/test_oracle_scale.py) -- the reference's own arithmetic (sequential fp32 sums), so given one distance matrix the
+indices must be IDENTICAL, not merely within a margin.
+"""
+import numpy as np
+import pytest
+
+from oracle import faithful, ideal, scale
+
+pytestmark = pytest.mark.gpu
+
+MAL_PROP = 0.24      # reference main.py:106
+TAU = 16 * np.finfo(np.float32).eps
+
+
+def close(a, b, rtol=1e-5, atol=1e-5):
+    return np.allclose(np.asarray(a), np.asarray(b), rtol=rtol, atol=atol, equal_nan=True)
+
+
+def point_distances(seed, n, dim=16, identical=0):
+    """Distances of n points in `dim` dimensions (fp32, as a client-distance matrix looks to the selection);
+    with `identical` > 0 rows 0..identical-1 are one point, like the attack's malicious clients."""
+    rng = np.random.default_rng(seed)
+    pts = rng.standard_normal((n, dim)).astype(np.float32)
+    pts *= (1.0 + 0.5 * rng.permutation(n) / n).astype(np.float32)[:, None]
+    if identical:
+        pts[:identical] = pts[:identical].mean(axis=0)
+    p64 = pts.astype(np.float64)
+    sq = (p64 * p64).sum(1)
+    dist = np.sqrt(np.maximum(sq[:, None] + sq[None, :] - 2.0 * (p64 @ p64.T), 0.0)).astype(np.float32)
+    dist = np.minimum(dist, dist.T)
+    if identical:
+        dist[:identical, :identical] = 0.0
+        dist[:identical, :] = dist[0, :]
+        dist[:, :identical] = dist[:, [0]]
+    np.fill_diagonal(dist, np.inf)
+    return dist
+
+
+def scaled(seed, n, d):
+    rng = np.random.default_rng(seed)
+    g = rng.standard_normal((n, d)).astype(np.float32)
+    return g * (1.0 + 0.5 * rng.permutation(n) / n).astype(np.float32)[:, None]
+
+
+# ---- selection on a given distance matrix: the reference's decisions, bit for bit ----------------------
+@pytest.mark.parametrize('n', [200, 333, 640, 1000, 1500, 2049, 4000, 8000, 10000])
+def test_bulyan_selection_is_the_reference_selection(eng, n):
+    f = int(n * MAL_PROP)
+    dist = point_distances(4100 + n, n)
+    want = scale.bulyan_selection(dist, n, f)
+    got = eng.bulyan_select(dist, n, f).tolist()
+    assert got == want, 'first difference at pick %d' % next(i for i, (a, b) in enumerate(zip(got, want)) if a != b)
+    assert eng.krum_select(dist, n, f) == scale.krum_pick(dist, n, f)
+
+
+@pytest.mark.parametrize('n', [700, 4000, 10000])
+def test_bulyan_selection_with_the_attack_ties(eng, n):
+    """f identical malicious rows (malicious.py:26-27): their scores tie exactly at every pick and the visit order
+    1, 0, 2, ... decides, in the reference and here."""
+    f = int(n * MAL_PROP)
+    dist = point_distances(4200 + n, n, identical=f)
+    want = scale.bulyan_selection(dist, n, f)
+    assert eng.bulyan_select(dist, n, f).tolist() == want
+    assert eng.krum_select(dist, n, f) == scale.krum_pick(dist, n, f)
+
+
+@pytest.mark.parametrize('n,dim', [(600, 2000), (2500, 3000)])
+def test_bulyan_selection_on_concentrated_scores(eng, n, dim):
+    """High-dimensional iid points: all scores lie within a fraction of a percent of each other, so many picks are
+    decided inside the rounding noise of the reference's sequential fp32 sums -- the case that needs the reference's
+    own arithmetic rather than a more accurate one."""
+    f = int(n * MAL_PROP)
+    rng = np.random.default_rng(4300 + n)
+    pts = rng.standard_normal((n, dim)).astype(np.float32)
+    p64 = pts.astype(np.float64)
+    sq = (p64 * p64).sum(1)
+    dist = np.sqrt(np.maximum(sq[:, None] + sq[None, :] - 2.0 * (p64 @ p64.T), 0.0)).astype(np.float32)
+    dist = np.minimum(dist, dist.T)
+    np.fill_diagonal(dist, np.inf)
+    want = scale.bulyan_selection(dist, n, f)
+    ideal_sel = scale.bulyan_selection(dist, n, f, mode='ideal')
+    got = eng.bulyan_select(dist, n, f).tolist()
+    assert got == want
+    # (informational) this is a case where exact fp64 scoring and the reference disagree
+    print('picks where fp64 scoring differs from the reference: %d of %d'
+          % (sum(a != b for a, b in zip(ideal_sel, want)), len(want)))
+
+
+# ---- end to end at configs[3]'s N ------------------------------------------------------------------------
+def test_config4_bulyan_end_to_end_n4000(eng):
+    """Bulyan N = 4000, f = 960 on a D = 4096 slice: Gram distances (bf16 x 3 split MFMA, chunk-free schedule),
+    row sort with n_pad = 4096, the selection loop, the 2080-row second stage through the selection.
+    The distances differ from the reference's sdot by fp32 rounding, so picks inside tau are reported."""
+    n, d = 4000, 4096
+    f = int(n * MAL_PROP)
+    g = scaled(4400, n, d)
+    out, sel = eng.bulyan(g, n, f, return_selection=True)
+    sel = np.asarray(sel).tolist()
+    assert len(sel) == n - 2 * f and len(set(sel)) == len(sel)
+    dist64 = ideal.distance_matrix(g)
+    want, margins = scale.bulyan_selection(dist64.astype(np.float32), n, f, mode='ideal', with_margins=True)
+    noisy = np.flatnonzero(margins <= TAU)
+    first_noisy = int(noisy[0]) if len(noisy) else len(sel)
+    assert sel[:first_noisy] == want[:first_noisy]
+    print('N=4000: %d of %d picks have an fp64 margin below tau; prefix checked: %d' % (len(noisy), len(sel), first_noisy))
+    # the second stage is the reference's trimmed mean of exactly the picked rows, in selection order
+    cols = np.random.default_rng(0).choice(d, 96, replace=False)
+    assert close(np.asarray(out)[cols], faithful.trimmed_mean(g[sel][:, cols], len(sel), 2 * f))
+    assert close(out, ideal.trimmed_mean(g[sel], 2 * f))
+    # given the GPU's OWN distances the selection must be the reference's, pick for pick
+    dist_gpu = eng.pairwise_distances(g).numpy()
+    assert np.allclose(dist_gpu[~np.eye(n, dtype=bool)], dist64[~np.eye(n, dtype=bool)], rtol=1e-6)
+    assert sel == scale.bulyan_selection(dist_gpu, n, f)
+
+
+# ---- second stage: row_index in selection order at theta = 2080 and 5200 --------------------------------------
+@pytest.mark.parametrize('n,theta,cols', [(4000, 2080, 70), (10000, 5200, 40), (3000, 1537, 33), (6000, 2561, 20)])
+def test_trimmed_mean_through_a_selection(eng, n, theta, cols):
+    rng = np.random.default_rng(4500 + n)
+    # quarter-integer data: exact +t / -t ties at the window edge, which the stable sort resolves by ROW ORDER, so
+    # the order of the selection is visible in the result (defences.py:50, :70)
+    g = (np.round(rng.standard_normal((n, cols)) * 64) / 64).astype(np.float32)
+    order = rng.permutation(n)[:theta].astype(np.int32)
+    c = 2 * int(n * MAL_PROP)
+    want = faithful.trimmed_mean(g[order], theta, c)
+    gd = eng.to_device(g)
+    got = eng.trimmed_mean(gd, n, c, row_index=order).numpy()
+    assert close(got, want)
+    # continuous data as well
+    g2 = rng.standard_normal((n, cols)).astype(np.float32)
+    got2 = eng.trimmed_mean(eng.to_device(g2), n, c, row_index=order).numpy()
+    assert close(got2, faithful.trimmed_mean(g2[order], theta, c))
+
+
+def test_trimmed_mean_row_index_must_be_int32_on_the_device(eng):
+    torch = pytest.importorskip('torch')
+    g = torch.randn((50, 40), device='cuda')
+    order = torch.randperm(50, device='cuda')[:31]           # int64, as torch.tensor(selection) would be
+    want = ideal.trimmed_mean(g.cpu().numpy()[order.cpu().numpy()], 10)
+    assert close(eng.trimmed_mean(g, 50, 10, row_index=order).cpu().numpy(), want)      # converted, not reinterpreted
+    with pytest.raises(ValueError):
+        eng.trimmed_mean(g, 50, 10, row_index=torch.tensor([0, 1, 50], device='cuda'))   # out of range
+    with pytest.raises(ValueError):
+        eng.trimmed_mean(g, 50, 10, row_index=order.cpu())                                 # wrong device
+
+
+# ---- configs[4]'s flow at N = 10000 ----------------------------------------------------------------------
+def test_config5_flow_n10000(eng):
+    """attack -> ONE distance matrix -> Krum and Bulyan from it, N = 10000, f = m = 2400, on a D = 2048 slice."""
+    torch = pytest.importorskip('torch')
+    n, d = 10000, 2048
+    f = int(n * MAL_PROP)
+    g_host = scaled(4600, n, d)
+    g = torch.from_numpy(g_host).cuda()
+    drift, mean, std = eng.drift_attack(g[:f], 1.5, write_back=True)
+    want_drift = faithful.drift_vector(g_host[:f].copy(), 1.5)
+    assert close(drift.cpu().numpy(), want_drift)
+    g_host[:f] = drift.cpu().numpy()
+    assert torch.equal(g[:f], drift[None, :].expand(f, d))
+    dist = eng.pairwise_distances(g)
+    dist_host = dist.numpy()
+    want64 = ideal.distance_matrix(g_host)
+    mask = ~np.eye(n, dtype=bool)
+    mask[:f, :f] = False
+    assert np.all(dist_host[:f, :f][~np.eye(f, dtype=bool)] == 0.0)
+    assert np.allclose(dist_host[mask], want64[mask], rtol=1e-6)
+    assert np.array_equal(dist_host, dist_host.T)
+    # the reference's decisions on this matrix
+    assert eng.krum_select(dist, n, f) == scale.krum_pick(dist_host, n, f)
+    sel = eng.bulyan_select(dist, n, f).tolist()
+    assert sel == scale.bulyan_selection(dist_host, n, f)
+    out = eng.trimmed_mean(g, n, 2 * f, row_index=np.asarray(sel, dtype=np.int32)).cpu().numpy()
+    cols = np.random.default_rng(1).choice(d, 48, replace=False)
+    assert close(out[cols], faithful.trimmed_mean(g_host[sel][:, cols], len(sel), 2 * f))
+    # and the fused entry point agrees with the pieces
+    out2, sel2 = eng.bulyan(g, n, f, return_selection=True)
+    assert sel2.cpu().tolist() == sel and close(out2.cpu().numpy(), out)
+
+
+# ---- the remaining exports ------------------------------------------------------------------
+def test_host_convenience_entry_points(eng):
+    import ctypes
+    g = scaled(4700, 37, 900)
+    n, f = 37, 8
+    dist = np.empty((n, n), dtype=np.float32)
+    rc = eng.lib.byz_pairwise_distances_host(eng.ctx, g.ctypes.data_as(ctypes.c_void_p), n, 900,
+                                             dist.ctypes.data_as(ctypes.c_void_p))
+    assert rc == 0
+    want = faithful.distance_matrix(g)
+    off = ~np.eye(n, dtype=bool)
+    assert np.allclose(dist[off], want[off], rtol=2e-6) and np.all(np.isinf(np.diag(dist)))
+    idx = ctypes.c_int32(-7)
+    assert eng.lib.byz_krum_select_host(eng.ctx, want.ctypes.data_as(ctypes.c_void_p), n, n, f, ctypes.byref(idx)) == 0
+    assert idx.value == faithful.krum_pick(want, faithful.visit_order(n), n, f)
+    eng.reserve(4000, 10000)                                   # byz_ctx_reserve: pre-sizes, must not disturb results
+    assert eng.krum(g, n, f, return_index=True) == faithful.krum(g, n, f, return_index=True)
+
+
+def test_drift_hook_called_directly(eng):
+    """DriftAttack._attack_grads with arbitrary vectors (malicious.py:34-36) goes through byz_drift_axpy_dev."""
+    from attacking_federate_learning_amd import malicious
+    rng = np.random.default_rng(4800)
+    mean, std = rng.standard_normal(70001).astype(np.float32), np.abs(rng.standard_normal(70001)).astype(np.float32)
+    want = mean.copy()
+    want[:] -= 1.5 * std[:]
+    att = malicious.DriftAttack(1.5)
+    got = att._attack_grads(mean, std, None, None)
+    assert got is mean and np.allclose(got, want, rtol=1e-6, atol=1e-7)
+
+
+def test_distances_to_dict_is_the_reference_dict(eng):
+    g = scaled(4900, 9, 300)
+    d = eng.pairwise_distances(g)
+    as_dict = d.to_dict()
+    assert list(as_dict.keys()) == [1, 0] + list(range(2, 9))
+    dense = d.numpy()
+    assert all(as_dict[i][j] == dense[i, j] for i in range(9) for j in range(9) if i != j)
+    assert all(i not in as_dict[i] for i in range(9))

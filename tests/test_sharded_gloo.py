@@ -23,7 +23,27 @@ class OracleKernels:
         g = g_local.numpy().astype(np.float64)
         return torch.from_numpy(g @ g.T)
 
-    def distances_from_gram(self, gram):
+    def gram_share(self, panel, row_index, share_count, share_index):
+        """numpy stand-in of byz_gram_share_dev: every share_count-th 128 x 128 lower-triangle tile, in list order."""
+        rows = panel.numpy().astype(np.float64)
+        if row_index is not None:
+            rows = rows[np.asarray(row_index)]
+        full = rows @ rows.T
+        n = len(rows)
+        out = np.zeros_like(full)
+        tile, position = 4, 0       # tiny tiles so that a 23-row test really splits the work
+        for ti in range(0, n, tile):
+            for tj in range(0, ti + 1, tile):
+                if position % share_count == share_index:
+                    out[ti:ti + tile, tj:tj + tile] = full[ti:ti + tile, tj:tj + tile]
+                    out[tj:tj + tile, ti:ti + tile] = full[tj:tj + tile, ti:ti + tile]
+                position += 1
+        return torch.from_numpy(out)
+
+    def near_pairs_count(self):
+        return 0            # the fp64 stand-in resolves every pair through the Gram
+
+    def distances_from_gram(self, gram, local_columns=None, all_reduce=None):
         c = gram.numpy()
         sq = np.diag(c)
         d2 = np.maximum(sq[:, None] + sq[None, :] - 2 * c, 0.0)
@@ -35,7 +55,7 @@ class OracleKernels:
     def krum_select(self, d, users_count, corrupted_count):
         return faithful.krum_pick(d, faithful.visit_order(len(d)), users_count, corrupted_count)
 
-    def bulyan_select(self, d, users_count, corrupted_count):
+    def bulyan_select(self, d, users_count, corrupted_count, on_device=False):
         return ideal.bulyan_selection(d, users_count, corrupted_count)
 
     def trimmed_mean(self, g_local, corrupted_count, row_index=None):
@@ -89,8 +109,20 @@ def worker(rank, world, port, n, d, f, results):
         out['krum'] = agg.krum(g_local, n, f, gather=True).numpy()
         out['tm'] = agg.trimmed_mean(g_local, n, f, gather=True).numpy()
         out['nodef'] = agg.no_defense(g_local, gather=True).numpy()
-        b, sel = agg.bulyan(g_local, n, f, gather=True, return_selection=True)
+        b, sel = agg.bulyan(g_local, n, f, gather=True, return_selection=True, total_columns=d)
         out['bulyan'], out['selection'] = b.numpy(), np.asarray(sel)
+        # ---- the clients layout (north_star): rows stay where the clients left them
+        mine2 = torch.from_numpy(g[start:start + rows_per_rank[rank]].copy())
+        drift2, _, _ = agg.drift_attack_clients(mine2, rows_per_rank, f, 1.5)
+        out['c_drift'] = drift2.numpy()
+        out['c_rows'] = mine2.numpy().copy()
+        out['c_krum_index'] = agg.krum_clients(mine2, rows_per_rank, n, f, return_index=True)
+        out['c_krum'] = agg.krum_clients(mine2, rows_per_rank, n, f).numpy()
+        # small panels on purpose: several gathers, a ragged last one
+        out['c_dist'] = np.asarray(agg.client_distances(mine2, rows_per_rank, panel_columns=50))
+        b2, sel2 = agg.bulyan_clients(mine2, rows_per_rank, n, f, return_selection=True)
+        out['c_bulyan'], out['c_selection'] = b2.numpy(), np.asarray(sel2)
+        out['comm'] = agg.comm_report()
         results[rank] = out
     finally:
         dist.destroy_process_group()
@@ -120,6 +152,20 @@ def test_ranks_equal_the_unsharded_oracle(world, n, d, f):
         assert np.array_equal(r['nodef'], faithful.no_defense(g, n, f))
         assert r['selection'].tolist() == want_sel
         assert np.array_equal(r['bulyan'], want_bulyan)
+        # clients layout: same answers, full vectors on every rank
+        assert np.allclose(r['c_drift'], g[0], rtol=1e-6, atol=1e-6)
+        lo = sum(n // world + (1 if q < n % world else 0) for q in range(rank))
+        assert np.allclose(r['c_rows'], g[lo:lo + len(r['c_rows'])], rtol=1e-6, atol=1e-6)
+        assert r['c_krum_index'] == r['krum_index']
+        assert np.allclose(r['c_krum'], g[r['krum_index']], rtol=1e-6, atol=1e-6)
+        want_dist = ideal.distance_matrix(g)
+        off = ~np.eye(n, dtype=bool)
+        assert np.allclose(r['c_dist'][off], want_dist[off], rtol=1e-5)
+        assert r['c_selection'].tolist() == want_sel
+        assert np.allclose(r['c_bulyan'], want_bulyan, rtol=1e-5, atol=1e-6)
+        if world > 1:
+            assert r['comm']['allgather_row_tiles']['calls'] >= 2 and r['comm']['allgather_row_tiles']['bytes'] > 0
+            assert 'reshard_selected_rows' in r['comm'] and 'allreduce_gram' in r['comm']
 
 
 def test_column_slices_cover_everything():
