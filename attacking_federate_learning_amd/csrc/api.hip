@@ -189,6 +189,7 @@ void byz_ctx_destroy(byz_ctx* ctx) {
     ctx->scores.release();
     ctx->selection.release();
     ctx->twin_class.release();
+    ctx->redo_tiles.release();
     ctx->xchg.release();
     ctx->small.release();
     ctx->stage_in.release();
@@ -395,6 +396,17 @@ int byz_trimmed_mean_dev(byz_ctx* ctx, const float* G, int64_t n_rows, int64_t n
     // defences.py:45: number_to_consider = int(rows - corrupted) - 1, then a Python slice [:k]
     const int64_t keep = python_prefix_len(n_rows, n_rows - corrupted_count - 1);
     return launch_trimmed_mean(ctx, G, n_rows, n_cols, ld, row_index, keep, out, as_stream(stream));
+}
+
+int byz_trimmed_mean_redone(byz_ctx* ctx, int64_t* tiles_host, void* stream) {
+    BYZ_TRY(enter(ctx));
+    BYZ_REQUIRE(tiles_host, "trimmed_mean_redone: null output");
+    *tiles_host = 0;
+    if (ctx->redo_tiles.ptr == nullptr || !ctx->redo_valid) return BYZ_OK;
+    int32_t count = 0;
+    BYZ_TRY(read_i32(ctx, ctx->redo_tiles.as<int32_t>(), &count, 1, as_stream(stream)));
+    *tiles_host = count;
+    return BYZ_OK;
 }
 
 int byz_bulyan_select_dev(byz_ctx* ctx, const float* dist, int64_t n_rows, int64_t users_count,

@@ -120,6 +120,8 @@ struct byz_ctx {
     byz::Buffer row_total;       // n fp64: sum of a row's finite distances
     byz::Buffer row_top;         // n fp64: sum of a row's largest `drop` distances
     byz::Buffer scores;          // n fp32 Krum scores
+    bool redo_valid = false;     // the last trimmed mean went through the ring selection (redo_tiles[0] is its count)
+    byz::Buffer redo_tiles;      // trimmed mean: tiles the ring selection handed to the general kernel (count first)
     byz::Buffer twin_class;      // 2n int32: twin class of every row (scratch, then final)
     byz::Buffer xchg;            // Bulyan grid loop: tagged 8-byte granules the workgroups exchange
     int64_t bulyan_rescored = 0; // rows the last Bulyan loop re-scored in the reference's fp32 arithmetic

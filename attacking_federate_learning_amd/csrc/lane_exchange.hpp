@@ -112,5 +112,35 @@ __device__ __forceinline__ void wave_bitonic_sort(float (&x)[C][R], int lane) {
     });
 }
 
+// Sorts a BITONIC sequence of 64*R values ascending (same index order i = r + R*l): log2(64 R) half-cleaner steps
+// instead of the full network.  |x - median| over values sorted by x is such a sequence (it falls, then rises).
+template <int R, int C>
+__device__ __forceinline__ void wave_bitonic_merge(float (&x)[C][R], int lane) {
+    const float pinf = __builtin_inff();
+    for_pow2_down<32 * R>([&](auto jc) {
+        constexpr int j = decltype(jc)::value;
+        if constexpr (j < R) {
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                if ((r & j) == 0) {
+#pragma unroll
+                    for (int c = 0; c < C; ++c) cmp_swap(x[c][r], x[c][r | j]);
+                }
+            }
+        } else {
+            constexpr int s = j / R;
+            const float sel = (lane & s) ? pinf : -pinf;
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+#pragma unroll
+                for (int c = 0; c < C; ++c) {
+                    const float other = lane_xor(x[c][r], s, lane);
+                    x[c][r] = __builtin_amdgcn_fmed3f(x[c][r], other, sel);
+                }
+            }
+        }
+    });
+}
+
 }  // namespace lanes
 }  // namespace byz

@@ -435,7 +435,8 @@ __global__ __launch_bounds__(kGridThreads) void bulyan_grid_kernel(
                 const double u24 = 5.9604644775390625e-08;
                 const double band = (band_scale >= 0.0f ? static_cast<double>(band_scale) * 1.1 * u24 * static_cast<double>(take + 1)
                                                         : -static_cast<double>(band_scale) * u24 * sqrt(static_cast<double>(take + 1))) + 1e-9;
-                const double thr = take <= 1 ? double_above(m1) * (1.0 + 1e-12) : double_above(m1) * (1.0 + band);
+                const double ub = double_above(m1);
+                const double thr = ub + fabs(ub) * (take <= 1 ? 1e-12 : band);
                 d.threshold = thr;
                 const bool in_a = static_cast<double>(a) <= thr;
                 const bool in_b = static_cast<double>(b) <= thr;

@@ -444,6 +444,12 @@ class Engine:
             self.synchronize(m.stream)  # the temporary index buffer must outlive the kernel
         return out
 
+    def trimmed_mean_redone(self, stream=None):
+        """16-column tiles of the last trimmed mean that the ring selection handed to the general kernel."""
+        tiles = ctypes.c_int64(0)
+        _check(self.lib.byz_trimmed_mean_redone(self.ctx, ctypes.byref(tiles), _vp(stream)))
+        return int(tiles.value)
+
     def bulyan_select(self, distances, users_count, corrupted_count, on_device=False):
         """The pick-and-remove loop of defences.py:59-68: theta indices in selection order.  `on_device=True` leaves
         them in a DeviceBuffer (int32) for `trimmed_mean(row_index=...)` -- no host round trip between the stages."""

@@ -34,6 +34,8 @@ import numpy as np  # noqa: E402
 
 PEAK_HBM = 8.0e12        # B/s, spec (MI355X_MICROARCH.md chip table; 6.29e12 measured copy)
 PEAK_MFMA_F32 = 157.3e12  # flop/s, dense fp32-input MFMA (same table)
+PEAK_MFMA_BF16 = 2.5e15   # flop/s, dense bf16 MFMA (same table)
+SPLIT_FACTOR = 6.0        # bf16 MFMA flops issued per algorithmic fp32 flop of the exact three-way split
 MAL_PROP = 0.24           # reference main.py:106
 
 
@@ -48,6 +50,8 @@ def parse_args():
     p.add_argument('--no-cpu-baseline', action='store_true')
     p.add_argument('--no-extras', action='store_true')
     p.add_argument('--cpu-seconds', type=float, default=20.0, help='budget of the cpu_baseline leg')
+    p.add_argument('--layout', default='columns', choices=['columns', 'clients', 'both'],
+                   help='multi-GPU layout of the gradient matrix (sharded.py); "both" times the other one as well')
     return p.parse_args()
 
 
@@ -95,29 +99,49 @@ class Workload:
 class BulyanSharded(Workload):
     """configs[3] (and the Bulyan half of configs[4]): column-sharded Bulyan through ShardedAggregator."""
 
-    def __init__(self, torch, agg, eng, n, d_total, device, seed, with_attack=False):
+    def __init__(self, torch, agg, eng, n, d_total, device, seed, with_attack=False, layout='columns'):
         self.torch, self.agg, self.eng = torch, agg, eng
         self.n, self.d_total = n, d_total
         self.f = int(n * MAL_PROP)
-        lo, hi = column_bounds(d_total, agg.world)[agg.rank]
-        self.d_local = hi - lo
-        self.g = make_matrix(torch, n, self.d_local, seed + 17 * agg.rank, device)
+        self.layout = layout
+        if layout == 'clients':
+            # north_star's layout: rank r holds the rows of its clients, all D columns (reference main.py:26-32)
+            self.rows_per_rank = [n // agg.world + (1 if r < n % agg.world else 0) for r in range(agg.world)]
+            self.d_local = d_total
+            self.g = make_matrix(torch, self.rows_per_rank[agg.rank], d_total, seed + 17 * agg.rank, device)
+        else:
+            lo, hi = column_bounds(d_total, agg.world)[agg.rank]
+            self.d_local = hi - lo
+            self.g = make_matrix(torch, n, self.d_local, seed + 17 * agg.rank, device)
         self.with_attack = with_attack
         self.name = 'c5s' if with_attack else 'c4'
         self.defence = 'attack+Krum+Bulyan' if with_attack else 'Bulyan'
         self.last = None
 
     def step(self):
+        if self.layout == 'clients':
+            if self.with_attack:
+                self.agg.drift_attack_clients(self.g, self.rows_per_rank, self.f, 1.5, write_back=True)
+                dist_m = self.agg.client_distances(self.g, self.rows_per_rank)
+                idx = self.agg.kernels.krum_select(dist_m, self.n, self.f)
+                sel = np.asarray(self.agg.kernels.bulyan_select(dist_m, self.n, self.f), dtype=np.int64)
+                cols, row_index = self.agg.reshard_rows_to_columns(self.g, self.rows_per_rank, sel)
+                out = self.agg.kernels.trimmed_mean(cols, 2 * self.f, row_index=row_index)
+                self.last = (self.agg._maybe_gather(out, True, total=self.d_total), sel, idx)
+            else:
+                self.last = self.agg.bulyan_clients(self.g, self.rows_per_rank, self.n, self.f, return_selection=True)
+            return
         if self.with_attack:
             # rows 0..m-1 are the malicious clients (reference main.py:28); per column, no exchange
             self.agg.drift_attack(self.g, self.f, 1.5, write_back=True)
             dist_m = self.agg.global_distances(self.g)
             idx = self.agg.kernels.krum_select(dist_m, self.n, self.f)
-            sel = np.asarray(self.agg.kernels.bulyan_select(dist_m, self.n, self.f), dtype=np.int32)
+            sel = self.agg.kernels.bulyan_select(dist_m, self.n, self.f, on_device=True)   # stays on the device
             out = self.agg.kernels.trimmed_mean(self.g, 2 * self.f, row_index=sel)
-            self.last = (self.agg._maybe_gather(out, True), sel, idx)
+            self.last = (self.agg._maybe_gather(out, True, total=self.d_total), sel, idx)
         else:
-            out, sel = self.agg.bulyan(self.g, self.n, self.f, gather=True, return_selection=True)
+            out, sel = self.agg.bulyan(self.g, self.n, self.f, gather=True, return_selection=True,
+                                       total_columns=self.d_total)
             self.last = (out, sel)
 
     def dtype(self):
@@ -131,18 +155,26 @@ class BulyanSharded(Workload):
         # under the attack rows 0..f-1 are one vector and the engine runs the Gram over the unique rows only: the
         # kernel's work is (N - f + 1)^2 * D_local, not N^2 * D_local
         rows = self.n - self.f + 1 if self.with_attack and self.n >= 512 else self.n
-        return {'kernel': 'gram_tile', 'bound': 'mfma', 'work': float(rows) ** 2 * self.d_local,
-                'peak': PEAK_MFMA_F32, 'unit': 'TFLOP/s', 'scale': 1e12,
-                'issued_factor': 6.0 if self.n > 256 else 1.0, 'issued_peak': 2.5e15 if self.n > 256 else PEAK_MFMA_F32}
+        share = self.agg.world if self.layout == 'clients' else 1     # clients: every rank does 1/W of the tiles, all D
+        split = self.n > 256
+        # The roof.  For N > 256 the contraction runs on the bf16 matrix cores as an exact three-way split: six bf16
+        # MFMA flops per algorithmic fp32 flop, so the pipe's ceiling for THIS arithmetic is 2.5 PF / 6 = 417 TF of
+        # fp32-equivalent work (the fp32-input MFMA's 157 TF, which round 1 graded against, is a floor it already beats).
+        peak = PEAK_MFMA_BF16 / SPLIT_FACTOR if split else PEAK_MFMA_F32
+        return {'kernel': 'gram_tile', 'bound': 'mfma', 'work': float(rows) ** 2 * self.d_local / share,
+                'peak': peak, 'unit': 'TFLOP/s', 'scale': 1e12,
+                'issued_factor': SPLIT_FACTOR if split else 1.0, 'issued_peak': PEAK_MFMA_BF16 if split else PEAK_MFMA_F32,
+                'peak_note': ('fp32-equivalent roof of the exact bf16x3 split: 2.5 PF dense bf16 / 6 MFMA flops per fp32 flop'
+                              if split else 'dense fp32-input MFMA peak')}
 
     def at_profiled_size(self):
         return self.name == 'c4' and self.n == 4000 and self.d_local == 10000000
 
     def config(self):
-        return {'workload': '%s: %s N=%d D=%d f=%d theta=%d (BASELINE configs[%d]), columns sharded %d-way'
+        return {'workload': '%s: %s N=%d D=%d f=%d theta=%d (BASELINE configs[%d]), %s sharded %d-way'
                             % (self.name, self.defence, self.n, self.d_total, self.f, self.n - 2 * self.f,
-                               4 if self.with_attack else 3, self.agg.world),
-                'clients': self.n, 'params': self.d_total, 'corrupted': self.f,
+                               4 if self.with_attack else 3, self.layout, self.agg.world),
+                'clients': self.n, 'params': self.d_total, 'corrupted': self.f, 'layout': self.layout,
                 'params_per_gpu': self.d_local, 'input_family': 'scaled'}
 
 
@@ -352,7 +384,10 @@ def roofline_of(wl, per_kernel, traffic_table):
            'peak': dom['peak'] / dom['scale'], 'unit': dom['unit'], 'frac': achieved / dom['peak'],
            'traffic': traffic, 'avg_launch_ms': avg_s * 1e3, 'launches': k['launches'],
            'algorithmic_work_per_launch': dom['work']}
+    if dom.get('peak_note'):
+        out['peak_note'] = dom['peak_note']
     if dom.get('issued_factor', 1.0) != 1.0:
+        out['vs_fp32_mfma_peak'] = achieved / PEAK_MFMA_F32
         # the matrix-core instructions actually issued: 6 bf16 MFMA flops per algorithmic fp32 flop, against the
         # dense bf16 MFMA peak -- how busy the matrix pipe really is
         out['mfma_issued'] = {'achieved': achieved * dom['issued_factor'] / 1e12, 'peak': dom['issued_peak'] / 1e12,
@@ -376,88 +411,111 @@ def load_traffic_table():
         return None
 
 
-# ---- CPU baseline (oracle = numpy port of the reference; checker/baseline only, never the product) --------
+# ---- CPU baseline (oracle = restatement of the reference; checker/baseline only, never the product) ---------------
+def usable_cores():
+    try:
+        return len(os.sched_getaffinity(0))
+    except AttributeError:
+        return os.cpu_count() or 1
+
+
 def cpu_baseline(wl, budget_s):
-    from oracle import faithful
+    """The reference's CPU path on this box's host cores, on a bounded sample of the same workload.
+
+    Three figures, all labelled:
+      value / kind "port"   oracle.faithful (vectorised numpy restatement), OpenBLAS pinned to ONE thread
+      also.port_all_cores   the same with OpenBLAS free to use the box (the reference's only threaded call is sdot)
+      also.as_shipped       oracle.shipped: the reference's own loops (dicts, sorted(), sum, key=abs lambda), one thread
+    """
+    from oracle import faithful, shipped
     try:
         from threadpoolctl import threadpool_limits
     except ImportError:
         threadpool_limits = None
     rng = np.random.default_rng(5)
-    t_budget = max(budget_s, 3.0)
+    t_budget = max(budget_s, 6.0)
+    cores = usable_cores()
 
-    def run():
-        if isinstance(wl, BulyanSharded):
-            n, d, f = wl.n, wl.d_total, wl.f
-            theta = n - 2 * f
-            # (i) distance pairs at the true D (defences.py:20): sqrt(sdot) of the fp32 difference
-            rows = [rng.standard_normal(d).astype(np.float32) for _ in range(4)]
-            t0, pairs = time.perf_counter(), 0
-            while time.perf_counter() - t0 < 0.35 * t_budget:
-                for i in range(4):
-                    for j in range(i):
-                        np.linalg.norm(rows[i] - rows[j])
-                        pairs += 1
-            t_pair = (time.perf_counter() - t0) / pairs
-            # (ii) one Krum pick over n live rows (defences.py:32-37): n sorts of n-1 + sequential sums
-            pts = rng.standard_normal((n, 8)).astype(np.float32)
-            dist = np.sqrt(((pts[:, None, :] - pts[None, :, :]) ** 2).sum(-1)).astype(np.float32)
-            np.fill_diagonal(dist, np.inf)
+    def timed(fn, seconds, at_least=1):
+        t0, reps = time.perf_counter(), 0
+        while reps < at_least or time.perf_counter() - t0 < seconds:
+            fn()
+            reps += 1
+        return (time.perf_counter() - t0) / reps, reps
+
+    def bulyan_parts(threads, as_shipped, seconds):
+        """(round time, description) of configs[3]/[4] from its three measured parts."""
+        n, d, f = wl.n, wl.d_total, wl.f
+        theta = n - 2 * f
+        rows = [rng.standard_normal(d).astype(np.float32) for _ in range(3)]
+        # (i) one distance at the true D (defences.py:20): norm of the fp32 difference
+        t_pair, pairs = timed(lambda: np.linalg.norm(rows[0] - rows[1]), 0.3 * seconds)
+        # (ii) one Krum pick over n live rows (defences.py:32-37)
+        pts = rng.standard_normal((n, 8)).astype(np.float32)
+        dist = np.sqrt(((pts[:, None, :] - pts[None, :, :]) ** 2).sum(-1)).astype(np.float32)
+        np.fill_diagonal(dist, np.inf)
+        if as_shipped:
+            as_dict = shipped.dict_from_dense(dist)
+            t0 = time.perf_counter()
+            shipped.krum(None, n, f, distances=as_dict, return_index=True)
+        else:
             t0 = time.perf_counter()
             faithful.krum_pick(dist, faithful.visit_order(n), n, f)
-            t_pick = time.perf_counter() - t0
-            # (iii) trimmed_mean per column over theta rows (defences.py:48-51)
-            sample_cols = 400
-            sub = rng.standard_normal((theta, sample_cols)).astype(np.float32)
-            t0 = time.perf_counter()
-            faithful.trimmed_mean(sub, theta, 2 * f)
-            t_col = (time.perf_counter() - t0) / sample_cols
-            # picks shrink: pick t scores n - t rows of n - t - 1 distances
-            pick_total = sum(t_pick * ((n - t) / n) ** 2 for t in range(theta))
-            total = t_pair * n * (n - 1) / 2 + pick_total + t_col * d
-            extra = 0.0
-            if wl.with_attack:
-                extra = t_pick   # the Krum pass; the attack statistics are negligible beside the distances
-            return 1.0 / (total + extra), (
-                'extrapolated from: %d distance pairs at D=%d (%.1f ms/pair x N(N-1)/2), one Krum pick at N=%d '
-                '(%.2f s, x theta picks with the (n_t/N)^2 shrink), trimmed_mean over %d columns at theta=%d rows '
-                '(%.0f us/column x D)' % (pairs, d, t_pair * 1e3, n, t_pick, sample_cols, theta, t_col * 1e6))
-        if isinstance(wl, TrimmedMeanC3):
-            cols = 0
-            sub = rng.standard_normal((wl.n, 200)).astype(np.float32)
-            t0 = time.perf_counter()
-            while time.perf_counter() - t0 < t_budget:
-                faithful.trimmed_mean(sub, wl.n, wl.c)
-                cols += sub.shape[1]
-            t_col = (time.perf_counter() - t0) / cols
-            return 1.0 / (t_col * wl.d), 'extrapolated from %d columns at N=%d (%.0f us/column x D)' % (
-                cols, wl.n, t_col * 1e6)
-        if isinstance(wl, KrumC2):
-            g = rng.standard_normal((wl.n, wl.d)).astype(np.float32)
-            t0, rounds = time.perf_counter(), 0
-            while time.perf_counter() - t0 < t_budget or rounds == 0:
-                faithful.krum(g, wl.n, wl.f)
-                rounds += 1
-            return rounds / (time.perf_counter() - t0), 'full rounds: %d in the budget' % rounds
-        if isinstance(wl, AttackOnly):
-            m = min(wl.m, 64)
-            g = rng.standard_normal((m, min(wl.d, 1 << 20))).astype(np.float32)
-            t0, rounds = time.perf_counter(), 0
-            while time.perf_counter() - t0 < 0.5 * t_budget or rounds == 0:
-                faithful.drift_vector(g, 1.5)
-                rounds += 1
-            per = (time.perf_counter() - t0) / rounds
-            per *= (wl.m / m) * (wl.d / g.shape[1])
-            return 1.0 / per, 'extrapolated linearly from m=%d, D=%d' % (m, g.shape[1])
-        return None, 'n/a'
+        t_pick = time.perf_counter() - t0
+        # (iii) trimmed_mean per column over theta rows (defences.py:48-51)
+        cols = 48 if as_shipped else 400
+        sub = rng.standard_normal((theta, cols)).astype(np.float32)
+        t0 = time.perf_counter()
+        (shipped if as_shipped else faithful).trimmed_mean(sub, theta, 2 * f)
+        t_col = (time.perf_counter() - t0) / cols
+        # picks shrink: pick t scores n - t rows of n - t - 1 distances
+        pick_total = sum(t_pick * ((n - t) / n) ** 2 for t in range(theta))
+        total = t_pair * n * (n - 1) / 2 + pick_total + t_col * d + (t_pick if wl.with_attack else 0.0)
+        return total, ('extrapolated: %.1f ms per distance at D=%d x N(N-1)/2 (%d timed); one Krum pick at N=%d %.2f s x '
+                       'theta picks with the (n_t/N)^2 shrink; trimmed_mean %.0f us per column at theta=%d x D (%d timed)'
+                       % (t_pair * 1e3, d, pairs, n, t_pick, t_col * 1e6, theta, cols))
 
-    if threadpool_limits is not None:
-        with threadpool_limits(limits=1):
-            value, sample = run()
-    else:
-        value, sample = run()
-    return {'value': value, 'unit': 'rounds/s', 'cores': 1, 'kind': 'port', 'sample': sample,
-            'host_cores_available': os.cpu_count()}
+    def measure(threads, as_shipped, seconds):
+        def run():
+            if isinstance(wl, BulyanSharded):
+                total, sample = bulyan_parts(threads, as_shipped, seconds)
+                return 1.0 / total, sample
+            if isinstance(wl, TrimmedMeanC3):
+                cols = 24 if as_shipped else 200
+                sub = rng.standard_normal((wl.n, cols)).astype(np.float32)
+                fn = (shipped if as_shipped else faithful).trimmed_mean
+                t, reps = timed(lambda: fn(sub, wl.n, wl.c), seconds)
+                return 1.0 / (t / cols * wl.d), 'extrapolated from %d columns at N=%d (%.0f us/column x D)' % (
+                    cols * reps, wl.n, t / cols * 1e6)
+            if isinstance(wl, KrumC2):
+                g = rng.standard_normal((wl.n, wl.d)).astype(np.float32)
+                fn = (shipped if as_shipped else faithful).krum
+                t, reps = timed(lambda: fn(g, wl.n, wl.f), seconds)
+                return 1.0 / t, 'full rounds: %d timed' % reps
+            if isinstance(wl, AttackOnly):
+                m = min(wl.m, 64)
+                g = rng.standard_normal((m, min(wl.d, 1 << 20))).astype(np.float32)
+                t, reps = timed(lambda: faithful.drift_vector(g, 1.5), 0.5 * seconds)
+                return 1.0 / (t * (wl.m / m) * (wl.d / g.shape[1])), 'extrapolated linearly from m=%d, D=%d' % (m, g.shape[1])
+            return None, 'n/a'
+        if threadpool_limits is not None:
+            with threadpool_limits(limits=threads):
+                return run()
+        return run()
+
+    value, sample = measure(1, False, 0.45 * t_budget)
+    out = {'value': value, 'unit': 'rounds/s', 'cores': 1, 'kind': 'port', 'sample': sample,
+           'host_cores_available': cores, 'also': {}}
+    many = min(cores, 64)     # scipy-openblas is built for up to 64 threads
+    v2, s2 = measure(many, False, 0.25 * t_budget)
+    out['also']['port_all_cores'] = {'value': v2, 'unit': 'rounds/s', 'cores': many, 'kind': 'port', 'sample': s2,
+                                     'note': 'OPENBLAS threads = %d; only sdot inside np.linalg.norm is threaded' % many}
+    if not isinstance(wl, AttackOnly):
+        v3, s3 = measure(1, True, 0.3 * t_budget)
+        out['also']['as_shipped'] = {'value': v3, 'unit': 'rounds/s', 'cores': 1, 'kind': 'port', 'sample': s3,
+                                     'note': "oracle.shipped: the reference's own loops (dict of dicts, sorted(), Python "
+                                             'sum, sorted(key=abs)), restated because /root/reference is not on this box'}
+    return out
 
 
 # ---- main -----------------------------------------------------------------------------------------
@@ -492,7 +550,8 @@ def main():
         n = args.clients or (4000 if args.workload == 'c4' else 10000)
         # c5s: the slice of configs[4] one GPU of eight would hold (25M/8 columns) -- 125 GB
         d_total = args.params or (10_000_000 if args.workload == 'c4' else 3_125_000 * world)
-        wl = BulyanSharded(torch, agg, eng, n, d_total, device, 1237, with_attack=args.workload == 'c5s')
+        primary = 'columns' if args.layout == 'both' else args.layout
+        wl = BulyanSharded(torch, agg, eng, n, d_total, device, 1237, with_attack=args.workload == 'c5s', layout=primary)
     elif args.workload == 'c3':
         wl = TrimmedMeanC3(torch, eng, args.clients or 1000, args.params or 1_000_000, device, 1236)
     elif args.workload == 'c2':
@@ -500,8 +559,13 @@ def main():
     else:
         wl = AttackOnly(torch, eng, args.clients or 2400, args.params or 4_000_000, device, 1238)
 
+    agg.comm_report()     # drop whatever the set-up booked
     elapsed, per_kernel = timed_steps(torch, dist, wl, eng, args.steps, args.warmup, world)
     ms_per_step = elapsed / args.steps * 1e3
+    # the timed steps' collectives: bytes THIS rank received and the time its compute stream spent in (or, for the
+    # overlapped gathers, waiting for) each of them, per step
+    collectives = {k: {'calls_per_step': v['calls'] / args.steps, 'MB_per_step': v['bytes'] / args.steps / 1e6,
+                       'ms_per_step': v['ms'] / args.steps} for k, v in agg.comm_report().items()}
     line = {
         'metric': 'aggregation rounds/sec at N clients x D params (%s)' % wl.defence,
         'value': args.steps / elapsed, 'unit': 'rounds/s', 'n_gpus': args.gpus, 'steps': args.steps,
@@ -510,13 +574,29 @@ def main():
         'config': wl.config(),
         'roofline': roofline_of(wl, per_kernel, traffic),
         'kernels': kernel_table(per_kernel, args.steps),
+        'collectives': collectives,
     }
+    if args.workload in ('c4', 'c5s') and (args.layout == 'both' or (world > 1 and args.layout == 'columns'
+                                                                    and os.environ.get('BYZ_BENCH_ONE_LAYOUT') != '1')):
+        # the other layout, same K steps: north_star names client sharding with an all-gather of row tiles; which one is
+        # faster is a measurement, so every multi-GPU run records both
+        other_name = 'clients' if wl.layout == 'columns' else 'columns'
+        del wl.g
+        torch.cuda.empty_cache()
+        other = BulyanSharded(torch, agg, eng, n, d_total, device, 1237, with_attack=args.workload == 'c5s', layout=other_name)
+        agg.comm_report()
+        e2, pk2 = timed_steps(torch, dist, other, eng, args.steps, args.warmup, world)
+        line['other_layout'] = {
+            'layout': other_name, 'value': args.steps / e2, 'unit': 'rounds/s', 'ms_per_step': e2 / args.steps * 1e3,
+            'config': other.config(), 'roofline': roofline_of(other, pk2, None), 'kernels': kernel_table(pk2, args.steps),
+            'collectives': {k: {'calls_per_step': v['calls'] / args.steps, 'MB_per_step': v['bytes'] / args.steps / 1e6,
+                                'ms_per_step': v['ms'] / args.steps} for k, v in agg.comm_report().items()}}
+        wl = other
 
     if rank == 0 and world == 1:
         if not args.no_cpu_baseline:
             line['cpu_baseline'] = cpu_baseline(wl, args.cpu_seconds)
         if not args.no_extras and args.workload == 'c4':
-            del wl.g
             wl.g = None
             torch.cuda.empty_cache()
             extras = {}

@@ -127,6 +127,10 @@ int byz_trimmed_mean_dev(byz_ctx* ctx, const float* G_dev, int64_t n_rows, int64
                          int64_t ld, const int32_t* row_index_dev, int64_t corrupted_count,
                          float* out_dev, void* stream);
 
+/* 16-column tiles of the last byz_trimmed_mean_dev (or Bulyan second stage) that the fast ring selection */
+/* handed to the general kernel (ties at the window edge, outliers, non-finite values); synchronises.    */
+int byz_trimmed_mean_redone(byz_ctx* ctx, int64_t* tiles_host, void* stream);
+
 /* ---- defences.bulyan (reference defences.py:55-70) ------------------------------------- */
 /* Selection loop on a distance matrix: theta = users_count - 2*corrupted_count picks, each */
 /* the Krum winner among the rows still present.  Exact fp64 running scores pick the winner  */

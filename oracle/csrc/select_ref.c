@@ -175,3 +175,37 @@ int ref_bulyan_selection(const float* dist, int n, int64_t users_count, int64_t 
     free(t.sorted);
     return made;
 }
+
+/* Spot check of a selection too long to recompute: for every listed pick t the rows selection[0..t-1] are removed
+ * and the reference's pick among the rest (defences.py:26-37, one full scoring pass) must be selection[t].
+ * Returns the number of listed picks that disagree; first_bad gets the first such pick (or -1).
+ * If every pick of a selection passes, the selection IS the reference's (induction over t); a sample of picks at a
+ * size where all of them cannot be afforded is evidence, not proof, and the tests say which one they ran. */
+int ref_verify_picks(const float* dist, int n, int64_t users_count, int64_t corrupted, int mode, const int32_t* selection,
+                     int theta, const int32_t* picks, int n_picks, int32_t* first_bad, int32_t* expected) {
+    table_t t;
+    if (build_table(dist, n, &t)) return -2;
+    uint8_t* removed = (uint8_t*)calloc((size_t)n, 1);
+    double* scores = (double*)malloc((size_t)n * sizeof(double));
+    int bad = 0;
+    *first_bad = -1;
+    *expected = -1;
+    for (int k = 0; k < n_picks; ++k) {
+        const int at = picks[k];
+        if (at < 0 || at >= theta) continue;
+        memset(removed, 0, (size_t)n);
+        for (int q = 0; q < at; ++q) removed[selection[q]] = 1;
+        const int idx = pick(&t, removed, n - at, users_count - at, corrupted, mode, scores, NULL);
+        if (idx != selection[at]) {
+            if (bad == 0) {
+                *first_bad = at;
+                *expected = idx;
+            }
+            ++bad;
+        }
+    }
+    free(scores);
+    free(removed);
+    free(t.sorted);
+    return bad;
+}

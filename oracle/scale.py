@@ -35,11 +35,20 @@ def _load():
     global _lib
     if _lib is None:
         build()
+        # a container's CPU quota can be far below what nproc reports: spinning OpenMP barriers on oversubscribed cores
+        # turn seconds into tens of minutes, so the team is capped and made to sleep at barriers
+        os.environ.setdefault('OMP_WAIT_POLICY', 'PASSIVE')
         lib = ctypes.CDLL(LIB)
         i64, vp = ctypes.c_int64, ctypes.c_void_p
         lib.ref_krum_pick.argtypes = [vp, ctypes.c_int, i64, i64, ctypes.c_int, vp, vp]
         lib.ref_bulyan_selection.argtypes = [vp, ctypes.c_int, i64, i64, ctypes.c_int, vp, vp]
         lib.ref_set_threads.argtypes = [ctypes.c_int]
+        lib.ref_verify_picks.argtypes = [vp, ctypes.c_int, i64, i64, ctypes.c_int, vp, ctypes.c_int, vp, ctypes.c_int, vp, vp]
+        try:
+            usable = len(os.sched_getaffinity(0))
+        except AttributeError:
+            usable = os.cpu_count() or 1
+        lib.ref_set_threads(max(1, min(usable, int(os.environ.get('BYZ_ORACLE_THREADS', '32')))))
         _lib = lib
     return _lib
 
@@ -84,3 +93,18 @@ def bulyan_selection(dist, users_count, corrupted_count, mode='faithful', with_m
         raise KeyError(-1)
     picked = sel[:theta].tolist()
     return (picked, margins[:theta]) if with_margins else picked
+
+
+def verify_picks(dist, users_count, corrupted_count, selection, picks, mode='faithful'):
+    """For every pick index in `picks`: remove selection[:t], run the reference's scoring pass over the rest
+    (defences.py:26-37) and compare its winner with selection[t].  Returns (mismatches, first_bad_pick, expected_row).
+    One pick costs O(N^2); a whole selection O(theta N^2) -- use bulyan_selection for that."""
+    d = _dense(dist)
+    sel = np.ascontiguousarray(selection, dtype=np.int32)
+    picks = np.ascontiguousarray(picks, dtype=np.int32)
+    first_bad, expected = ctypes.c_int32(-1), ctypes.c_int32(-1)
+    bad = _load().ref_verify_picks(d.ctypes.data, d.shape[0], int(users_count), int(corrupted_count), _MODES[mode],
+                                   sel.ctypes.data, len(sel), picks.ctypes.data, len(picks),
+                                   ctypes.addressof(first_bad), ctypes.addressof(expected))
+    assert bad >= 0
+    return bad, first_bad.value, expected.value

@@ -111,6 +111,28 @@ def test_golden_attack(eng, golden, case):
     assert all(u.grads is users[0].grads for u in users) == bool(c['aliased'])
 
 
+@pytest.mark.parametrize('name', ['NoDefense', 'Krum', 'TrimmedMean', 'Bulyan'])
+def test_golden_dropin_rounds(defences, name):
+    """Two rounds of `Server.defend` (server.py:86-90) on the matrices the UNMODIFIED reference main loop produced
+    (recorded by tests/test_dropin_reference.py where /root/reference exists): the drop-in `defences.defend[...]` call
+    of server.py:87 with its exact arguments, then the momentum step, must land on the reference's weights."""
+    import os
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'dropin_rounds.npz')
+    z = np.load(path)
+    mal_prop, momentum, learning_rate = float(z['mal_prop']), 0.9, 0.1
+    weights = z['weights_start'].copy()
+    velocity = np.zeros_like(weights)
+    for e, key in enumerate(('round0_grads', '%s/round1_grads' % name)):
+        users_grads = z[key]
+        n = len(users_grads)
+        before = users_grads.copy()
+        current_grads = defences.defend[name](users_grads, n, int(n * mal_prop))        # server.py:87
+        velocity = momentum * velocity - learning_rate * current_grads                      # server.py:89
+        weights += velocity                                                                # server.py:90
+        assert np.array_equal(users_grads, before)
+        assert np.allclose(weights, z['%s/weights%d' % (name, e)], rtol=1e-5, atol=1e-6), (name, e)
+
+
 def test_assertions_like_the_reference(defences):
     g = gaussian(1, 6, 10)
     with pytest.raises(AssertionError):

@@ -49,13 +49,34 @@ def scaled(seed, n, d):
 
 
 # ---- selection on a given distance matrix: the reference's decisions, bit for bit ----------------------
+FULL_ORACLE_MAX = 4000     # the whole selection is recomputed by the C oracle up to here (O(theta N^2))
+
+
+def sampled_picks(theta, every=40):
+    return np.unique(np.concatenate([np.arange(0, theta, every), np.arange(min(12, theta)),
+                                     np.arange(max(theta - 12, 0), theta)])).astype(np.int32)
+
+
+def check_selection(dist, n, f, got):
+    """Every pick against the reference's arithmetic up to FULL_ORACLE_MAX rows; beyond that every 40th pick plus both
+    ends (each check removes the picks before it and runs the reference's full scoring pass, defences.py:26-37)."""
+    theta = n - 2 * f
+    assert len(got) == theta and len(set(got)) == theta
+    if n <= FULL_ORACLE_MAX:
+        want = scale.bulyan_selection(dist, n, f)
+        assert got == want, 'first difference at pick %d' % next(i for i, (a, b) in enumerate(zip(got, want)) if a != b)
+    else:
+        picks = sampled_picks(theta)
+        bad, first, expected = scale.verify_picks(dist, n, f, got, picks)
+        assert bad == 0, 'pick %d: reference picks row %d, got %d (%d of %d sampled picks differ)' % (
+            first, expected, got[first], bad, len(picks))
+
+
 @pytest.mark.parametrize('n', [200, 333, 640, 1000, 1500, 2049, 4000, 8000, 10000])
 def test_bulyan_selection_is_the_reference_selection(eng, n):
     f = int(n * MAL_PROP)
     dist = point_distances(4100 + n, n)
-    want = scale.bulyan_selection(dist, n, f)
-    got = eng.bulyan_select(dist, n, f).tolist()
-    assert got == want, 'first difference at pick %d' % next(i for i, (a, b) in enumerate(zip(got, want)) if a != b)
+    check_selection(dist, n, f, eng.bulyan_select(dist, n, f).tolist())
     assert eng.krum_select(dist, n, f) == scale.krum_pick(dist, n, f)
 
 
@@ -65,8 +86,9 @@ def test_bulyan_selection_with_the_attack_ties(eng, n):
     1, 0, 2, ... decides, in the reference and here."""
     f = int(n * MAL_PROP)
     dist = point_distances(4200 + n, n, identical=f)
-    want = scale.bulyan_selection(dist, n, f)
-    assert eng.bulyan_select(dist, n, f).tolist() == want
+    got = eng.bulyan_select(dist, n, f).tolist()
+    check_selection(dist, n, f, got)
+    print('N=%d with %d identical rows: %d rows re-scored in fp32 over %d picks' % (n, f, eng.bulyan_rescored(), n - 2 * f))
     assert eng.krum_select(dist, n, f) == scale.krum_pick(dist, n, f)
 
 
@@ -174,7 +196,7 @@ def test_config5_flow_n10000(eng):
     # the reference's decisions on this matrix
     assert eng.krum_select(dist, n, f) == scale.krum_pick(dist_host, n, f)
     sel = eng.bulyan_select(dist, n, f).tolist()
-    assert sel == scale.bulyan_selection(dist_host, n, f)
+    check_selection(dist_host, n, f, sel)
     out = eng.trimmed_mean(g, n, 2 * f, row_index=np.asarray(sel, dtype=np.int32)).cpu().numpy()
     cols = np.random.default_rng(1).choice(d, 48, replace=False)
     assert close(out[cols], faithful.trimmed_mean(g_host[sel][:, cols], len(sel), 2 * f))
@@ -211,7 +233,7 @@ def test_drift_hook_called_directly(eng):
     want[:] -= 1.5 * std[:]
     att = malicious.DriftAttack(1.5)
     got = att._attack_grads(mean, std, None, None)
-    assert got is mean and np.allclose(got, want, rtol=1e-6, atol=1e-7)
+    assert got is mean and np.allclose(got, want, rtol=1e-6, atol=1e-6)   # one fused multiply-add vs numpy's two roundings
 
 
 def test_distances_to_dict_is_the_reference_dict(eng):
@@ -222,3 +244,39 @@ def test_distances_to_dict_is_the_reference_dict(eng):
     dense = d.numpy()
     assert all(as_dict[i][j] == dense[i, j] for i in range(9) for j in range(9) if i != j)
     assert all(i not in as_dict[i] for i in range(9))
+
+
+# ---- the ring selection of the trimmed mean (256 .. 2560 rows) and its hand-over to the general kernel --------------
+@pytest.mark.parametrize('n,c', [(256, 60), (1000, 200), (1000, 0), (1000, 998), (1537, 300), (2080, 1920), (2560, 1000)])
+def test_ring_selection_resolves_continuous_columns(eng, n, c):
+    """Continuous data: (nearly) every tile is resolved by the one-histogram ring selection, and the answer is the
+    reference's.  A few columns per thousand have exact +t / -t ties at the window edge and go the general way."""
+    torch = pytest.importorskip('torch')
+    d = 4096
+    g = scaled(5000 + n + c, n, d)
+    gt = torch.from_numpy(g).cuda()
+    got = eng.trimmed_mean(gt, n, c).cpu().numpy()
+    redone = eng.trimmed_mean_redone()
+    assert close(got, ideal.trimmed_mean(g, c))
+    cols = np.random.default_rng(2).choice(d, 40, replace=False)
+    assert close(got[cols], faithful.trimmed_mean(g[:, cols], n, c))
+    assert redone <= max(2, (d // 16) // 20), 'ring selection handed %d of %d tiles back' % (redone, d // 16)
+
+
+def test_ring_selection_hands_hard_tiles_to_the_general_kernel(eng):
+    """Quantised columns (ties everywhere), a constant column, outliers and a NaN: all beyond the ring selection."""
+    n, d = 1000, 640
+    rng = np.random.default_rng(5100)
+    g = rng.standard_normal((n, d)).astype(np.float32)
+    g[:, 0:64] = np.round(g[:, 0:64] * 4) / 4           # exact ties at the window edge
+    g[:, 64:80] = 1.25                                   # constant columns
+    g[5, 100:140] = 1e30                                 # outliers squeeze everything into one bucket
+    g[7, 200] = np.nan
+    g[:300, 300:340] = g[0, 300:340]                     # 300 identical clients (the attack): more than one sort holds
+    got = eng.trimmed_mean(g, n, 200)
+    assert eng.trimmed_mean_redone() >= 10
+    want = faithful.trimmed_mean(g, n, 200)
+    assert np.isnan(got[200]) and np.isnan(want[200])
+    ok = np.ones(d, dtype=bool)
+    ok[200] = False
+    assert close(got[ok], want[ok])

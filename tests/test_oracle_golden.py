@@ -133,3 +133,19 @@ def test_batched_client_step_matches_on_cpu_tensors(golden):
     grads = per_client_gradients(clients.MnistNet(), c['weights'], data, torch.from_numpy(c['target']))
     assert [tuple(g.shape) for g in grads] == [(3, 100, 784), (3, 100), (3, 10, 100), (3, 10)]
     check_client_rows(np.concatenate([g.reshape(3, -1).numpy() for g in grads], axis=1), c)
+
+
+def test_the_loops_as_shipped_equal_the_vectorised_restatement():
+    """oracle.shipped (dicts, sorted, sum, key=abs: what bench.py times as "reference as shipped") against
+    oracle.faithful, bit for bit."""
+    from oracle import shipped
+    rng = np.random.default_rng(77)
+    g = rng.standard_normal((19, 300)).astype(np.float32)
+    g[:4] = g[0]
+    n, f = 19, 4
+    assert shipped.krum(g, n, f, return_index=True) == faithful.krum(g, n, f, return_index=True)
+    assert np.array_equal(shipped.trimmed_mean(g, n, f), faithful.trimmed_mean(g, n, f))
+    assert np.array_equal(shipped.bulyan(g, n, f), faithful.bulyan(g, n, f))
+    d = shipped.dict_from_dense(faithful.distance_matrix(g))
+    assert list(d.keys()) == faithful.visit_order(n)
+    assert shipped.krum(g, n, f, distances=d, return_index=True) == faithful.krum(g, n, f, return_index=True)

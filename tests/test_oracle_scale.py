@@ -82,3 +82,14 @@ def test_no_winner_raises_like_the_reference():
         scale.bulyan_selection(dist, 5, 0)
     with pytest.raises(KeyError):
         faithful.bulyan_selection(dist, 5, 0)
+
+
+def test_verify_picks_agrees_with_the_full_selection():
+    n, f = 120, 28
+    dist = point_distances(21, n)
+    sel = scale.bulyan_selection(dist, n, f)
+    assert scale.verify_picks(dist, n, f, sel, np.arange(len(sel))) == (0, -1, -1)
+    wrong = list(sel)
+    wrong[30], wrong[31] = wrong[31], wrong[30]
+    bad, first, expected = scale.verify_picks(dist, n, f, wrong, np.arange(len(sel)))
+    assert bad >= 1 and first == 30 and expected == sel[30]
