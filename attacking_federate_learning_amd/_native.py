@@ -8,7 +8,7 @@ LIB_PATH = os.path.join(_HERE, 'libbyzagg.so')
 OK, E_INVALID, E_PRECONDITION, E_HIP, E_UNSUPPORTED, E_NO_WINNER = 0, -1, -2, -3, -4, -5
 
 KERNELS = ('column_stats', 'gram_tile', 'gram_reduce', 'distances', 'row_sort', 'krum_argmin',
-           'bulyan_loop', 'trimmed_mean', 'misc')
+           'bulyan_loop', 'trimmed_mean', 'misc', 'plane_split')
 
 c_i64, c_i32, c_int, c_f32, c_vp = ctypes.c_int64, ctypes.c_int32, ctypes.c_int, ctypes.c_float, ctypes.c_void_p
 _P = ctypes.POINTER

@@ -171,6 +171,8 @@ void byz_ctx_destroy(byz_ctx* ctx) {
     ctx->tile_order.release();
     ctx->tile_owned.release();
     ctx->gram_tickets.release();
+    ctx->gram_planes.release();
+    ctx->plane_order.release();
     ctx->dup_rep.release();
     ctx->row_signature.release();
     ctx->unique_rows.release();
@@ -617,7 +619,7 @@ int byz_drift_attack_host(byz_ctx* ctx, const float* rows_host, int64_t n_rows, 
 // ---- timing --------------------------------------------------------------------------------------
 static const char* const kKernelNames[BYZ_K_COUNT] = {
     "column_stats", "gram_tile", "gram_reduce", "distances", "row_sort",
-    "krum_argmin",  "bulyan_loop", "trimmed_mean", "misc"};
+    "krum_argmin",  "bulyan_loop", "trimmed_mean", "misc", "plane_split"};
 
 const char* byz_kernel_name(int kernel) {
     return (kernel >= 0 && kernel < BYZ_K_COUNT) ? kKernelNames[kernel] : "?";

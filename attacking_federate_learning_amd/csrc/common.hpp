@@ -99,6 +99,11 @@ struct byz_ctx {
     byz::Buffer tile_order;      // (ti, tj) of every lower-triangle tile, in XCD-friendly order
     byz::Buffer dup_rep;         // representative row of every group of identical rows (+ one flag word)
     byz::Buffer gram_tickets;    // chunked Gram schedule: next chunk allowed to update a tile's slab
+    byz::Buffer gram_planes;     // pre-split Gram: the bf16 planes of one super-chunk of columns, in MFMA fragment order
+    byz::Buffer plane_order;     // pre-split Gram: (256-row block, 128-row block) of every workgroup tile
+    std::vector<int32_t> plane_order_host;
+    int64_t plane_order_T = -1;
+    int64_t plane_order_share = 1 * 65536 + 0;
     byz::Buffer row_signature;   // dedup: 64-bit signature of every row
     byz::Buffer unique_rows;     // dedup: the unique rows, ascending
     byz::Buffer row_map;         // dedup: position of every row's representative among the unique rows (+ scratch)
@@ -211,6 +216,10 @@ int launch_assemble_columns(byz_ctx* ctx, float* G, int64_t n_rows, int64_t n_co
 
 int launch_gram(byz_ctx* ctx, const float* G, int64_t n_rows, int64_t n_cols, int64_t ld, double* gram,
                 hipStream_t stream);
+// gram_planes.hip: the long-K Gram on operands split once into bf16 planes
+bool gram_planes_enabled();
+int launch_gram_planes(byz_ctx* ctx, const float* G, int64_t n_rows, int64_t n_cols, int64_t ld, const int32_t* row_index,
+                       double* slabs, int share_count, int share_index, uint8_t* owned_host, hipStream_t stream);
 int launch_gram_share(byz_ctx* ctx, const float* G, int64_t n_rows, int64_t n_cols, int64_t ld, const int32_t* row_index,
                       int share_count, int share_index, double* gram, hipStream_t stream);
 // dedup.hip: identical rows found before the Gram

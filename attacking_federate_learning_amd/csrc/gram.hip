@@ -852,7 +852,21 @@ static int launch_gram_rows(byz_ctx* ctx, const float* G, int64_t n_rows, int64_
         set_error("gram: grid too large");
         return BYZ_E_UNSUPPORTED;
     }
-    {
+    // long K and many tiles in split arithmetic: the operands are split ONCE into bf16 planes (gram_planes.hip) instead
+    // of once per tile; same arithmetic, bitwise the same slabs
+    const bool planes = chunked && split_mode && chunk_stages * BK == 8192 && gram_planes_enabled();
+    if (planes) {
+        std::vector<uint8_t> owned;
+        if (share_count > 1) owned.assign(static_cast<size_t>(n_tiles_all), 0);
+        BYZ_TRY(launch_gram_planes(ctx, G, n_rows, n_cols, ld, row_index, ctx->gram_partials.as<double>(), share_count,
+                                   share_index, share_count > 1 ? owned.data() : nullptr, stream));
+        if (share_count > 1) {
+            BYZ_TRY(ctx->tile_owned.ensure(owned.size()));
+            BYZ_HIP(hipMemcpyAsync(ctx->tile_owned.ptr, owned.data(), owned.size(), hipMemcpyHostToDevice, stream));
+            BYZ_HIP(hipStreamSynchronize(stream));   // pageable host vector
+            ctx->tile_order_T = -1;                   // tile_owned no longer describes the fused kernel's list
+        }
+    } else {
         KernelTimer t(ctx, BYZ_K_GRAM, stream);
         const int2* order = ctx->tile_order.as<int2>();
         const int round_size = env_int("BYZ_GRAM_ROUND", ctx->num_cus / 8 * 2);   // workgroups an XCD holds at a time

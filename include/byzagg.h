@@ -215,7 +215,7 @@ int byz_drift_attack_host(byz_ctx* ctx, const float* rows_host, int64_t n_rows, 
 enum {
     BYZ_K_COLUMN_STATS = 0, BYZ_K_GRAM = 1, BYZ_K_GRAM_REDUCE = 2, BYZ_K_DISTANCES = 3,
     BYZ_K_ROW_SORT = 4, BYZ_K_KRUM_ARGMIN = 5, BYZ_K_BULYAN_LOOP = 6, BYZ_K_TRIMMED_MEAN = 7,
-    BYZ_K_MISC = 8, BYZ_K_COUNT = 9
+    BYZ_K_MISC = 8, BYZ_K_PLANE_SPLIT = 9, BYZ_K_COUNT = 10
 };
 int byz_timing_enable(byz_ctx* ctx, int on);
 int byz_timing_reset(byz_ctx* ctx);

@@ -1,0 +1,38 @@
+"""Step-by-step check of the plane Gram against the fused one (development aid; prints as it goes)."""
+import os, sys, time
+t0 = time.time()
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+print('%.1fs torch imported' % (time.time() - t0), flush=True)
+from attacking_federate_learning_amd.engine import get_engine
+eng = get_engine()
+print('%.1fs engine up' % (time.time() - t0), flush=True)
+cases = [(2900, 3 * 8192 + 100, 0), (3000, 5 * 8192, 0), (3300, 2 * 8192 + 33 * 32 + 4, 700), (4000, 20 * 8192 + 36, 0)]
+variants = sys.argv[1:] or ['0', '3']
+for n, d, dup in cases:
+    gen = torch.Generator(device='cuda').manual_seed(900 + n)
+    g = torch.randn((n, d), generator=gen, device='cuda', dtype=torch.float32)
+    g *= (1.0 + 0.5 * torch.rand((n, 1), generator=gen, device='cuda'))
+    if dup:
+        g[torch.randperm(n, device='cuda')[:dup]] = g[7].clone()
+    os.environ['BYZ_GRAM_PLANES'] = '0'
+    fused = eng.gram(g).clone()
+    torch.cuda.synchronize()
+    print('%.1fs case %s fused done' % (time.time() - t0, (n, d, dup)), flush=True)
+    os.environ['BYZ_GRAM_PLANES'] = '1'
+    for v in variants:
+        os.environ['BYZ_GRAM_PLANES_VARIANT'] = v
+        for mb in (None, '400'):
+            if mb:
+                os.environ['BYZ_GRAM_PLANE_MB'] = mb
+            else:
+                os.environ.pop('BYZ_GRAM_PLANE_MB', None)
+            try:
+                got = eng.gram(g)
+                torch.cuda.synchronize()
+                print('%.1fs    variant %s budget %s: equal=%s' % (time.time() - t0, v, mb, bool(torch.equal(got, fused))), flush=True)
+            except Exception as exc:
+                print('%.1fs    variant %s budget %s: ERROR %s' % (time.time() - t0, v, mb, exc), flush=True)
+    os.environ.pop('BYZ_GRAM_PLANE_MB', None)
+    del g
+print('%.1fs all done' % (time.time() - t0), flush=True)

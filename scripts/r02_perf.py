@@ -1,0 +1,69 @@
+"""Round-2 development timings (not the contract bench): plane Gram vs fused Gram, the Bulyan loop by band setting."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+from attacking_federate_learning_amd.engine import get_engine
+
+eng = get_engine()
+which = sys.argv[1:] or ['gram', 'loop']
+gen = torch.Generator(device='cuda').manual_seed(0)
+
+
+def kernel_ms(fn, iters=2, warm=1):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    eng.timing(True)
+    for _ in range(iters):
+        fn()
+    torch.cuda.synchronize()
+    out = {k: (round(v['total_ms'] / iters, 3), v['launches'] // iters) for k, v in eng.timing_read().items() if v['launches']}
+    eng.timing(False)
+    return out
+
+if 'gram' in which:
+    for n, d in ((4000, 1000000),):
+        g = torch.randn((n, d), device='cuda', generator=gen)
+        for planes in ('0', '1'):
+            os.environ['BYZ_GRAM_PLANES'] = planes
+            t = kernel_ms(lambda: eng.gram(g))
+            tile = t.get('gram_tile', (0, 0))[0]
+            print('gram N=%d D=%d planes=%s: %s  -> tile kernel %.1f TF-eq, with split %.1f TF-eq' % (
+                n, d, planes, t, float(n) * n * d / tile / 1e9, float(n) * n * d / (tile + t.get('plane_split', (0, 0))[0]) / 1e9), flush=True)
+        os.environ['BYZ_GRAM_PLANES'] = '1'
+        if 'variants' in which:
+            os.environ['BYZ_GRAM_PLANES'] = '0'
+            ref = eng.gram(g).clone()
+            os.environ['BYZ_GRAM_PLANES'] = '1'
+            for var in ('0', '1', '3', '13', '23'):
+                os.environ['BYZ_GRAM_PLANES_VARIANT'] = var
+                t = kernel_ms(lambda: eng.gram(g))
+                same = bool(torch.equal(eng.gram(g), ref)) if int(var) < 10 else None
+                print('   variant=%s: tile %.2f ms (%.1f TF-eq) split %.2f ms bitwise_equal_fused=%s' % (
+                    var, t['gram_tile'][0], float(n) * n * d / t['gram_tile'][0] / 1e9, t['plane_split'][0], same), flush=True)
+            os.environ.pop('BYZ_GRAM_PLANES_VARIANT')
+        del g
+
+if 'loop' in which:
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tests'))
+    for n in (4000, 10000):
+        f = int(n * 0.24)
+        rng = np.random.default_rng(4100 + n)
+        pts = rng.standard_normal((n, 16)).astype(np.float32)
+        pts *= (1.0 + 0.5 * rng.permutation(n) / n).astype(np.float32)[:, None]
+        p64 = pts.astype(np.float64)
+        sq = (p64 * p64).sum(1)
+        dist = np.sqrt(np.maximum(sq[:, None] + sq[None, :] - 2.0 * (p64 @ p64.T), 0.0)).astype(np.float32)
+        dist = np.minimum(dist, dist.T)
+        np.fill_diagonal(dist, np.inf)
+        ref = None
+        for band in ('rigorous', '-8', '0'):
+            os.environ['BYZ_BULYAN_BAND'] = band
+            t = kernel_ms(lambda: eng.bulyan_select(dist, n, f), iters=1, warm=1)
+            sel = eng.bulyan_select(dist, n, f).tolist()
+            if ref is None:
+                ref = sel
+            print('bulyan loop N=%d band=%s: %s rescored=%s same_as_rigorous=%s' % (
+                n, band, {k: v for k, v in t.items() if k in ('bulyan_loop', 'row_sort')}, getattr(eng, 'bulyan_rescored', lambda: '?')(), sel == ref), flush=True)
+        os.environ.pop('BYZ_BULYAN_BAND')

@@ -280,3 +280,34 @@ def test_ring_selection_hands_hard_tiles_to_the_general_kernel(eng):
     ok = np.ones(d, dtype=bool)
     ok[200] = False
     assert close(got[ok], want[ok])
+
+
+# ---- the pre-split (bf16 plane) Gram: the same arithmetic as the fused split kernel, bit for bit ---------------
+@pytest.mark.parametrize('n,d,dup', [(2900, 3 * 8192 + 100, 0), (3000, 5 * 8192, 0), (3300, 2 * 8192 + 33 * 32 + 4, 700),
+                                     (4000, 20 * 8192 + 36, 0)])
+def test_plane_gram_is_bitwise_the_fused_gram(eng, monkeypatch, n, d, dup):
+    """gram_planes.hip splits every operand once into bf16 planes (fragment order in HBM) and multiplies 256 x 128 tiles;
+    gram.hip splits inside the 128 x 128 tile kernel.  Same six terms, same chain lengths, same slab order: the fp64 Gram
+    must be IDENTICAL, with several super-chunks (a small plane budget), a ragged K tail, an odd number of slab rows,
+    and through the identical-row shortcut's row indirection."""
+    torch = pytest.importorskip('torch')
+    gen = torch.Generator(device='cuda').manual_seed(900 + n)
+    g = torch.randn((n, d), generator=gen, device='cuda', dtype=torch.float32)
+    g *= (1.0 + 0.5 * torch.rand((n, 1), generator=gen, device='cuda'))
+    if dup:
+        g[torch.randperm(n, device='cuda')[:dup]] = g[7].clone()
+    monkeypatch.setenv('BYZ_GRAM_PLANES', '0')
+    fused = eng.gram(g).clone()
+    monkeypatch.setenv('BYZ_GRAM_PLANES', '1')
+    one = eng.gram(g).clone()
+    monkeypatch.setenv('BYZ_GRAM_PLANE_MB', '400')      # two chunks of planes at a time: several super-chunks
+    many = eng.gram(g).clone()
+    assert torch.equal(fused, one), float((fused - one).abs().max())
+    assert torch.equal(fused, many), float((fused - many).abs().max())
+    rows = [0, 1, n // 2, n - 1]
+    host = g[rows].cpu().numpy().astype(np.float64)
+    want = host @ host.T
+    got = one[rows][:, rows].cpu().numpy()
+    norms = np.sqrt(np.diag(want))
+    worst = float(np.max(np.abs(got - want) / (norms[:, None] * norms[None, :])))
+    assert worst < 1e-6, worst
