@@ -173,6 +173,7 @@ void byz_ctx_destroy(byz_ctx* ctx) {
     ctx->gram_tickets.release();
     ctx->gram_planes.release();
     ctx->plane_order.release();
+    ctx->plane_unscale.release();
     ctx->dup_rep.release();
     ctx->row_signature.release();
     ctx->unique_rows.release();
@@ -186,6 +187,7 @@ void byz_ctx_destroy(byz_ctx* ctx) {
     ctx->colstat_partials.release();
     ctx->sorted_idx.release();
     ctx->rank_t.release();
+    ctx->sorted_val.release();
     ctx->row_total.release();
     ctx->row_top.release();
     ctx->scores.release();

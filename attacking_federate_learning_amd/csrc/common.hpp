@@ -100,6 +100,7 @@ struct byz_ctx {
     byz::Buffer dup_rep;         // representative row of every group of identical rows (+ one flag word)
     byz::Buffer gram_tickets;    // chunked Gram schedule: next chunk allowed to update a tile's slab
     byz::Buffer gram_planes;     // pre-split Gram: the bf16 planes of one super-chunk of columns, in MFMA fragment order
+    byz::Buffer plane_unscale;   // pre-split Gram, f16x2: 2^-shift of every (chunk, row) of the super-chunk (fp64)
     byz::Buffer plane_order;     // pre-split Gram: (256-row block, 128-row block) of every workgroup tile
     std::vector<int32_t> plane_order_host;
     int64_t plane_order_T = -1;
@@ -121,6 +122,7 @@ struct byz_ctx {
     byz::Buffer dist;            // n x n fp32 distances (when the caller does not pass one)
     byz::Buffer colstat_partials;  // row-split partial column sums
     byz::Buffer sorted_idx;      // n x n uint16: column index at every ascending rank
+    byz::Buffer sorted_val;      // n x n fp32: every row's distances in ascending order (the reference-arithmetic re-score)
     byz::Buffer rank_t;          // n x n uint16: rank_t[w][u] = rank of column w in row u
     byz::Buffer row_total;       // n fp64: sum of a row's finite distances
     byz::Buffer row_top;         // n fp64: sum of a row's largest `drop` distances
@@ -219,7 +221,7 @@ int launch_gram(byz_ctx* ctx, const float* G, int64_t n_rows, int64_t n_cols, in
 // gram_planes.hip: the long-K Gram on operands split once into bf16 planes
 bool gram_planes_enabled();
 int launch_gram_planes(byz_ctx* ctx, const float* G, int64_t n_rows, int64_t n_cols, int64_t ld, const int32_t* row_index,
-                       double* slabs, int share_count, int share_index, uint8_t* owned_host, hipStream_t stream);
+                       double* slabs, int share_count, int share_index, uint8_t* owned_host, bool f16, hipStream_t stream);
 int launch_gram_share(byz_ctx* ctx, const float* G, int64_t n_rows, int64_t n_cols, int64_t ld, const int32_t* row_index,
                       int share_count, int share_index, double* gram, hipStream_t stream);
 // dedup.hip: identical rows found before the Gram

@@ -801,7 +801,7 @@ static int launch_gram_rows(byz_ctx* ctx, const float* G, int64_t n_rows, int64_
     const char* mode_env = std::getenv("BYZ_GRAM_MODE");
     const std::string mode_s = mode_env ? mode_env : (n_tiles >= 4 ? "split" : "exact");
     const bool dma = (ld % 4 == 0) && (reinterpret_cast<uintptr_t>(G) % 16 == 0) && env_int("BYZ_GRAM_NO_DMA", 0) == 0;
-    const bool split_mode = dma && mode_s == "split";
+    const bool split_mode = dma && (mode_s == "split" || mode_s == "f16x2");   // f16x2 exists only on pre-split operands
     // chunked schedule (see the kernel): many tiles and a long K
     const int64_t chunk_stages = env_int("BYZ_GRAM_CHUNK_COLS", 8192) / BK;
     const bool chunked = n_tiles >= 256 && stages > 2 * chunk_stages && env_int("BYZ_GRAM_NO_CHUNKS", 0) == 0 &&
@@ -852,14 +852,17 @@ static int launch_gram_rows(byz_ctx* ctx, const float* G, int64_t n_rows, int64_
         set_error("gram: grid too large");
         return BYZ_E_UNSUPPORTED;
     }
-    // long K and many tiles in split arithmetic: the operands are split ONCE into bf16 planes (gram_planes.hip) instead
-    // of once per tile; same arithmetic, bitwise the same slabs
-    const bool planes = chunked && split_mode && chunk_stages * BK == 8192 && gram_planes_enabled();
+    // long K and many tiles: the operands are split ONCE into 16-bit planes (gram_planes.hip) instead of once per tile.
+    //   BYZ_GRAM_MODE unset / f16x2: two fp16 planes, three MFMAs per block (error 6e-8, see gram_planes.hip);
+    //   BYZ_GRAM_MODE=split:         three bf16 planes, bitwise the fused split kernel's slabs
+    const bool planes_ok = chunked && dma && chunk_stages * BK == 8192 && gram_planes_enabled();
+    const bool f16 = planes_ok && (mode_env == nullptr || mode_s == "f16x2");
+    const bool planes = planes_ok && (f16 || split_mode);
     if (planes) {
         std::vector<uint8_t> owned;
         if (share_count > 1) owned.assign(static_cast<size_t>(n_tiles_all), 0);
         BYZ_TRY(launch_gram_planes(ctx, G, n_rows, n_cols, ld, row_index, ctx->gram_partials.as<double>(), share_count,
-                                   share_index, share_count > 1 ? owned.data() : nullptr, stream));
+                                   share_index, share_count > 1 ? owned.data() : nullptr, f16, stream));
         if (share_count > 1) {
             BYZ_TRY(ctx->tile_owned.ensure(owned.size()));
             BYZ_HIP(hipMemcpyAsync(ctx->tile_owned.ptr, owned.data(), owned.size(), hipMemcpyHostToDevice, stream));

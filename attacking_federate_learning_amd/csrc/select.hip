@@ -48,7 +48,7 @@ template <bool TABLES>
 __global__ void row_sort_kernel(const float* __restrict__ dist, int n, int n_pad, int prefix_len, int drop,
                                 float* __restrict__ scores, uint16_t* __restrict__ sorted_idx,
                                 uint16_t* __restrict__ rank_t, double* __restrict__ row_total,
-                                double* __restrict__ row_top) {
+                                double* __restrict__ row_top, float* __restrict__ sorted_val) {
     extern __shared__ __attribute__((aligned(16))) unsigned long long keys[];  // n_pad keys, then scratch
     double* scratch = reinterpret_cast<double*>(keys + n_pad);                 // blockDim.x doubles
     const int u = blockIdx.x;
@@ -99,6 +99,7 @@ __global__ void row_sort_kernel(const float* __restrict__ dist, int n, int n_pad
             const unsigned long long key = keys[r];
             const int c = static_cast<int>(key & 0xffffffffu);
             sorted_idx[static_cast<int64_t>(u) * n + r] = static_cast<uint16_t>(c);
+            sorted_val[static_cast<int64_t>(u) * n + r] = from_ordered_bits(static_cast<uint32_t>(key >> 32));
             rank_t[static_cast<int64_t>(c) * n + u] = static_cast<uint16_t>(r);
             if (r < n - 1) {
                 const double v = static_cast<double>(from_ordered_bits(static_cast<uint32_t>(key >> 32)));
@@ -296,34 +297,65 @@ __device__ __forceinline__ bool gather_granules(const unsigned long long* slots,
     return true;
 }
 
+// both granules of a pick in one polling loop: one exchange latency instead of two
+__device__ __forceinline__ bool gather_granule_pair(const unsigned long long* slots_a, const unsigned long long* slots_b,
+                                                    int n_wgs, uint32_t tag4, uint32_t tag18, int lane,
+                                                    unsigned long long& mine_a, unsigned long long& mine_b) {
+    unsigned long long va = mine_a, vb = mine_b;
+    bool ok_a = lane >= n_wgs, ok_b = lane >= n_wgs;
+    for (unsigned spins = 0;; ++spins) {
+        if (!ok_a) {
+            va = granule_load(slots_a + lane);
+            ok_a = (static_cast<uint32_t>(va) & 15u) == tag4;
+        }
+        if (!ok_b) {
+            vb = granule_load(slots_b + lane);
+            ok_b = (static_cast<uint32_t>(vb) & 0x3ffffu) == tag18;
+        }
+        if (__ballot(!(ok_a && ok_b)) == 0ull) break;
+        if (spins > kSpinLimit) return false;
+        __builtin_amdgcn_s_sleep(1);
+    }
+    mine_a = va;
+    mine_b = vb;
+    return true;
+}
+
 // The reference's score of row u at this pick (defences.py:33-34): ascending live distances, sequential fp32 sum of
 // the first `take`.  One wave; the result is wave-uniform.  Adding +0.0 for a skipped entry is exact.
-__device__ __forceinline__ float reference_score(const float* __restrict__ dist, const uint16_t* __restrict__ sorted_idx,
+// The row's ascending values and their columns come from the tables row_sort_kernel wrote (two coalesced loads per 64
+// entries, the next 64 already in flight); the left-to-right sum runs as a DPP chain: s[l] = s[l - 1] + x[l] issued 63
+// times fixes lane l at step l, one VALU instruction per element instead of a readlane + add pair.
+__device__ __forceinline__ float reference_score(const float* __restrict__ sorted_val, const uint16_t* __restrict__ sorted_idx,
                                                  const uint32_t* removed, int n, int u, int take, int lane) {
     const uint16_t* order = sorted_idx + static_cast<int64_t>(u) * n;
-    const float* drow = dist + static_cast<int64_t>(u) * n;
-    float s = 0.0f;
+    const float* vals = sorted_val + static_cast<int64_t>(u) * n;
+    float carry = 0.0f;
     int got = 0;
+    int col_next = lane < n ? order[lane] : u;
+    float v_next = lane < n ? vals[lane] : 0.0f;
     for (int r0 = 0; r0 < n && got < take; r0 += 64) {
-        const int r = r0 + lane;
-        bool live = false;
-        float v = 0.0f;
-        if (r < n) {
-            const int col = order[r];
-            live = col != u && !((removed[col >> 5] >> (col & 31)) & 1u);
-            if (live) v = drow[col];
-        }
+        const int col = col_next;
+        const float v = v_next;
+        const int rn = r0 + 64 + lane;
+        col_next = rn < n ? order[rn] : u;
+        v_next = rn < n ? vals[rn] : 0.0f;
+        const bool live = r0 + lane < n && col != u && !((removed[col >> 5] >> (col & 31)) & 1u);
         const unsigned long long m = __ballot(live);
         if (m == 0ull) continue;
         const int before = __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(m >> 32),
                                                      __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(m), 0));
-        if (!live || got + before >= take) v = 0.0f;   // past the prefix the reference sums
+        const float x = (live && got + before < take) ? v : 0.0f;   // past the prefix the reference sums: + 0.0
         got += __popcll(m);
-        const int vb = __float_as_int(v);
+        float s = __fadd_rn(carry, x);          // lane 0 is final
+        // lanes whose source lane does not exist (lane 0) keep their value; 2 wait states between a VALU write and a
+        // DPP read of the same register
 #pragma unroll
-        for (int l = 0; l < 64; ++l) s = __fadd_rn(s, __int_as_float(__builtin_amdgcn_readlane(vb, l)));
+        for (int l = 1; l < 64; ++l)
+            asm volatile("s_nop 1\n\tv_add_f32_dpp %0, %0, %1 wave_shr:1 row_mask:0xf bank_mask:0xf" : "+v"(s) : "v"(x));
+        carry = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(s), 63));
     }
-    return s;
+    return carry;
 }
 
 struct GridDecision {
@@ -334,7 +366,7 @@ struct GridDecision {
 
 __global__ __launch_bounds__(kGridThreads) void bulyan_grid_kernel(
     const float* __restrict__ dist, int n, int theta, int drop, int users_count, int corrupted,
-    const uint16_t* __restrict__ sorted_idx, const uint16_t* __restrict__ rank_t,
+    const uint16_t* __restrict__ sorted_idx, const uint16_t* __restrict__ rank_t, const float* __restrict__ sorted_val,
     const double* __restrict__ row_total, const double* __restrict__ row_top, const int32_t* __restrict__ cls,
     unsigned long long* __restrict__ xchg, float band_scale, int32_t* __restrict__ selection,
     int32_t* __restrict__ status, int32_t* __restrict__ rescored) {
@@ -406,9 +438,7 @@ __global__ __launch_bounds__(kGridThreads) void bulyan_grid_kernel(
                     granule_store(slot(parity, 1) + wg, gb | tag18);
                 }
                 unsigned long long va = none_a, vb = static_cast<unsigned long long>(kInfBits) << 32;
-                ok = gather_granules(slot(parity, 0), n_wgs, 15u, tag, lane, none_a, va);
-                ok = ok && gather_granules(slot(parity, 1), n_wgs, 0x3ffffu, tag18, lane,
-                                           static_cast<unsigned long long>(kInfBits) << 32, vb);
+                ok = gather_granule_pair(slot(parity, 0), slot(parity, 1), n_wgs, tag, tag18, lane, va, vb);
                 ga = va;
                 gb = vb;
             } else if (lane != 0) {
@@ -477,7 +507,7 @@ __global__ __launch_bounds__(kGridThreads) void bulyan_grid_kernel(
             Candidate r{static_cast<double>(kKrumInit), 0x7fffffff, -1};
             for (int k = wave; k < n_lead; k += kGridThreads / 64) {
                 const int row = wg * kGridThreads + leaders[k];
-                const float s32 = reference_score(dist, sorted_idx, removed, n, row, take, lane);
+                const float s32 = reference_score(sorted_val, sorted_idx, removed, n, row, take, lane);
                 if (s32 < kKrumInit) {
                     Candidate o{static_cast<double>(s32), visit_position(row), row};
                     if (better(o, r)) r = o;
@@ -573,6 +603,7 @@ int launch_row_sort(byz_ctx* ctx, const float* dist, int64_t n, int64_t prefix_l
         BYZ_TRY(ctx->rank_t.ensure(static_cast<size_t>(n) * n * sizeof(uint16_t)));
         BYZ_TRY(ctx->row_total.ensure(static_cast<size_t>(n) * sizeof(double)));
         BYZ_TRY(ctx->row_top.ensure(static_cast<size_t>(n) * sizeof(double)));
+        BYZ_TRY(ctx->sorted_val.ensure(static_cast<size_t>(n) * n * sizeof(float)));
     }
     const size_t lds = static_cast<size_t>(n_pad) * 8 + static_cast<size_t>(threads) * 8;
     KernelTimer t(ctx, BYZ_K_ROW_SORT, stream);
@@ -582,13 +613,13 @@ int launch_row_sort(byz_ctx* ctx, const float* dist, int64_t n, int64_t prefix_l
         row_sort_kernel<true><<<static_cast<unsigned>(n), threads, lds, stream>>>(
             dist, (int)n, (int)n_pad, (int)prefix_len, (int)drop_count, ctx->scores.as<float>(),
             ctx->sorted_idx.as<uint16_t>(), ctx->rank_t.as<uint16_t>(), ctx->row_total.as<double>(),
-            ctx->row_top.as<double>());
+            ctx->row_top.as<double>(), ctx->sorted_val.as<float>());
     } else {
         BYZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&row_sort_kernel<false>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
         row_sort_kernel<false><<<static_cast<unsigned>(n), threads, lds, stream>>>(
             dist, (int)n, (int)n_pad, (int)prefix_len, (int)drop_count, ctx->scores.as<float>(), nullptr,
-            nullptr, nullptr, nullptr);
+            nullptr, nullptr, nullptr, nullptr);
     }
     return check_launch("row_sort_kernel");
 }
@@ -625,7 +656,7 @@ int launch_bulyan_loop(byz_ctx* ctx, const float* dist, int64_t n, int64_t theta
     const unsigned n_wgs = static_cast<unsigned>(ceil_div(n, kGridThreads));   // <= 64: all resident, they wait for each other
     bulyan_grid_kernel<<<n_wgs, kGridThreads, 0, stream>>>(
         dist, (int)n, (int)theta, (int)drop_count, (int)users_count, (int)corrupted, ctx->sorted_idx.as<uint16_t>(),
-        ctx->rank_t.as<uint16_t>(), ctx->row_total.as<double>(), ctx->row_top.as<double>(), cls,
+        ctx->rank_t.as<uint16_t>(), ctx->sorted_val.as<float>(), ctx->row_total.as<double>(), ctx->row_top.as<double>(), cls,
         ctx->xchg.as<unsigned long long>(), band_scale, selection_dev, status_dev, status_dev + 1);
     return check_launch("bulyan_grid_kernel");
 }

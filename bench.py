@@ -35,7 +35,6 @@ import numpy as np  # noqa: E402
 PEAK_HBM = 8.0e12        # B/s, spec (MI355X_MICROARCH.md chip table; 6.29e12 measured copy)
 PEAK_MFMA_F32 = 157.3e12  # flop/s, dense fp32-input MFMA (same table)
 PEAK_MFMA_BF16 = 2.5e15   # flop/s, dense bf16 MFMA (same table)
-SPLIT_FACTOR = 6.0        # bf16 MFMA flops issued per algorithmic fp32 flop of the exact three-way split
 MAL_PROP = 0.24           # reference main.py:106
 
 
@@ -147,7 +146,11 @@ class BulyanSharded(Workload):
     def dtype(self):
         # fp32 data and fp32 results; for N > 256 the Gram contraction runs as an exact three-way bf16 split of every
         # fp32 operand on the bf16 matrix cores (six bf16 MFMAs per fp32 product block, fp32 accumulate)
-        return 'f32 (Gram: bf16x3 exact-split MFMA, fp32 accumulate)' if self.n > 256 else 'f32'
+        if self.n <= 256:
+            return 'f32'
+        mode = self.dominant().get('arithmetic')
+        return {'f16x2': 'f32 (Gram: fp16x2 split of every fp32 operand, 3 fp16 MFMAs per block, fp32/fp64 accumulate; 6e-8 vs fp64)',
+                'split': 'f32 (Gram: bf16x3 exact-split MFMA, fp32 accumulate)'}.get(mode, 'f32')
 
     def dominant(self):
         # the Gram: N^2 * D_local flops per launch (half Gram, 2 flop per MAC) -- SURVEY.md 8(d).  The peak is the
@@ -156,16 +159,29 @@ class BulyanSharded(Workload):
         # kernel's work is (N - f + 1)^2 * D_local, not N^2 * D_local
         rows = self.n - self.f + 1 if self.with_attack and self.n >= 512 else self.n
         share = self.agg.world if self.layout == 'clients' else 1     # clients: every rank does 1/W of the tiles, all D
-        split = self.n > 256
-        # The roof.  For N > 256 the contraction runs on the bf16 matrix cores as an exact three-way split: six bf16
-        # MFMA flops per algorithmic fp32 flop, so the pipe's ceiling for THIS arithmetic is 2.5 PF / 6 = 417 TF of
-        # fp32-equivalent work (the fp32-input MFMA's 157 TF, which round 1 graded against, is a floor it already beats).
-        peak = PEAK_MFMA_BF16 / SPLIT_FACTOR if split else PEAK_MFMA_F32
+        # Which arithmetic the engine picks (csrc/gram.hip launch_gram_rows): few tiles -> fp32-input MFMA; many tiles ->
+        # bf16 x 3 (six bf16 MFMA flops per fp32 flop); many tiles AND a long K -> operands split once into two fp16 planes
+        # (csrc/gram_planes.hip), three fp16 MFMA flops per fp32 flop.  The roof of each arithmetic is the dense 16-bit
+        # MFMA peak divided by that factor; `mfma_issued` says how busy the matrix pipe really is.
+        t = -(-rows // 128)
+        n_tiles = -(-(t * (t + 1) // 2) // share)
+        mode = os.environ.get('BYZ_GRAM_MODE')
+        long_k = n_tiles >= 256 and self.d_local > 16384 and os.environ.get('BYZ_GRAM_PLANES', '1') != '0'
+        if mode is None:
+            mode = 'f16x2' if long_k else ('split' if n_tiles >= 4 else 'exact')
+        if mode == 'f16x2' and not long_k:
+            mode = 'split'
+        factor = {'exact': 1.0, 'split': 6.0, 'f16x2': 3.0}[mode]
+        peak = PEAK_MFMA_F32 if mode == 'exact' else PEAK_MFMA_BF16 / factor
+        note = {'exact': 'dense fp32-input MFMA peak',
+                'split': 'fp32-equivalent roof of the exact bf16x3 split: 2.5 PF dense bf16 / 6 MFMA flops per fp32 flop',
+                'f16x2': 'fp32-equivalent roof of the fp16x2 split (operands split once, csrc/gram_planes.hip): '
+                         '2.5 PF dense fp16 / 3 MFMA flops per fp32 flop'}[mode]
         return {'kernel': 'gram_tile', 'bound': 'mfma', 'work': float(rows) ** 2 * self.d_local / share,
-                'peak': peak, 'unit': 'TFLOP/s', 'scale': 1e12,
-                'issued_factor': SPLIT_FACTOR if split else 1.0, 'issued_peak': PEAK_MFMA_BF16 if split else PEAK_MFMA_F32,
-                'peak_note': ('fp32-equivalent roof of the exact bf16x3 split: 2.5 PF dense bf16 / 6 MFMA flops per fp32 flop'
-                              if split else 'dense fp32-input MFMA peak')}
+                'peak': peak, 'unit': 'TFLOP/s', 'scale': 1e12, 'arithmetic': mode, 'work_is_per_step': True,
+                'issued_factor': factor, 'issued_peak': PEAK_MFMA_BF16 if mode != 'exact' else PEAK_MFMA_F32,
+                'companion': 'plane_split' if long_k and mode in ('f16x2', 'split') else None,
+                'peak_note': note}
 
     def at_profiled_size(self):
         return self.name == 'c4' and self.n == 4000 and self.d_local == 10000000
@@ -367,31 +383,44 @@ def timed_steps(torch, dist, wl, eng, steps, warmup, world, events=True):
     return elapsed, per_kernel
 
 
-def roofline_of(wl, per_kernel, traffic_table):
+def roofline_of(wl, per_kernel, traffic_table, steps=None):
+    """`work` is the dominant kernel's algorithmic work per STEP; a step may take several launches of it (the long-K Gram
+    runs one launch per super-chunk of columns), so achieved = work per step / that kernel's time per step, and the
+    per-launch figures are the per-step ones divided by the launches per step."""
     dom = wl.dominant()
     k = per_kernel.get(dom['kernel'])
     if not k:
         return None
-    avg_s = k['total_ms'] / k['launches'] / 1e3
-    achieved = dom['work'] / avg_s
+    if not steps or not dom.get('work_is_per_step'):
+        steps = k['launches']          # `work` is per launch (every other workload: one dominant launch per unit of work)
+    per_step = k['launches'] / float(steps)
+    step_s = k['total_ms'] / steps / 1e3
+    achieved = dom['work'] / step_s
     traffic = None
     if traffic_table:
         # the committed PMC passes were taken at the BASELINE sizes of each workload; other sizes report null
         rec = traffic_table.get('%s/%s' % (wl.name, dom['kernel'])) if wl.at_profiled_size() else None
-        if rec:
+        if rec and rec.get('arithmetic', 'split') == dom.get('arithmetic', 'split'):
             traffic = rec.get('hbm_bytes_per_launch')
     out = {'kernel': dom['kernel'], 'bound': dom['bound'], 'achieved': achieved / dom['scale'],
            'peak': dom['peak'] / dom['scale'], 'unit': dom['unit'], 'frac': achieved / dom['peak'],
-           'traffic': traffic, 'avg_launch_ms': avg_s * 1e3, 'launches': k['launches'],
-           'algorithmic_work_per_launch': dom['work']}
+           'traffic': traffic, 'avg_launch_ms': step_s * 1e3 / per_step, 'launches': k['launches'],
+           'launches_per_step': per_step, 'algorithmic_work_per_launch': dom['work'] / per_step}
+    if dom.get('arithmetic'):
+        out['arithmetic'] = dom['arithmetic']
     if dom.get('peak_note'):
         out['peak_note'] = dom['peak_note']
+    comp = per_kernel.get(dom.get('companion') or '')
+    if comp and comp['launches']:
+        # the one-off operand split that feeds the tile kernel (HBM bound): the rate with its time counted in
+        both_s = (k['total_ms'] + comp['total_ms']) / steps / 1e3
+        out['with_plane_split'] = {'achieved': dom['work'] / both_s / dom['scale'], 'unit': dom['unit'],
+                                   'plane_split_ms_per_step': comp['total_ms'] / steps}
     if dom.get('issued_factor', 1.0) != 1.0:
         out['vs_fp32_mfma_peak'] = achieved / PEAK_MFMA_F32
-        # the matrix-core instructions actually issued: 6 bf16 MFMA flops per algorithmic fp32 flop, against the
-        # dense bf16 MFMA peak -- how busy the matrix pipe really is
+        # the matrix-core instructions actually issued per algorithmic fp32 flop, against the dense 16-bit MFMA peak
         out['mfma_issued'] = {'achieved': achieved * dom['issued_factor'] / 1e12, 'peak': dom['issued_peak'] / 1e12,
-                              'unit': 'TFLOP/s (bf16 MFMA)', 'frac': achieved * dom['issued_factor'] / dom['issued_peak']}
+                              'unit': 'TFLOP/s (16-bit MFMA)', 'frac': achieved * dom['issued_factor'] / dom['issued_peak']}
     return out
 
 
@@ -572,7 +601,7 @@ def main():
         'warmup': args.warmup, 'ms_per_step': ms_per_step, 'higher_is_better': True,
         'scaling': 'strong', 'vs_baseline': None, 'dtype': wl.dtype(), 'data': 'synthetic',
         'config': wl.config(),
-        'roofline': roofline_of(wl, per_kernel, traffic),
+        'roofline': roofline_of(wl, per_kernel, traffic, args.steps),
         'kernels': kernel_table(per_kernel, args.steps),
         'collectives': collectives,
     }
@@ -588,7 +617,7 @@ def main():
         e2, pk2 = timed_steps(torch, dist, other, eng, args.steps, args.warmup, world)
         line['other_layout'] = {
             'layout': other_name, 'value': args.steps / e2, 'unit': 'rounds/s', 'ms_per_step': e2 / args.steps * 1e3,
-            'config': other.config(), 'roofline': roofline_of(other, pk2, None), 'kernels': kernel_table(pk2, args.steps),
+            'config': other.config(), 'roofline': roofline_of(other, pk2, None, args.steps), 'kernels': kernel_table(pk2, args.steps),
             'collectives': {k: {'calls_per_step': v['calls'] / args.steps, 'MB_per_step': v['bytes'] / args.steps / 1e6,
                                 'ms_per_step': v['ms'] / args.steps} for k, v in agg.comm_report().items()}}
         wl = other
@@ -619,7 +648,7 @@ def main():
                 if key in extras:
                     key += '_batched'
                 extras[key] = {'config': w2.config(), 'value': k2 / e2, 'unit': 'rounds/s',
-                               'ms_per_step': e2 / k2 * 1e3, 'roofline': roofline_of(w2, pk2, traffic),
+                               'ms_per_step': e2 / k2 * 1e3, 'roofline': roofline_of(w2, pk2, traffic, k2),
                                'kernels': kernel_table(pk2, k2)}
                 del w2
                 torch.cuda.empty_cache()

@@ -25,24 +25,21 @@ def kernel_ms(fn, iters=2, warm=1):
 if 'gram' in which:
     for n, d in ((4000, 1000000),):
         g = torch.randn((n, d), device='cuda', generator=gen)
-        for planes in ('0', '1'):
-            os.environ['BYZ_GRAM_PLANES'] = planes
+        flops = float(n) * n * d
+        for label, env in (('fused bf16x3', {'BYZ_GRAM_PLANES': '0', 'BYZ_GRAM_MODE': 'split'}),
+                           ('planes bf16x3', {'BYZ_GRAM_PLANES': '1', 'BYZ_GRAM_MODE': 'split'}),
+                           ('planes f16x2', {'BYZ_GRAM_PLANES': '1', 'BYZ_GRAM_MODE': 'f16x2'}),
+                           ('planes f16x2 nbuf4', {'BYZ_GRAM_PLANES': '1', 'BYZ_GRAM_MODE': 'f16x2', 'BYZ_GRAM_PLANES_VARIANT': '4'}),
+                           ('planes f16x2 no-DMA', {'BYZ_GRAM_PLANES': '1', 'BYZ_GRAM_MODE': 'f16x2', 'BYZ_GRAM_PLANES_VARIANT': '10'}),
+                           ('planes f16x2 no-MFMA', {'BYZ_GRAM_PLANES': '1', 'BYZ_GRAM_MODE': 'f16x2', 'BYZ_GRAM_PLANES_VARIANT': '20'})):
+            os.environ.pop('BYZ_GRAM_PLANES_VARIANT', None)
+            os.environ.update(env)
             t = kernel_ms(lambda: eng.gram(g))
-            tile = t.get('gram_tile', (0, 0))[0]
-            print('gram N=%d D=%d planes=%s: %s  -> tile kernel %.1f TF-eq, with split %.1f TF-eq' % (
-                n, d, planes, t, float(n) * n * d / tile / 1e9, float(n) * n * d / (tile + t.get('plane_split', (0, 0))[0]) / 1e9), flush=True)
-        os.environ['BYZ_GRAM_PLANES'] = '1'
-        if 'variants' in which:
-            os.environ['BYZ_GRAM_PLANES'] = '0'
-            ref = eng.gram(g).clone()
-            os.environ['BYZ_GRAM_PLANES'] = '1'
-            for var in ('0', '1', '3', '13', '23'):
-                os.environ['BYZ_GRAM_PLANES_VARIANT'] = var
-                t = kernel_ms(lambda: eng.gram(g))
-                same = bool(torch.equal(eng.gram(g), ref)) if int(var) < 10 else None
-                print('   variant=%s: tile %.2f ms (%.1f TF-eq) split %.2f ms bitwise_equal_fused=%s' % (
-                    var, t['gram_tile'][0], float(n) * n * d / t['gram_tile'][0] / 1e9, t['plane_split'][0], same), flush=True)
-            os.environ.pop('BYZ_GRAM_PLANES_VARIANT')
+            tile, split = t.get('gram_tile', (0, 0))[0], t.get('plane_split', (0, 0))[0]
+            print('gram N=%d D=%d %-22s tile %.2f ms (%.1f TF-eq)  split %.2f ms  -> %.1f TF-eq overall' % (
+                n, d, label, tile, flops / tile / 1e9, split, flops / (tile + split) / 1e9), flush=True)
+        for k in ('BYZ_GRAM_PLANES_VARIANT', 'BYZ_GRAM_MODE', 'BYZ_GRAM_PLANES'):
+            os.environ.pop(k, None)
         del g
 
 if 'loop' in which:

@@ -296,6 +296,7 @@ def test_plane_gram_is_bitwise_the_fused_gram(eng, monkeypatch, n, d, dup):
     g *= (1.0 + 0.5 * torch.rand((n, 1), generator=gen, device='cuda'))
     if dup:
         g[torch.randperm(n, device='cuda')[:dup]] = g[7].clone()
+    monkeypatch.setenv('BYZ_GRAM_MODE', 'split')          # bf16 x 3 on both sides (the planes' default is f16 x 2)
     monkeypatch.setenv('BYZ_GRAM_PLANES', '0')
     fused = eng.gram(g).clone()
     monkeypatch.setenv('BYZ_GRAM_PLANES', '1')
@@ -311,3 +312,51 @@ def test_plane_gram_is_bitwise_the_fused_gram(eng, monkeypatch, n, d, dup):
     norms = np.sqrt(np.diag(want))
     worst = float(np.max(np.abs(got - want) / (norms[:, None] * norms[None, :])))
     assert worst < 1e-6, worst
+
+
+@pytest.mark.parametrize('n,d,family', [(2900, 3 * 8192 + 100, 'scaled'), (4000, 6 * 8192 + 36, 'heavy'), (3000, 4 * 8192, 'ranges')])
+def test_f16x2_gram_against_fp64(eng, monkeypatch, n, d, family):
+    """The default long-K arithmetic: every value split into two fp16 planes (per row and 8192-column chunk scaled by a
+    power of two), three MFMAs per block.  Against fp64 on sampled rows: c_ij within 2e-7 |g_i| |g_j| (the reference's
+    own sdot is 1e-6 .. 1e-4 there); identical rows give exact zero distances and identical distance rows; the result
+    does not depend on how the columns are cut into super-chunks; a second call reproduces it bit for bit."""
+    torch = pytest.importorskip('torch')
+    gen = torch.Generator(device='cuda').manual_seed(1700 + n)
+    g = torch.randn((n, d), generator=gen, device='cuda', dtype=torch.float32)
+    if family == 'scaled':
+        g *= (1.0 + 0.5 * torch.rand((n, 1), generator=gen, device='cuda'))
+    elif family == 'heavy':      # a few huge coordinates per row: the scale follows the chunk's largest magnitude
+        g *= torch.where(torch.rand((n, d), generator=gen, device='cuda') < 1e-3, 1.0e3, 1.0)
+    else:                        # rows and column ranges of wildly different magnitude, one all-zero row
+        g *= torch.pow(10.0, torch.randint(-12, 12, (n, 1), generator=gen, device='cuda').float())
+        g[:, 8192:2 * 8192] *= 1.0e-6
+        g[11] = 0.0
+    g[5] = g[n - 1]
+    g[1700] = g[5]
+    monkeypatch.delenv('BYZ_GRAM_MODE', raising=False)
+    monkeypatch.setenv('BYZ_GRAM_PLANES', '1')
+    one = eng.gram(g).clone()
+    monkeypatch.setenv('BYZ_GRAM_PLANE_MB', '300')
+    many = eng.gram(g).clone()
+    monkeypatch.delenv('BYZ_GRAM_PLANE_MB')
+    assert torch.equal(one, many)
+    assert torch.equal(one, eng.gram(g))
+    rows = [0, 1, 5, 11, 1700, n // 2, n - 2, n - 1]
+    host = g[rows].cpu().numpy().astype(np.float64)
+    want = host @ host.T
+    got = one[rows][:, rows].cpu().numpy()
+    norms = np.sqrt(np.diag(want))
+    scale = np.maximum(norms[:, None] * norms[None, :], np.finfo(np.float64).tiny)
+    worst = float(np.max(np.abs(got - want) / scale))
+    assert worst < 2e-7, worst
+    dist = eng.pairwise_distances(g).numpy()
+    assert dist[5, 1700] == 0.0 and dist[5, n - 1] == 0.0 and dist[1700, n - 1] == 0.0
+    keep = np.ones(n, dtype=bool)
+    keep[[5, 1700, n - 1]] = False
+    assert np.array_equal(dist[5, keep], dist[1700, keep]) and np.array_equal(dist[5, keep], dist[n - 1, keep])
+    if family != 'ranges':       # distances against fp64 on the sampled rows (1e-6, the float bar of north_star)
+        sq = np.diag(want)
+        d_want = np.sqrt(np.maximum(sq[:, None] + sq[None, :] - 2.0 * want, 0.0))
+        d_got = dist[np.ix_(rows, rows)]
+        off = ~np.eye(len(rows), dtype=bool) & (d_want > 0)
+        assert float(np.max(np.abs(d_got[off] - d_want[off]) / d_want[off])) < 1e-6
