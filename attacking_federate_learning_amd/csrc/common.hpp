@@ -245,6 +245,9 @@ int launch_bulyan_loop(byz_ctx* ctx, const float* dist, int64_t n, int64_t theta
 int launch_trimmed_mean(byz_ctx* ctx, const float* G, int64_t n_rows, int64_t n_cols, int64_t ld,
                         const int32_t* row_index, int64_t keep, float* out, hipStream_t stream);
 int64_t trimmed_mean_max_rows();
+// window_rows.hip: the row-split ring selection (first stage of the trimmed mean)
+int launch_window_rows(byz_ctx* ctx, const float* G, int64_t n_rows, int64_t n_cols, int64_t ld, const int32_t* row_index,
+                       int64_t keep, float* out, int32_t* redo, hipStream_t stream);
 int64_t select_max_rows();
 
 int launch_lane_selftest(byz_ctx* ctx, int32_t* out, int32_t* n_patterns, hipStream_t stream);

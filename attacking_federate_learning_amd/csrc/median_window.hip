@@ -1237,18 +1237,31 @@ int launch_rpl(const float* G, int64_t n_rows, int64_t n_cols, int64_t ld, const
 }
 
 // ring selection first, then the general kernel over whatever it could not resolve (redo[0] tiles; the second launch is
-// sized for all of them and the surplus workgroups leave at once)
-template <int RPL>
+// sized for all of them and the surplus workgroups leave at once).  The first stage is the row-split kernel of
+// window_rows.hip; BYZ_TM_ROWS=0 keeps this file's column-split ring kernel (256 .. 2560 rows only).
+template <int RPL, int NC, int WAVES>
 int launch_ring(byz_ctx* ctx, const float* G, int64_t n_rows, int64_t n_cols, int64_t ld, const int32_t* row_index,
                 int64_t keep, float* out, hipStream_t stream) {
     const int64_t n_tiles = ceil_div(n_cols, static_cast<int64_t>(kCols));
     BYZ_TRY(ctx->redo_tiles.ensure(static_cast<size_t>(n_tiles + 1) * sizeof(int32_t)));
     int32_t* redo = ctx->redo_tiles.as<int32_t>();
     BYZ_HIP(hipMemsetAsync(redo, 0, sizeof(int32_t), stream));
-    median_window_kernel<RPL, 4, 4, 1><<<static_cast<unsigned>(n_tiles), 256, 0, stream>>>(
-        G, static_cast<int>(n_rows), n_cols, ld, row_index, static_cast<int>(keep), out, redo);
-    BYZ_TRY(check_launch("median_window_kernel<ring>"));
-    median_window_kernel<RPL, 4, 4, 2><<<static_cast<unsigned>(n_tiles), 256, 0, stream>>>(
+    const char* e = std::getenv("BYZ_TM_ROWS");
+    int rc = BYZ_E_UNSUPPORTED;
+    if (!e || std::atoi(e) != 0) rc = launch_window_rows(ctx, G, n_rows, n_cols, ld, row_index, keep, out, redo, stream);
+    if (rc == BYZ_E_UNSUPPORTED) {
+        if constexpr (NC == 4 && WAVES == 4 && RPL >= 4) {
+            median_window_kernel<RPL, 4, 4, 1><<<static_cast<unsigned>(n_tiles), 256, 0, stream>>>(
+                G, static_cast<int>(n_rows), n_cols, ld, row_index, static_cast<int>(keep), out, redo);
+            BYZ_TRY(check_launch("median_window_kernel<ring>"));
+        } else {
+            ctx->redo_valid = false;
+            return launch_rpl<RPL, NC, WAVES>(G, n_rows, n_cols, ld, row_index, keep, out, stream);
+        }
+    } else if (rc != BYZ_OK) {
+        return rc;
+    }
+    median_window_kernel<RPL, NC, WAVES, 2><<<static_cast<unsigned>(n_tiles), 64 * WAVES, 0, stream>>>(
         G, static_cast<int>(n_rows), n_cols, ld, row_index, static_cast<int>(keep), out, redo);
     return check_launch("median_window_kernel<redo>");
 }
@@ -1267,22 +1280,21 @@ int launch_trimmed_mean(byz_ctx* ctx, const float* G, int64_t n_rows, int64_t n_
     KernelTimer t(ctx, BYZ_K_TRIMMED_MEAN, stream);
     ctx->redo_valid = false;
     const int64_t rpl = ceil_div(n_rows, 64);
-    {   // experiment knob: from this many 64-row groups on, use the one-column-per-wave variant
-        const char* e = std::getenv("BYZ_TM_NC1_FROM");
-        const int64_t from = e ? std::atoll(e) : 41;
-        if (rpl >= from && rpl <= 64) return launch_rpl<64, 1, 16>(G, n_rows, n_cols, ld, row_index, keep, out, stream);
-    }
     if (rpl > 88) return launch_trimmed_mean_sorted(ctx, G, n_rows, n_cols, ld, row_index, keep, out, stream);
-    // the ring selection: 256 .. 2560 rows (BYZ_TM_RING=0 keeps the general kernel for everything)
+    // the ring selection (window_rows.hip) with this file's general kernel behind it: 129 .. 5376 rows
+    // (BYZ_TM_RING=0 keeps the general kernel for everything)
     {
         const char* e = std::getenv("BYZ_TM_RING");
-        if ((!e || std::atoi(e) != 0) && keep >= 1 && rpl >= 4 && rpl <= kMaxRpl) {
+        if ((!e || std::atoi(e) != 0) && keep >= 1 && rpl >= 3 && rpl <= 84) {
             ctx->redo_valid = true;
-            if (rpl <= 8) return launch_ring<8>(ctx, G, n_rows, n_cols, ld, row_index, keep, out, stream);
-            if (rpl <= 16) return launch_ring<16>(ctx, G, n_rows, n_cols, ld, row_index, keep, out, stream);
-            if (rpl <= 24) return launch_ring<24>(ctx, G, n_rows, n_cols, ld, row_index, keep, out, stream);
-            if (rpl <= 32) return launch_ring<32>(ctx, G, n_rows, n_cols, ld, row_index, keep, out, stream);
-            return launch_ring<40>(ctx, G, n_rows, n_cols, ld, row_index, keep, out, stream);
+            if (rpl <= 4) return launch_ring<4, 4, 4>(ctx, G, n_rows, n_cols, ld, row_index, keep, out, stream);
+            if (rpl <= 8) return launch_ring<8, 4, 4>(ctx, G, n_rows, n_cols, ld, row_index, keep, out, stream);
+            if (rpl <= 16) return launch_ring<16, 4, 4>(ctx, G, n_rows, n_cols, ld, row_index, keep, out, stream);
+            if (rpl <= 24) return launch_ring<24, 4, 4>(ctx, G, n_rows, n_cols, ld, row_index, keep, out, stream);
+            if (rpl <= 32) return launch_ring<32, 4, 4>(ctx, G, n_rows, n_cols, ld, row_index, keep, out, stream);
+            if (rpl <= kMaxRpl) return launch_ring<40, 4, 4>(ctx, G, n_rows, n_cols, ld, row_index, keep, out, stream);
+            if (rpl <= 64) return launch_ring<64, 1, 16>(ctx, G, n_rows, n_cols, ld, row_index, keep, out, stream);
+            return launch_ring<88, 1, 16>(ctx, G, n_rows, n_cols, ld, row_index, keep, out, stream);
         }
     }
     if (rpl <= 1) return launch_rpl<1, 4, 4>(G, n_rows, n_cols, ld, row_index, keep, out, stream);

@@ -297,6 +297,15 @@ __device__ __forceinline__ bool gather_granules(const unsigned long long* slots,
     return true;
 }
 
+__device__ __forceinline__ int wave_sum_int(int x) {   // wave-uniform result
+    x += __builtin_amdgcn_update_dpp(0, x, 0xB1, 0xF, 0xF, true);    // quad_perm [1,0,3,2]
+    x += __builtin_amdgcn_update_dpp(0, x, 0x4E, 0xF, 0xF, true);    // quad_perm [2,3,0,1]
+    x += __builtin_amdgcn_update_dpp(0, x, 0x141, 0xF, 0xF, true);   // row_half_mirror
+    x += __builtin_amdgcn_update_dpp(0, x, 0x140, 0xF, 0xF, true);   // row_mirror
+    return __builtin_amdgcn_readlane(x, 0) + __builtin_amdgcn_readlane(x, 16) + __builtin_amdgcn_readlane(x, 32) +
+           __builtin_amdgcn_readlane(x, 48);
+}
+
 // both granules of a pick in one polling loop: one exchange latency instead of two
 __device__ __forceinline__ bool gather_granule_pair(const unsigned long long* slots_a, const unsigned long long* slots_b,
                                                     int n_wgs, uint32_t tag4, uint32_t tag18, int lane,
@@ -328,32 +337,71 @@ __device__ __forceinline__ bool gather_granule_pair(const unsigned long long* sl
 // times fixes lane l at step l, one VALU instruction per element instead of a readlane + add pair.
 __device__ __forceinline__ float reference_score(const float* __restrict__ sorted_val, const uint16_t* __restrict__ sorted_idx,
                                                  const uint32_t* removed, int n, int u, int take, int lane) {
+    constexpr int kDepth = 8;   // 64-entry chunks loaded per batch: the tables are not cache resident, one load latency per batch
     const uint16_t* order = sorted_idx + static_cast<int64_t>(u) * n;
     const float* vals = sorted_val + static_cast<int64_t>(u) * n;
     float carry = 0.0f;
     int got = 0;
-    int col_next = lane < n ? order[lane] : u;
-    float v_next = lane < n ? vals[lane] : 0.0f;
-    for (int r0 = 0; r0 < n && got < take; r0 += 64) {
-        const int col = col_next;
-        const float v = v_next;
-        const int rn = r0 + 64 + lane;
-        col_next = rn < n ? order[rn] : u;
-        v_next = rn < n ? vals[rn] : 0.0f;
-        const bool live = r0 + lane < n && col != u && !((removed[col >> 5] >> (col & 31)) & 1u);
-        const unsigned long long m = __ballot(live);
-        if (m == 0ull) continue;
-        const int before = __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(m >> 32),
-                                                     __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(m), 0));
-        const float x = (live && got + before < take) ? v : 0.0f;   // past the prefix the reference sums: + 0.0
-        got += __popcll(m);
-        float s = __fadd_rn(carry, x);          // lane 0 is final
-        // lanes whose source lane does not exist (lane 0) keep their value; 2 wait states between a VALU write and a
-        // DPP read of the same register
+    int col_next[kDepth];
+    float v_next[kDepth];
+    auto fetch = [&](int r0) __attribute__((always_inline)) {
 #pragma unroll
-        for (int l = 1; l < 64; ++l)
-            asm volatile("s_nop 1\n\tv_add_f32_dpp %0, %0, %1 wave_shr:1 row_mask:0xf bank_mask:0xf" : "+v"(s) : "v"(x));
-        carry = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(s), 63));
+        for (int k = 0; k < kDepth; ++k) {
+            const int r = r0 + 64 * k + lane;
+            col_next[k] = r < n ? order[r] : u;     // a row's own column marks "not an entry"
+            v_next[k] = r < n ? vals[r] : 0.0f;
+        }
+    };
+    fetch(0);
+    for (int r0 = 0; r0 < n && got < take; r0 += 64 * kDepth) {
+        int col[kDepth];
+        float v[kDepth];
+#pragma unroll
+        for (int k = 0; k < kDepth; ++k) {
+            col[k] = col_next[k];
+            v[k] = v_next[k];
+        }
+        if (r0 + 64 * kDepth < n) fetch(r0 + 64 * kDepth);
+#pragma unroll
+        for (int k = 0; k < kDepth; ++k) {
+            if (got >= take) break;     // wave-uniform
+            const bool live = col[k] != u && !((removed[col[k] >> 5] >> (col[k] & 31)) & 1u);
+            const unsigned long long m = __ballot(live);
+            if (m == 0ull) continue;
+            const int before = __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(m >> 32),
+                                                         __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(m), 0));
+            const float x = (live && got + before < take) ? v[k] : 0.0f;   // past the prefix the reference sums: + 0.0
+            got += __popcll(m);
+            // Fast path.  While the running sum stays inside one binade [2^E, 2^(E+1)) it is a multiple of q = ulp(2^E),
+            // and adding x rounds to the nearest multiple of q: fl(s + x) = s + q rn(x / q) unless x / q lies exactly
+            // half way (then the parity of s decides).  So a chunk without such a tie and without a binade crossing
+            // adds q * sum(rn(x_l / q)) -- integers, any order.  Everything else takes the sequential chain below.
+            {
+                const int eb = static_cast<int>((__float_as_uint(carry) >> 23) & 0xffu);
+                if (eb >= 40 && eb <= 220) {
+                    const float invq = __uint_as_float(static_cast<uint32_t>(277 - eb) << 23);   // 2^(23 - E)
+                    const float qf = __uint_as_float(static_cast<uint32_t>(eb - 23) << 23);       // 2^(E - 23)
+                    const float t = x * invq;                                                     // exact
+                    const float r = __builtin_rintf(t);
+                    const bool odd_one = !(t < 16777216.0f) || __builtin_fabsf(t - r) == 0.5f;
+                    if (__ballot(odd_one) == 0ull) {
+                        const int total = wave_sum_int(static_cast<int>(r));                      // < 2^30
+                        const int base = static_cast<int>(carry * invq);                          // [2^23, 2^24)
+                        if (total < (1 << 24) && base + total < (1 << 24)) {
+                            carry = __fadd_rn(carry, static_cast<float>(total) * qf);             // every step exact
+                            continue;
+                        }
+                    }
+                }
+            }
+            float s = __fadd_rn(carry, x);          // lane 0 is final
+            // lanes whose source lane does not exist (lane 0) keep their value; 2 wait states between a VALU write and
+            // a DPP read of the same register
+#pragma unroll
+            for (int l = 1; l < 64; ++l)
+                asm volatile("s_nop 1\n\tv_add_f32_dpp %0, %0, %1 wave_shr:1 row_mask:0xf bank_mask:0xf" : "+v"(s) : "v"(x));
+            carry = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(s), 63));
+        }
     }
     return carry;
 }

@@ -6,7 +6,7 @@ import torch
 from attacking_federate_learning_amd.engine import get_engine
 
 eng = get_engine()
-which = sys.argv[1:] or ['gram', 'loop']
+which = sys.argv[1:] or ["gram", "loop"]
 gen = torch.Generator(device='cuda').manual_seed(0)
 
 
@@ -64,3 +64,19 @@ if 'loop' in which:
             print('bulyan loop N=%d band=%s: %s rescored=%s same_as_rigorous=%s' % (
                 n, band, {k: v for k, v in t.items() if k in ('bulyan_loop', 'row_sort')}, getattr(eng, 'bulyan_rescored', lambda: '?')(), sel == ref), flush=True)
         os.environ.pop('BYZ_BULYAN_BAND')
+
+if 'tm' in which:
+    for n, d, c in ((1000, 1000000, 200), (2080, 1 << 20, 1920), (5200, 1 << 19, 4800), (256, 1 << 21, 60), (100, 1 << 22, 20)):
+        g = torch.randn((n, d), device='cuda', generator=gen)
+        res = {}
+        for label, env in (('rows', {'BYZ_TM_ROWS': '1'}), ('columns', {'BYZ_TM_ROWS': '0'})):
+            os.environ.update(env)
+            t = kernel_ms(lambda: eng.trimmed_mean(g, n, c), iters=3, warm=1)
+            res[label] = eng.trimmed_mean(g, n, c).clone()
+            ms = t['trimmed_mean'][0]
+            print('trimmed_mean N=%d D=%d keep=%d %-8s %.3f ms  %.2f TB/s (%.2f of 8)  redone tiles %s' % (
+                n, d, n - c - 1, label, ms, 4.0 * n * d / ms / 1e9, 4.0 * n * d / ms / 1e9 / 8.0, eng.trimmed_mean_redone()), flush=True)
+        os.environ.pop('BYZ_TM_ROWS')
+        diff = (res['rows'] - res['columns']).abs().max().item()
+        print('    max |rows - columns| = %.3e' % diff, flush=True)
+        del g
