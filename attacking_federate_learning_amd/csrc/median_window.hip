@@ -902,7 +902,7 @@ __device__ __forceinline__ bool finish_fast(const float (&x)[4][RPL], const floa
             const uint32_t t = wave_sum_u32(below[c]);
             bm1[c] = static_cast<int>(t & 0xffffu);
             bm2[c] = static_cast<int>(t >> 16);
-            fine = fine && bm1[c] < B && bm2[c] < B && bm2[c] - bm1[c] <= 1;
+            fine = fine && bm1[c] < B && bm2[c] < B && bm2[c] - bm1[c] <= 8;
         }
     }
     if (!fine) return false;
@@ -1238,7 +1238,7 @@ int launch_rpl(const float* G, int64_t n_rows, int64_t n_cols, int64_t ld, const
 
 // ring selection first, then the general kernel over whatever it could not resolve (redo[0] tiles; the second launch is
 // sized for all of them and the surplus workgroups leave at once).  The first stage is the row-split kernel of
-// window_rows.hip; BYZ_TM_ROWS=0 keeps this file's column-split ring kernel (256 .. 2560 rows only).
+// window_rows.hip (above 1024 rows) or this file's column-split ring kernel (129 .. 2560 rows).
 template <int RPL, int NC, int WAVES>
 int launch_ring(byz_ctx* ctx, const float* G, int64_t n_rows, int64_t n_cols, int64_t ld, const int32_t* row_index,
                 int64_t keep, float* out, hipStream_t stream) {
@@ -1246,9 +1246,12 @@ int launch_ring(byz_ctx* ctx, const float* G, int64_t n_rows, int64_t n_cols, in
     BYZ_TRY(ctx->redo_tiles.ensure(static_cast<size_t>(n_tiles + 1) * sizeof(int32_t)));
     int32_t* redo = ctx->redo_tiles.as<int32_t>();
     BYZ_HIP(hipMemsetAsync(redo, 0, sizeof(int32_t), stream));
+    // BYZ_TM_ROWS: unset -> the row-split kernel above 1024 rows (measured: 2.29 vs 2.18 ms at 1000 rows x 1e6 columns,
+    // 8.5 vs 9.1 ms at 2080 rows x 2^20, 12.5 vs 16.3 ms at 5200 rows x 2^19); 1 -> always; 0 -> never
     const char* e = std::getenv("BYZ_TM_ROWS");
     int rc = BYZ_E_UNSUPPORTED;
-    if (!e || std::atoi(e) != 0) rc = launch_window_rows(ctx, G, n_rows, n_cols, ld, row_index, keep, out, redo, stream);
+    if (e ? std::atoi(e) != 0 : n_rows > 1024)
+        rc = launch_window_rows(ctx, G, n_rows, n_cols, ld, row_index, keep, out, redo, stream);
     if (rc == BYZ_E_UNSUPPORTED) {
         if constexpr (NC == 4 && WAVES == 4 && RPL >= 4) {
             median_window_kernel<RPL, 4, 4, 1><<<static_cast<unsigned>(n_tiles), 256, 0, stream>>>(

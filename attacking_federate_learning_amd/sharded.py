@@ -324,6 +324,7 @@ class ShardedAggregator:
         the xGMI full mesh: all links busy, where a ring would be bound by one 153 GB/s link)."""
         ops = []
         nbytes = 0
+        landed = []    # (contiguous landing buffer, strided destination): a block of a pitch-padded matrix is not contiguous
         for peer in range(self.world):
             if peer == self.rank:
                 continue
@@ -331,14 +332,20 @@ class ShardedAggregator:
             if blocks_out[peer].numel():
                 ops.append(self.dist.P2POp(self.dist.isend, blocks_out[peer], global_peer, group=self.group))
             if blocks_in[peer].numel():
-                ops.append(self.dist.P2POp(self.dist.irecv, blocks_in[peer], global_peer, group=self.group))
-                nbytes += blocks_in[peer].numel() * blocks_in[peer].element_size()
+                dst = blocks_in[peer]
+                if not dst.is_contiguous():
+                    dst = dst.new_empty(dst.shape)
+                    landed.append((dst, blocks_in[peer]))
+                ops.append(self.dist.P2POp(self.dist.irecv, dst, global_peer, group=self.group))
+                nbytes += dst.numel() * dst.element_size()
         if not ops:
             return
 
         def run():
             for req in self.dist.batch_isend_irecv(ops):
                 req.wait()
+            for buf, dst in landed:
+                dst.copy_(buf)
         self._timed(name, nbytes, blocks_in[(self.rank + 1) % self.world], run)
 
     def reshard_clients_to_columns(self, rows_local, rows_per_rank):
@@ -375,7 +382,10 @@ class ShardedAggregator:
         mine = wanted_rows[owner == self.rank] - offsets[self.rank]
         device = rows_local.device
         mine_t = torch.from_numpy(mine).to(device)
-        out = torch.empty((len(wanted_rows), hi - lo), dtype=rows_local.dtype, device=device)
+        # the leading dimension is padded to a multiple of four floats: slice widths differ by one between ranks, and a
+        # 16-byte-aligned row pitch is what lets every rank's kernels take the same (LDS-DMA, vector-load) paths
+        pitch = -(-(hi - lo) // 4) * 4
+        out = torch.empty((len(wanted_rows), pitch), dtype=rows_local.dtype, device=device)[:, :hi - lo]
         all_of_mine = len(mine) == rows_local.shape[0] and np.array_equal(mine, np.arange(rows_local.shape[0]))
         picked = rows_local if all_of_mine else rows_local.index_select(0, mine_t)
         blocks_in = [out[int(starts[p]):int(starts[p + 1])] for p in range(self.world)]

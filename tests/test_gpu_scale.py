@@ -247,7 +247,7 @@ def test_distances_to_dict_is_the_reference_dict(eng):
 
 
 # ---- the ring selection of the trimmed mean (256 .. 2560 rows) and its hand-over to the general kernel --------------
-@pytest.mark.parametrize('n,c', [(256, 60), (1000, 200), (1000, 0), (1000, 998), (1537, 300), (2080, 1920), (2560, 1000)])
+@pytest.mark.parametrize('n,c', [(256, 60), (1000, 200), (1000, 0), (1001, 999), (1537, 300), (2080, 1920), (2560, 1000), (3000, 600), (5200, 4800)])
 def test_ring_selection_resolves_continuous_columns(eng, n, c):
     """Continuous data: (nearly) every tile is resolved by the one-histogram ring selection, and the answer is the
     reference's.  A few columns per thousand have exact +t / -t ties at the window edge and go the general way."""
