@@ -141,6 +141,30 @@ def test_config4_bulyan_end_to_end_n4000(eng):
     assert sel == scale.bulyan_selection(dist_gpu, n, f)
 
 
+def test_bulyan_end_to_end_through_the_long_k_gram(eng):
+    """The arithmetic BENCH's headline actually runs: N >= 2817 and D > 16384 send the Gram through the operands split
+    once into two fp16 planes (gram_planes.hip), then the grid selection loop and the row-split second stage.
+    Same protocol as above: distances within 1e-6 of fp64, the picks before the first fp64 margin below tau equal to
+    the fp64 oracle's, and -- given the GPU's own distances -- the reference's selection pick for pick."""
+    n, d = 3000, 3 * 8192 + 64
+    f = int(n * MAL_PROP)
+    g = scaled(4700, n, d)
+    out, sel = eng.bulyan(g, n, f, return_selection=True)
+    sel = np.asarray(sel).tolist()
+    assert len(sel) == n - 2 * f and len(set(sel)) == len(sel)
+    dist64 = ideal.distance_matrix(g)
+    dist_gpu = eng.pairwise_distances(g).numpy()
+    off = ~np.eye(n, dtype=bool)
+    assert np.allclose(dist_gpu[off], dist64[off], rtol=1e-6)
+    want, margins = scale.bulyan_selection(dist64.astype(np.float32), n, f, mode='ideal', with_margins=True)
+    noisy = np.flatnonzero(margins <= TAU)
+    first_noisy = int(noisy[0]) if len(noisy) else len(sel)
+    assert sel[:first_noisy] == want[:first_noisy]
+    print('N=3000 (f16x2 Gram): %d of %d picks have an fp64 margin below tau; prefix checked: %d' % (len(noisy), len(sel), first_noisy))
+    assert sel == scale.bulyan_selection(dist_gpu, n, f)
+    assert close(out, ideal.trimmed_mean(g[sel], 2 * f))
+
+
 # ---- second stage: row_index in selection order at theta = 2080 and 5200 --------------------------------------
 @pytest.mark.parametrize('n,theta,cols', [(4000, 2080, 70), (10000, 5200, 40), (3000, 1537, 33), (6000, 2561, 20)])
 def test_trimmed_mean_through_a_selection(eng, n, theta, cols):
