@@ -54,6 +54,12 @@ int read_small(byz_ctx* ctx, int32_t (&words)[32], hipStream_t stream) {
                       "shared); the distance matrix of this call is invalid");
             return BYZ_E_HIP;
         }
+        if (sticky & 8) {
+            set_error("krum (N <= 128): the helper workgroups of the distance kernel lost contact with its worker (GPU shared "
+                      "with another process?); the result of this call is invalid");
+            if (ctx->small_sync.ptr) BYZ_HIP(hipMemsetAsync(ctx->small_sync.ptr, 0, 64, stream));
+            return BYZ_E_HIP;
+        }
         if (sticky & 4) {
             set_error("distances: two rows have bitwise equal Gram entries but differ; their near-duplicate pairs were not "
                       "re-evaluated (please report the input)");
@@ -84,6 +90,8 @@ int check_matrix(const float* G, int64_t n_rows, int64_t n_cols, int64_t ld, con
 int krum_select(byz_ctx* ctx, const float* dist, int64_t n, int64_t users_count, int64_t corrupted,
                 int32_t* winner_dev, hipStream_t stream) {
     const int64_t prefix = python_prefix_len(n - 1, users_count - corrupted);
+    if (krum_small_applies(n, 1))
+        return launch_small_select(ctx, dist, n, prefix, nullptr, 0, 0, winner_dev, nullptr, stream);
     BYZ_TRY(launch_row_sort(ctx, dist, n, prefix, 0, false, stream));
     BYZ_TRY(launch_krum_argmin(ctx, n, winner_dev, stream));
     return BYZ_OK;
@@ -196,6 +204,7 @@ void byz_ctx_destroy(byz_ctx* ctx) {
     ctx->redo_tiles.release();
     ctx->xchg.release();
     ctx->small.release();
+    ctx->small_sync.release();
     ctx->stage_in.release();
     ctx->stage_out.release();
     ctx->pinned.release();
@@ -347,6 +356,10 @@ int byz_pairwise_distances_dev(byz_ctx* ctx, const float* G, int64_t n_rows, int
     BYZ_TRY(enter(ctx));
     BYZ_TRY(check_matrix(G, n_rows, n_cols, ld, "pairwise_distances"));
     BYZ_REQUIRE(dist, "pairwise_distances: null output");
+    if (krum_small_applies(n_rows, n_cols)) {
+        ctx->row_map_rows = 0;
+        return launch_small_distances(ctx, G, n_rows, n_cols, ld, dist, as_stream(stream));
+    }
     BYZ_TRY(ctx->gram.ensure(static_cast<size_t>(n_rows) * n_rows * sizeof(double)));
     BYZ_TRY(launch_gram(ctx, G, n_rows, n_cols, ld, ctx->gram.as<double>(), as_stream(stream)));
     return launch_distances_from_gram(ctx, ctx->gram.as<double>(), n_rows, dist, as_stream(stream), G, n_cols, ld);
@@ -380,11 +393,19 @@ int byz_krum_dev(byz_ctx* ctx, const float* G, int64_t n_rows, int64_t n_cols, i
     }
     hipStream_t s = as_stream(stream);
     BYZ_TRY(ensure_distance_workspaces(ctx, n_rows));
-    BYZ_TRY(launch_gram(ctx, G, n_rows, n_cols, ld, ctx->gram.as<double>(), s));
-    BYZ_TRY(launch_distances_from_gram(ctx, ctx->gram.as<double>(), n_rows, ctx->dist.as<float>(), s, G, n_cols, ld));
     int32_t* winner = ctx->small.as<int32_t>();
-    BYZ_TRY(krum_select(ctx, ctx->dist.as<float>(), n_rows, users_count, corrupted_count, winner, s));
-    if (out_row) BYZ_TRY(launch_copy_row(ctx, G, ld, n_rows, n_cols, winner, out_row, s));
+    if (krum_small_applies(n_rows, n_cols)) {
+        // the reference's own sizes: five short launches (krum_small.hip), the row copy is part of the last one
+        ctx->row_map_rows = 0;
+        BYZ_TRY(launch_small_distances(ctx, G, n_rows, n_cols, ld, ctx->dist.as<float>(), s));
+        const int64_t prefix = python_prefix_len(n_rows - 1, users_count - corrupted_count);
+        BYZ_TRY(launch_small_select(ctx, ctx->dist.as<float>(), n_rows, prefix, G, n_cols, ld, winner, out_row, s));
+    } else {
+        BYZ_TRY(launch_gram(ctx, G, n_rows, n_cols, ld, ctx->gram.as<double>(), s));
+        BYZ_TRY(launch_distances_from_gram(ctx, ctx->gram.as<double>(), n_rows, ctx->dist.as<float>(), s, G, n_cols, ld));
+        BYZ_TRY(krum_select(ctx, ctx->dist.as<float>(), n_rows, users_count, corrupted_count, winner, s));
+        if (out_row) BYZ_TRY(launch_copy_row(ctx, G, ld, n_rows, n_cols, winner, out_row, s));
+    }
     if (index_host) {
         int32_t words[32];
         BYZ_TRY(read_small(ctx, words, s));
@@ -434,8 +455,13 @@ int byz_bulyan_dev(byz_ctx* ctx, const float* G, int64_t n_rows, int64_t n_cols,
     const int64_t theta = users_count - 2 * corrupted_count;
     BYZ_TRY(ensure_distance_workspaces(ctx, n_rows));
     BYZ_TRY(ctx->selection.ensure(static_cast<size_t>(n_rows) * sizeof(int32_t)));
-    BYZ_TRY(launch_gram(ctx, G, n_rows, n_cols, ld, ctx->gram.as<double>(), s));
-    BYZ_TRY(launch_distances_from_gram(ctx, ctx->gram.as<double>(), n_rows, ctx->dist.as<float>(), s, G, n_cols, ld));
+    if (krum_small_applies(n_rows, n_cols)) {
+        ctx->row_map_rows = 0;
+        BYZ_TRY(launch_small_distances(ctx, G, n_rows, n_cols, ld, ctx->dist.as<float>(), s));
+    } else {
+        BYZ_TRY(launch_gram(ctx, G, n_rows, n_cols, ld, ctx->gram.as<double>(), s));
+        BYZ_TRY(launch_distances_from_gram(ctx, ctx->gram.as<double>(), n_rows, ctx->dist.as<float>(), s, G, n_cols, ld));
+    }
     int32_t* sel = ctx->selection.as<int32_t>();
     BYZ_TRY(bulyan_select(ctx, ctx->dist.as<float>(), n_rows, users_count, corrupted_count, sel, s));
     if (selection_out)

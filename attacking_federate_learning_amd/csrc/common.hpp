@@ -134,6 +134,8 @@ struct byz_ctx {
     int64_t bulyan_rescored = 0; // rows the last Bulyan loop re-scored in the reference's fp32 arithmetic
     byz::Buffer selection;       // theta int32
     byz::Buffer small;           // misc device scalars (winner index, status words)
+    byz::Buffer small_sync;      // krum_small.hip: flag / pair count / arrivals of the distance kernel's helpers
+    int32_t small_epoch = 0;     // krum_small.hip: value the flag takes in the current launch
     byz::Buffer stage_in;        // device copy of a host matrix
     byz::Buffer stage_out;       // device result before download
     byz::PinnedBuffer pinned;    // host bounce buffer for small results
@@ -149,7 +151,8 @@ inline hipStream_t as_stream(void* s) { return static_cast<hipStream_t>(s); }
 // ctx->small (256 bytes, allocated and zeroed with the context) holds the device-side scalars:
 //   [0] Krum winner   [8] Bulyan loop status   [9] rows the Bulyan loop re-scored
 //   [16] sticky device status (bit 0: a Gram chunk lost its ticket, bit 1: near-duplicate pair list overflowed,
-//        bit 2: two rows with bitwise equal Gram entries turned out to differ)
+//        bit 2: two rows with bitwise equal Gram entries turned out to differ, bit 3: the helpers of the small-N distance
+//        kernel lost contact with its worker)
 //   [17] number of near-duplicate pairs listed by the last distance kernel
 inline int32_t* device_status_word(byz_ctx* ctx) { return ctx->small.as<int32_t>() + 16; }
 inline int32_t* near_pair_count_word(byz_ctx* ctx) { return ctx->small.as<int32_t>() + 17; }
@@ -251,5 +254,12 @@ int launch_window_rows(byz_ctx* ctx, const float* G, int64_t n_rows, int64_t n_c
 int64_t select_max_rows();
 
 int launch_lane_selftest(byz_ctx* ctx, int32_t* out, int32_t* n_patterns, hipStream_t stream);
+
+// krum_small.hip: the whole of Krum for N <= 128 in five launches
+bool krum_small_applies(int64_t n_rows, int64_t n_cols);
+int launch_small_distances(byz_ctx* ctx, const float* G, int64_t n_rows, int64_t n_cols, int64_t ld, float* dist,
+                           hipStream_t stream);
+int launch_small_select(byz_ctx* ctx, const float* dist, int64_t n_rows, int64_t prefix_len, const float* G, int64_t n_cols,
+                        int64_t ld, int32_t* winner_dev, float* out_row, hipStream_t stream);
 
 }  // namespace byz
