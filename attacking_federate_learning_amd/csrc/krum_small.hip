@@ -91,9 +91,13 @@ __device__ __forceinline__ f32x4 load4_guarded(const float* __restrict__ row, in
 //     already covered (the order of the columns inside a slice does not matter to a sum over them);
 //   * past the last slice the prefetch reads one 16-byte word of the matrix over and over.
 // TINY (n_cols < 128: one slice, one workgroup) is the exception: element-wise guarded loads.
-template <bool TINY>
+// PER > 0: every workgroup consumes exactly PER slices, fully unrolled (slices past the last one contribute zeros): with no
+// loop the compiler's load counting is exact and two slices really are in flight behind the one being multiplied; PER == 0
+// is the loop form for long rows (its header waits for everything outstanding).
+template <bool TINY, int PER>
 __global__ __launch_bounds__(kThreads, 2) void small_gram_kernel(const float* __restrict__ G, int n_rows, int64_t n_cols,
-                                                                 int64_t ld, int n_slices, float* __restrict__ slabs) {
+                                                                 int64_t ld, int n_slices, float* __restrict__ slabs,
+                                                                 float* __restrict__ diag_slabs, int32_t* __restrict__ flags) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     int* shifts = reinterpret_cast<int*>(lds + 2 * kPlaneBytes);
     const int tid = threadIdx.x;
@@ -102,6 +106,10 @@ __global__ __launch_bounds__(kThreads, 2) void small_gram_kernel(const float* __
     const int half = lane >> 5, q4 = lane & 31;
     const int n_rb = (n_rows + 31) >> 5;                 // live 32-row blocks
     const int n_blocks = n_rb * (n_rb + 1) / 2;
+    if (blockIdx.x == 0 && tid == 0) {   // what K2 of this call will report to K3 (K3 of the previous call has read its own)
+        flags[0] = 0;
+        flags[1] = 0;
+    }
 
     // lower-triangle blocks of this wave: waves w and w + 4 share a SIMD, no SIMD carries more than three blocks
     int bi0 = 0, bj0 = 0, bi1 = 0, bj1 = 0, nb = 0;
@@ -118,27 +126,30 @@ __global__ __launch_bounds__(kThreads, 2) void small_gram_kernel(const float* __
     if (nb == 2 && bi1 >= n_rb) nb = 1;    // row blocks past the matrix
     if (nb >= 1 && bi0 >= n_rb) nb = 0;
 
-    const float* src[8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        int r = 16 * wave + 2 * i + half;
+    // loads: a thread owns ONE row of the slice -- lane l of wave q holds columns 16 k + 4 (l & 3) .. + 3, k = 0 .. 7, of row
+    // 16 q + (l >> 2): 64 contiguous bytes per row and instruction (half a cache line; the next instruction takes the other
+    // half), and the row's largest magnitude costs 31 local max + 2 DPP steps instead of 5 cross-lane steps per register.
+    const int r_local = 16 * wave + (lane >> 2);
+    const int chunk = lane & 3;
+    const float* src;
+    {
+        int r = r_local;
         if (r > n_rows - 1) r = n_rows - 1;   // rows past the matrix: clamped copies, they land in entries nobody reads
-        src[i] = G + static_cast<int64_t>(r) * ld;
+        src = G + static_cast<int64_t>(r) * ld;
     }
     const int64_t last_k0 = n_cols - kSlice;              // window of the ragged slice (TINY: unused)
     auto load_slice = [&](f32x4 (&v)[8], int s) __attribute__((always_inline)) {
         if constexpr (TINY) {
 #pragma unroll
-            for (int i = 0; i < 8; ++i) v[i] = load4_guarded(src[i], 4 * q4, n_cols);
+            for (int k = 0; k < 8; ++k) v[k] = load4_guarded(src, 16 * k + 4 * chunk, n_cols);
         } else {
             const bool live = s < n_slices;                // uniform
             int64_t k0 = static_cast<int64_t>(s) * kSlice;
             if (k0 > last_k0) k0 = last_k0;
+            const float* ptr = live ? src + k0 + 4 * chunk : G;
+            const int step = live ? 16 : 0;
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const float* ptr = live ? src[i] + k0 + 4 * q4 : G;
-                v[i] = *reinterpret_cast<const f32x4u*>(ptr);
-            }
+            for (int k = 0; k < 8; ++k) v[k] = *reinterpret_cast<const f32x4u*>(ptr + k * step);
         }
     };
 
@@ -193,52 +204,48 @@ __global__ __launch_bounds__(kThreads, 2) void small_gram_kernel(const float* __
     };
 
     // one slice: scale + split into LDS, prefetch into the freed registers, MFMAs, unscaled into `sum`
-    auto consume = [&](f32x4 (&v)[8], int s, int next_slice) __attribute__((always_inline)) {
-        // columns of the ragged slice's window that belong to the slice before it
-        int covered = 0;
-        if constexpr (!TINY) {
+    // MASKED: the slice may be the ragged one (its window overlaps the slice before it) or lie past the end (all zeros)
+    auto consume = [&](f32x4 (&v)[8], int s, int next_slice, auto prefetch_c, auto masked_c) __attribute__((always_inline)) {
+        constexpr bool kPrefetch = decltype(prefetch_c)::value;
+        constexpr bool kMasked = decltype(masked_c)::value;
+        if constexpr (kMasked && !TINY) {
+            // columns of the ragged slice's window that belong to the slice before it
             const int64_t k0 = static_cast<int64_t>(s) * kSlice;
-            covered = k0 > last_k0 ? static_cast<int>(k0 - last_k0) : 0;
+            const int covered = k0 > last_k0 ? static_cast<int>(k0 - last_k0) : 0;
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[k][e] = (16 * k + 4 * chunk + e >= covered) ? v[k][e] : 0.0f;
         }
+        // Largest magnitude of the row's slice.  No special case for inf / NaN input: they make the scaled planes inf / NaN
+        // whatever the shift is, and the poison reaches the Gram entries of that row as it would in any arithmetic.
+        float mx = 0.0f;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int r_local = 16 * wave + 2 * i + half;
-            float x4[4];
-            float mx = 0.0f;
-            bool bad = false;
+        for (int k = 0; k < 8; ++k)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                x4[e] = (4 * q4 + e >= covered) ? v[i][e] : 0.0f;
-                const float a = __builtin_fabsf(x4[e]);
-                bad = bad || !(a <= 3.0e38f);          // inf or NaN: no scaling, the poison propagates as it is
-                mx = __builtin_fmaxf(mx, a);
-            }
-            int flag = bad ? 1 : 0;
+            for (int e = 0; e < 4; ++e) mx = __builtin_fmaxf(mx, __builtin_fabsf(v[k][e]));
+        mx = __builtin_fmaxf(mx, lanes::lane_xor(mx, 1, lane));
+        mx = __builtin_fmaxf(mx, lanes::lane_xor(mx, 2, lane));
+        int shift = 14 + 127 - static_cast<int>((__float_as_uint(mx) >> 23) & 0xffu);   // mx 2^shift in [2^14, 2^15)
+        shift = shift > 126 ? 126 : shift;     // zero and subnormal magnitudes: as far up as a float scale goes
+        shift = shift < -126 ? -126 : shift;
+        const float scale = __uint_as_float(static_cast<uint32_t>(shift + 127) << 23);
+        if (chunk == 0) shifts[r_local] = shift;
+        unsigned char* dst = lds + r_local * kPitch + chunk * 8;
 #pragma unroll
-            for (int msk = 1; msk < 32; msk <<= 1) {   // the 32 lanes that hold this row's slice
-                mx = __builtin_fmaxf(mx, __shfl_xor(mx, msk, 64));
-                flag |= __shfl_xor(flag, msk, 64);
-            }
-            int shift = 14 - (static_cast<int>((__float_as_uint(mx) >> 23) & 0xffu) - 127);   // mx 2^shift in [2^14, 2^15)
-            shift = mx < 1.17549435e-38f ? 126 : shift;   // subnormal magnitudes: as far up as a float scale goes
-            shift = shift > 126 ? 126 : shift;
-            shift = shift < -126 ? -126 : shift;
-            shift = (flag != 0 || !(mx > 0.0f)) ? 0 : shift;
-            const float scale = __uint_as_float(static_cast<uint32_t>(shift + 127) << 23);
-            if (q4 == 0) shifts[r_local] = shift;
+        for (int k = 0; k < 8; ++k) {
             f16x4 h, m;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                const float x = x4[e] * scale;
+                const float x = v[k][e] * scale;
                 h[e] = static_cast<_Float16>(x);
                 m[e] = static_cast<_Float16>(x - static_cast<float>(h[e]));   // x - h is exact in fp32
             }
-            unsigned char* dst = lds + r_local * kPitch + q4 * 8;
-            *reinterpret_cast<u32x2*>(dst) = __builtin_bit_cast(u32x2, h);
-            *reinterpret_cast<u32x2*>(dst + kPlaneBytes) = __builtin_bit_cast(u32x2, m);
+            *reinterpret_cast<u32x2*>(dst + 32 * k) = __builtin_bit_cast(u32x2, h);
+            *reinterpret_cast<u32x2*>(dst + 32 * k + kPlaneBytes) = __builtin_bit_cast(u32x2, m);
         }
         __syncthreads();
-        if constexpr (!TINY) load_slice(v, next_slice);   // lands while the MFMAs run (a dummy word past the last slice)
+        if constexpr (!TINY && kPrefetch) load_slice(v, next_slice);   // lands while the MFMAs run (a dummy word past the last slice)
         if (nb == 2) multiply(std::integral_constant<int, 2>{});
         else if (nb == 1) multiply(std::integral_constant<int, 1>{});
         __syncthreads();   // the planes and shifts are rewritten by the next slice
@@ -246,19 +253,39 @@ __global__ __launch_bounds__(kThreads, 2) void small_gram_kernel(const float* __
 
     f32x4 va[8], vb[8];
     const int g = gridDim.x;
+    constexpr std::true_type yes{};
+    constexpr std::false_type no{};
     if constexpr (TINY) {
         load_slice(va, 0);
-        consume(va, 0, 1);
+        consume(va, 0, 1, no, no);
+    } else if constexpr (PER > 0) {
+        // the host sizes the grid so that (PER - 1) * grid < n_slices: only the last step can hold the ragged slice or none
+        const int s = blockIdx.x;
+        load_slice(va, s);
+        if constexpr (PER > 1) load_slice(vb, s + g);
+#define BYZ_STEP(c, buf)                                                                          \
+    if constexpr (PER > c) {                                                                      \
+        if constexpr (PER > c + 2) consume(buf, s + c * g, s + (c + 2) * g, yes, no);             \
+        else if constexpr (PER > c + 1) consume(buf, s + c * g, 0, no, no);                       \
+        else consume(buf, s + c * g, 0, no, yes);                                                 \
+    }
+        BYZ_STEP(0, va) BYZ_STEP(1, vb) BYZ_STEP(2, va) BYZ_STEP(3, vb) BYZ_STEP(4, va) BYZ_STEP(5, vb) BYZ_STEP(6, va) BYZ_STEP(7, vb)
+#undef BYZ_STEP
     } else {
+        // long rows: four slices per trip (the loop header waits for every outstanding load, the other three do not)
         int s = blockIdx.x;
         load_slice(va, s);
         load_slice(vb, s + g);
-        consume(va, s, s + 2 * g);            // grid <= n_slices: every workgroup has a first slice
-        while (s + g < n_slices) {
-            consume(vb, s + g, s + 3 * g);
-            s += 2 * g;
+        while (true) {
+            consume(va, s, s + 2 * g, yes, yes);
+            if (s + g >= n_slices) break;
+            consume(vb, s + g, s + 3 * g, yes, yes);
+            if (s + 2 * g >= n_slices) break;
+            consume(va, s + 2 * g, s + 4 * g, yes, yes);
+            if (s + 3 * g >= n_slices) break;
+            consume(vb, s + 3 * g, s + 5 * g, yes, yes);
+            s += 4 * g;
             if (s >= n_slices) break;
-            consume(va, s, s + 2 * g);
         }
     }
 
@@ -269,7 +296,12 @@ __global__ __launch_bounds__(kThreads, 2) void small_gram_kernel(const float* __
             const int bi = b == 0 ? bi0 : bi1, bj = b == 0 ? bj0 : bj1;
             float* blk = out + block_index(bi, bj) * kBlockEntries;
 #pragma unroll
-            for (int e = 0; e < 16; ++e) blk[((e & 3) + 8 * (e >> 2) + 4 * half) * 32 + q4] = sum[b][e];
+            for (int e = 0; e < 16; ++e) {
+                const int il = (e & 3) + 8 * (e >> 2) + 4 * half;
+                blk[il * 32 + q4] = sum[b][e];
+                // the diagonal once more, compactly: K2 needs c_ii and c_jj next to every c_ij
+                if (bi == bj && il == q4) diag_slabs[static_cast<int64_t>(blockIdx.x) * kMaxRows + 32 * bi + q4] = sum[b][e];
+            }
         }
     }
 }
@@ -277,26 +309,61 @@ __global__ __launch_bounds__(kThreads, 2) void small_gram_kernel(const float* __
 // ---- K2 ---------------------------------------------------------------------------------------------------------------
 // gram[entry] = sum over the slabs, fp64, fixed order: wave q adds slabs q, q + 8, ... on four independent chains, the
 // eight waves' sums are combined as a fixed tree.  Workgroup = 64 consecutive entries of one block (256 bytes per slab).
-__global__ __launch_bounds__(kThreads) void small_reduce_kernel(const float* __restrict__ slabs, int n_slabs, int n_blocks,
-                                                                double* __restrict__ gram) {
-    __shared__ double part[8][64];
+// c_ii and c_jj come out of the compact diagonal slabs by the very same summation (bitwise the sums of the workgroups that
+// own those entries), so that d_ij = sqrt(max(0, c_ii + c_jj - 2 c_ij)) is formed right here, on 160 CUs instead of one.
+// flags[0] counts the pairs the Gram identity cannot resolve (d^2 < (c_ii + c_jj) / 16: near-duplicate or identical rows),
+// flags[1] the exact zeros: while both stay 0 -- the normal case -- K3 has nothing to do.
+__global__ __launch_bounds__(kThreads) void small_reduce_kernel(const float* __restrict__ slabs,
+                                                                const float* __restrict__ diag_slabs, int n_slabs, int n_blocks,
+                                                                int n, double* __restrict__ gram, float* __restrict__ dist,
+                                                                int32_t* __restrict__ flags) {
+    __shared__ double part[3][8][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int64_t entry = static_cast<int64_t>(blockIdx.x) * 64 + lane;
+    const int entry = static_cast<int>(blockIdx.x) * 64 + lane;
+    const int blk = entry >> 10, local = entry & 1023;
+    const int bi = blk >= 6 ? 3 : (blk >= 3 ? 2 : (blk >= 1 ? 1 : 0));
+    const int bj = blk - bi * (bi + 1) / 2;
+    const int il = local >> 5, jl = local & 31;
+    const int i = 32 * bi + il, j = 32 * bj + jl;
     const int64_t slab = static_cast<int64_t>(n_blocks) * kBlockEntries;
-    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    double s[4] = {0.0, 0.0, 0.0, 0.0}, a[4] = {0.0, 0.0, 0.0, 0.0}, b[4] = {0.0, 0.0, 0.0, 0.0};
     int sl = wave;
     for (; sl + 24 < n_slabs; sl += 32) {
-        s0 += static_cast<double>(slabs[(sl + 0) * slab + entry]);
-        s1 += static_cast<double>(slabs[(sl + 8) * slab + entry]);
-        s2 += static_cast<double>(slabs[(sl + 16) * slab + entry]);
-        s3 += static_cast<double>(slabs[(sl + 24) * slab + entry]);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            s[c] += static_cast<double>(slabs[(sl + 8 * c) * slab + entry]);
+            a[c] += static_cast<double>(diag_slabs[(sl + 8 * c) * kMaxRows + i]);
+            b[c] += static_cast<double>(diag_slabs[(sl + 8 * c) * kMaxRows + j]);
+        }
     }
-    for (; sl < n_slabs; sl += 8) s0 += static_cast<double>(slabs[sl * slab + entry]);
-    part[wave][lane] = (s0 + s1) + (s2 + s3);
+    for (; sl < n_slabs; sl += 8) {
+        s[0] += static_cast<double>(slabs[sl * slab + entry]);
+        a[0] += static_cast<double>(diag_slabs[sl * kMaxRows + i]);
+        b[0] += static_cast<double>(diag_slabs[sl * kMaxRows + j]);
+    }
+    part[0][wave][lane] = (s[0] + s[1]) + (s[2] + s[3]);
+    part[1][wave][lane] = (a[0] + a[1]) + (a[2] + a[3]);
+    part[2][wave][lane] = (b[0] + b[1]) + (b[2] + b[3]);
     __syncthreads();
-    if (wave == 0)
-        gram[entry] = ((part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane])) +
-                      ((part[4][lane] + part[5][lane]) + (part[6][lane] + part[7][lane]));
+    if (wave != 0) return;
+    double tot[3];
+#pragma unroll
+    for (int v = 0; v < 3; ++v)
+        tot[v] = ((part[v][0][lane] + part[v][1][lane]) + (part[v][2][lane] + part[v][3][lane])) +
+                 ((part[v][4][lane] + part[v][5][lane]) + (part[v][6][lane] + part[v][7][lane]));
+    const double cij = tot[0], cii = tot[1], cjj = tot[2];
+    gram[entry] = cij;
+    if (i >= n || j >= n || j > i) return;   // padding rows; the upper half of a diagonal block (its mirror image is written)
+    if (i == j) {
+        dist[static_cast<int64_t>(i) * n + i] = __builtin_inff();   // the reference keeps no self-distance (defences.py:18-20)
+        return;
+    }
+    const double d2 = cii + cjj - 2.0 * cij;
+    const float d = static_cast<float>(sqrt(d2 < 0.0 ? 0.0 : d2));   // NaN (poisoned input) stays NaN
+    dist[static_cast<int64_t>(i) * n + j] = d;
+    dist[static_cast<int64_t>(j) * n + i] = d;
+    if (d2 < kNearEps * (cii + cjj)) atomicAdd(flags + 0, 1);
+    if (d == 0.0f) atomicAdd(flags + 1, 1);
 }
 
 // ---- K3 ---------------------------------------------------------------------------------------------------------------
@@ -311,7 +378,7 @@ struct DistanceArgs {
     int pair_capacity;
     double* pair_partial;      // (pair, chunk) sums of squared differences
     int64_t item_capacity;
-    int32_t* sync;             // [0] flag (epoch) [1] published pair count [2] arrivals
+    int32_t* sync;             // [0] flag (epoch) [1] published pair count [2] arrivals [4], [5] K2's findings
     int32_t epoch;
     int32_t* status;
 };
@@ -373,13 +440,17 @@ __global__ __launch_bounds__(kThreads) void small_distance_kernel(DistanceArgs p
     const int n_chunks = static_cast<int>((p.n_cols + kPairChunk - 1) / kPairChunk);
     const int helpers = static_cast<int>(gridDim.x) - 1;
 
+    // K2 has already written the distances; unless it met a pair the Gram identity cannot resolve (near-duplicate rows) or an
+    // exact zero (identical rows), there is nothing left to do here.  Uniform over the grid: nobody waits for anybody.
+    if (p.sync[4] == 0 && p.sync[5] == 0) return;
+
     if (blockIdx.x != 0) {
         // ---- helper: wait for the worker's pair count
         if (tid == 0) {
             unsigned spins = 0;
             int seen = 0;
             while (__hip_atomic_load(p.sync + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != p.epoch) {
-                __builtin_amdgcn_s_sleep(4);
+                __builtin_amdgcn_s_sleep(16);
                 if (++spins > kSpinLimit) {
                     seen = -2;
                     break;
@@ -412,25 +483,42 @@ __global__ __launch_bounds__(kThreads) void small_distance_kernel(DistanceArgs p
     }
 
     // ---- worker
+    const int lane = tid & 63, wave = tid >> 6;
     const int n_rb = (n + 31) >> 5;
     const int n_entries = n_rb * (n_rb + 1) / 2 * kBlockEntries;
-    for (int e = tid; e < n_entries; e += kThreads) gl[e] = p.gram[e];
+    {   // the Gram blocks into LDS: every load issued before the first use (a loop of dependent round trips otherwise)
+        typedef double f64x2 __attribute__((ext_vector_type(2)));
+        constexpr int kPer = kMaxBlocks * kBlockEntries / 2 / kThreads;   // 10 16-byte loads per thread
+        const f64x2* src = reinterpret_cast<const f64x2*>(p.gram);
+        const int n_vec = n_entries / 2;
+        f64x2 tmp[kPer];
+#pragma unroll
+        for (int k = 0; k < kPer; ++k) {
+            const int e = tid + k * kThreads;
+            tmp[k] = src[e < n_vec ? e : 0];
+        }
+#pragma unroll
+        for (int k = 0; k < kPer; ++k) {
+            const int e = tid + k * kThreads;
+            if (e < n_vec) reinterpret_cast<f64x2*>(gl)[e] = tmp[k];
+        }
+    }
     if (tid == 0) words[0] = 0;
     __syncthreads();
     // rep[i] = the first j < i whose Gram entries are bitwise those of i (c_ij == c_ii == c_jj): identical rows nominate
-    // each other this way in any arithmetic; the proof is the pair (i, rep[i]) on the list below
-    if (tid < n) {
-        const int i = tid;
+    // each other this way in any arithmetic; the proof is the pair (i, rep[i]) on the list below.  One wave per row, the
+    // lanes look at two candidates each.
+    for (int i = wave; i < n; i += kThreads / 64) {
         const unsigned long long cii = bits_of(gram_at(gl, i, i));
-        int best = i;
-        for (int j = 0; j < i; ++j) {
-            if (bits_of(gram_at(gl, i, j)) == cii && bits_of(gram_at(gl, j, j)) == cii) {
-                best = j;
-                break;
-            }
+        const int j0 = lane, j1 = lane + 64;
+        const bool h0 = j0 < i && bits_of(gram_at(gl, i, j0)) == cii && bits_of(gram_at(gl, j0, j0)) == cii;
+        const bool h1 = j1 < i && bits_of(gram_at(gl, i, j1 < n ? j1 : 0)) == cii && bits_of(gram_at(gl, j1 < n ? j1 : 0, j1 < n ? j1 : 0)) == cii;
+        const unsigned long long m0 = __ballot(h0), m1 = __ballot(h1);
+        const int best = m0 ? __builtin_ctzll(m0) : (m1 ? 64 + __builtin_ctzll(m1) : i);
+        if (lane == 0) {
+            rep[i] = best;
+            p.rep[i] = best;
         }
-        rep[i] = best;
-        p.rep[i] = best;
     }
     __syncthreads();
     for (int idx = tid; idx < n * n; idx += kThreads) {
@@ -516,26 +604,28 @@ __global__ __launch_bounds__(kThreads) void small_distance_kernel(DistanceArgs p
     // Identical rows must end up with bitwise identical distance rows (the reference resolves their exactly tied scores by
     // visit order): rep2[i] = the smallest j with d_ij == 0, chains followed to their root, every member of a group takes
     // the group's first row (gram.hip: canonicalise_duplicates).
-    if (tid < n) {
-        int best = tid;
-        for (int j = 0; j < tid; ++j) {
-            if (dl[tid * kDistPitch + j] == 0.0f) {
-                best = j;
-                break;
-            }
-        }
-        rep2[tid] = best;
+    bool any_twin = false;
+    for (int i = wave; i < n; i += kThreads / 64) {
+        const int j0 = lane, j1 = lane + 64;
+        const bool h0 = j0 < i && dl[i * kDistPitch + j0] == 0.0f;
+        const bool h1 = j1 < i && dl[i * kDistPitch + j1] == 0.0f;
+        const unsigned long long m0 = __ballot(h0), m1 = __ballot(h1);
+        const int best = m0 ? __builtin_ctzll(m0) : (m1 ? 64 + __builtin_ctzll(m1) : i);
+        if (lane == 0) rep2[i] = best;
+        any_twin = any_twin || best != i;
     }
-    __syncthreads();
-    for (int round = 0; round < 8; ++round) {   // rep2[i] < i along a chain: pointer jumping, log2(128) rounds at most
-        int r = 0, rr = 0;
-        if (tid < n) {
-            r = rep2[tid];
-            rr = rep2[r];
+    any_twin = __syncthreads_or(any_twin ? 1 : 0) != 0;
+    if (any_twin) {
+        for (int round = 0; round < 8; ++round) {   // rep2[i] < i along a chain: pointer jumping, log2(128) rounds at most
+            int r = 0, rr = 0;
+            if (tid < n) {
+                r = rep2[tid];
+                rr = rep2[r];
+            }
+            __syncthreads();
+            if (tid < n && rr != r) rep2[tid] = rr;
+            if (!__syncthreads_or(tid < n && rr != r ? 1 : 0)) break;
         }
-        __syncthreads();
-        if (tid < n && rr != r) rep2[tid] = rr;
-        if (!__syncthreads_or(tid < n && rr != r ? 1 : 0)) break;
     }
     for (int idx = tid; idx < n * n; idx += kThreads) {
         const int i = idx / n, j = idx - i * n;
@@ -638,8 +728,8 @@ int env_int(const char* name, int fallback) {
 
 }  // namespace
 
-// BYZ_KRUM_SMALL: 0 = the general path, 1 = this file.  Default 0 until a GPU visit has confirmed the parity tests.
-bool krum_small_enabled() { return env_int("BYZ_KRUM_SMALL", 0) != 0; }
+// BYZ_KRUM_SMALL: 0 = the general path, 1 (default) = this file.
+bool krum_small_enabled() { return env_int("BYZ_KRUM_SMALL", 1) != 0; }
 
 bool krum_small_applies(int64_t n_rows, int64_t n_cols) {
     // fp32 running sums over at most ~32 slices per workgroup keep the Gram at 1e-7; longer rows take the general path
@@ -656,9 +746,11 @@ int launch_small_distances(byz_ctx* ctx, const float* G, int64_t n_rows, int64_t
     const int n_blocks = n_rb * (n_rb + 1) / 2;
     const int64_t n_slices = ceil_div(n_cols, kSlice);
     // one workgroup per CU at most; the grid is sized so that everybody gets the same number of slices (+- 1)
-    const int64_t per = ceil_div(n_slices, ctx->num_cus);
-    const int grid = static_cast<int>(ceil_div(n_slices, per));
-    BYZ_TRY(ctx->gram_partials.ensure(static_cast<size_t>(grid) * n_blocks * kBlockEntries * sizeof(float)));
+    const int grid = static_cast<int>(ceil_div(n_slices, ceil_div(n_slices, ctx->num_cus)));
+    const int64_t per = ceil_div(n_slices, grid);   // (per - 1) * grid < n_slices: only a workgroup's last slice can be ragged or missing
+    // one slab of blocks per workgroup, then one compact diagonal per workgroup
+    const size_t slab_floats = static_cast<size_t>(grid) * n_blocks * kBlockEntries;
+    BYZ_TRY(ctx->gram_partials.ensure((slab_floats + static_cast<size_t>(grid) * kMaxRows) * sizeof(float)));
     BYZ_TRY(ctx->gram.ensure(static_cast<size_t>(kMaxBlocks) * kBlockEntries * sizeof(double)));
     BYZ_TRY(ctx->gram_rep.ensure(static_cast<size_t>(kMaxRows) * sizeof(int32_t)));
     const int pair_capacity = kMaxRows * (kMaxRows - 1) / 2;
@@ -669,29 +761,54 @@ int launch_small_distances(byz_ctx* ctx, const float* G, int64_t n_rows, int64_t
         BYZ_TRY(ctx->small_sync.ensure(64));
         BYZ_HIP(hipMemsetAsync(ctx->small_sync.ptr, 0, 64, stream));
     }
+    float* slabs = ctx->gram_partials.as<float>();
+    float* diag_slabs = slabs + slab_floats;
+    int32_t* flags = ctx->small_sync.as<int32_t>() + 4;
     static bool configured = false;
     if (!configured) {
-        BYZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&small_gram_kernel<false>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, kGramLds));
-        BYZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&small_gram_kernel<true>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, kGramLds));
+#define BYZ_ATTR(T, P)                                                                            \
+    BYZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&small_gram_kernel<T, P>),          \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, kGramLds))
+        BYZ_ATTR(true, 0);
+        BYZ_ATTR(false, 0);
+        BYZ_ATTR(false, 1);
+        BYZ_ATTR(false, 2);
+        BYZ_ATTR(false, 3);
+        BYZ_ATTR(false, 4);
+        BYZ_ATTR(false, 5);
+        BYZ_ATTR(false, 6);
+        BYZ_ATTR(false, 7);
+        BYZ_ATTR(false, 8);
+#undef BYZ_ATTR
         BYZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&small_distance_kernel),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, kK3Lds));
         configured = true;
     }
     {
         KernelTimer t(ctx, BYZ_K_GRAM, stream);
-        if (n_cols < kSlice)
-            small_gram_kernel<true><<<1, kThreads, kGramLds, stream>>>(G, n, n_cols, ld, 1, ctx->gram_partials.as<float>());
-        else
-            small_gram_kernel<false><<<static_cast<unsigned>(grid), kThreads, kGramLds, stream>>>(
-                G, n, n_cols, ld, static_cast<int>(n_slices), ctx->gram_partials.as<float>());
+        const int unrolled = env_int("BYZ_KRUM_SMALL_UNROLL", 1) != 0 && per <= 8 ? static_cast<int>(per) : 0;
+#define BYZ_K1(T, P)                                                                               \
+    small_gram_kernel<T, P><<<static_cast<unsigned>(T ? 1 : grid), kThreads, kGramLds, stream>>>(    \
+        G, n, n_cols, ld, static_cast<int>(T ? 1 : n_slices), slabs, diag_slabs, flags)
+        if (n_cols < kSlice) BYZ_K1(true, 0);
+        else switch (unrolled) {
+            case 1: BYZ_K1(false, 1); break;
+            case 2: BYZ_K1(false, 2); break;
+            case 3: BYZ_K1(false, 3); break;
+            case 4: BYZ_K1(false, 4); break;
+            case 5: BYZ_K1(false, 5); break;
+            case 6: BYZ_K1(false, 6); break;
+            case 7: BYZ_K1(false, 7); break;
+            case 8: BYZ_K1(false, 8); break;
+            default: BYZ_K1(false, 0); break;
+        }
+#undef BYZ_K1
         BYZ_TRY(check_launch("small_gram_kernel"));
     }
     {
         KernelTimer t(ctx, BYZ_K_GRAM_REDUCE, stream);
         small_reduce_kernel<<<static_cast<unsigned>(n_blocks * kBlockEntries / 64), kThreads, 0, stream>>>(
-            ctx->gram_partials.as<float>(), grid, n_blocks, ctx->gram.as<double>());
+            slabs, diag_slabs, grid, n_blocks, n, ctx->gram.as<double>(), dist, flags);
         BYZ_TRY(check_launch("small_reduce_kernel"));
     }
     {

@@ -97,11 +97,14 @@ def one_case(eng, n, d, f, family, seed):
     return ok and same_idx
 
 
-def timing(eng, n, d, f, rounds=300):
+def timing(eng, n, d, f, rounds=200):
     g = make(n, d, 77, 'scaled')
     buf = eng.to_device(g)
-    for mode in ('0', '1'):
-        os.environ['BYZ_KRUM_SMALL'] = mode
+    for mode in ('0', '1', '1u0'):
+        os.environ['BYZ_KRUM_SMALL'] = mode[0]
+        os.environ.pop('BYZ_KRUM_SMALL_UNROLL', None)
+        if 'u' in mode:
+            os.environ['BYZ_KRUM_SMALL_UNROLL'] = mode.split('u')[1]
         for _ in range(20):
             eng.krum(buf, n, f)
         eng.synchronize()
@@ -145,7 +148,7 @@ def main():
                 say('too many early failures: stopping the cases')
                 break
     say('cases failed:', bad, 'of', len(cases))
-    for n, d in ((100, 79510), (100, 21840)):
+    for n, d in ((100, 79510), (100, 21840), (100, 1000000), (128, 79510)):
         try:
             timing(eng, n, d, 24)
         except Exception as e:
