@@ -255,6 +255,88 @@ def test_identical_rows_have_zero_distance_and_tie_exactly(eng):
     assert idx == want
 
 
+# ---- N <= 128 (csrc/krum_small.hip, the default there) next to the general path ----------------------------------
+def _small_family(n, d, family, seed):
+    rng = np.random.default_rng(seed)
+    g = scaled(seed, n, d)
+    if family == 'attack':          # the first quarter of the rows are one vector (malicious.py:26-27)
+        m = max(2, n // 4)
+        g[:m] = (g[:m].mean(axis=0) - 1.5 * g[:m].std(axis=0)).astype(np.float32)
+    elif family == 'near':          # two rows that nearly coincide, one exact copy
+        g[5] = g[3] + np.float32(1e-4) * rng.standard_normal(d).astype(np.float32)
+        g[7] = g[2]
+    elif family == 'tiny':
+        g *= np.float32(1e-6)
+    elif family == 'mixed':         # rows on very different scales
+        g *= (10.0 ** rng.integers(-6, 6, size=n)).astype(np.float32)[:, None]
+    return g
+
+
+@pytest.mark.parametrize('n,d,f,family', [(10, 204, 2, 'scaled'), (33, 129, 8, 'scaled'), (64, 100, 10, 'scaled'),
+                                          (5, 7, 1, 'scaled'), (100, 21840, 24, 'scaled'), (100, 79510, 24, 'scaled'),
+                                          (128, 4099, 30, 'scaled'), (128, 128, 31, 'scaled'), (97, 8190, 24, 'attack'),
+                                          (100, 79510, 24, 'attack'), (40, 5000, 9, 'near'), (100, 79510, 24, 'near'),
+                                          (50, 3000, 12, 'tiny'), (50, 3000, 12, 'mixed'), (2, 300, 0, 'scaled'),
+                                          (128, 40000, 31, 'attack'), (100, 255, 24, 'near'), (128, 127, 20, 'attack')])
+def test_small_krum_path_next_to_the_general_path(eng, monkeypatch, n, d, f, family):
+    """Both implementations of Krum for N <= 128 on the same rows: distances against the norm of the fp32 difference
+    (defences.py:20) in fp64, the index against the reference's loop run on each path's OWN distance matrix, exact zeros
+    and bitwise equal distance rows for identical rows, and the two paths against each other."""
+    g = _small_family(n, d, family, 900 + n + d % 97)
+    want = np.empty((n, n))
+    for i in range(n):
+        diff = (g[i][None, :] - g).astype(np.float32).astype(np.float64)
+        want[i] = np.sqrt((diff * diff).sum(axis=1))
+    off = ~np.eye(n, dtype=bool)
+    got = {}
+    for mode in ('0', '1'):
+        monkeypatch.setenv('BYZ_KRUM_SMALL', mode)
+        dm = eng.pairwise_distances(g).numpy()
+        idx = eng.krum(g, n, f, return_index=True)
+        row = eng.krum(g, n, f)
+        eng.check()
+        assert np.all(np.isinf(np.diag(dm))) and np.array_equal(dm, dm.T)
+        zero = want[off] == 0
+        assert np.all(dm[off][zero] == 0.0)
+        rel = np.abs(dm[off][~zero] - want[off][~zero]) / want[off][~zero]
+        assert rel.max() < 1e-6, (mode, rel.max())
+        assert idx == faithful.krum_pick(dm, faithful.visit_order(n), n, f), mode
+        assert np.array_equal(row, g[idx])
+        got[mode] = (dm, idx)
+    assert got['0'][1] == got['1'][1]
+    if family == 'attack':
+        m = max(2, n // 4)
+        dm = got['1'][0]
+        assert all(np.array_equal(dm[0, m:], dm[i, m:]) for i in range(1, m))
+
+
+def test_small_krum_path_covers_selection_and_bulyan(eng, monkeypatch, golden):
+    """The entry points that share the N <= 128 kernels: krum_select on a given matrix (scores as the reference's sum()
+    forms them), Bulyan end to end, and the golden Krum cases through the GENERAL path too (it stays reachable)."""
+    rng = np.random.default_rng(77)
+    for n, f in ((2, 0), (3, 1), (17, 4), (100, 24), (128, 31)):
+        pts = rng.standard_normal((n, 9)).astype(np.float32)
+        dist = np.sqrt(((pts[:, None, :] - pts[None, :, :]) ** 2).sum(-1)).astype(np.float32)
+        dist[np.arange(n), np.arange(n)] = np.inf
+        dist[0, 1] = dist[1, 0]
+        want = faithful.krum_pick(dist, faithful.visit_order(n), n, f)
+        for mode in ('0', '1'):
+            monkeypatch.setenv('BYZ_KRUM_SMALL', mode)
+            assert eng.krum_select(dist, n, f) == want, (n, f, mode)
+    g = scaled(4242, 43, 3000)
+    monkeypatch.setenv('BYZ_KRUM_SMALL', '0')
+    a, sel_a = eng.bulyan(g, 43, 10, return_selection=True)
+    monkeypatch.setenv('BYZ_KRUM_SMALL', '1')
+    b, sel_b = eng.bulyan(g, 43, 10, return_selection=True)
+    assert np.array_equal(np.asarray(sel_a), np.asarray(sel_b)) and close(a, b)
+    monkeypatch.setenv('BYZ_KRUM_SMALL', '0')
+    for case in ('krum_iid_10x257', 'krum_scaled_33x1000', 'krum_attacked_12x300', 'krum_allsame_6x64', 'krum_f0_5x40'):
+        c = golden[case]
+        n, f = len(c['G']), int(c['f'])
+        assert eng.krum_select(c['dist'], n, f) == int(c['index'])
+        assert eng.krum(c['G'], n, f, return_index=True) == int(c['index'])
+
+
 @pytest.mark.parametrize('n,f', [(2, 0), (5, 1), (64, 15), (100, 24), (128, 31), (333, 80), (1000, 240)])
 def test_krum_selection_is_bit_exact_given_distances(eng, n, f):
     rng = np.random.default_rng(2000 + n)
