@@ -406,6 +406,92 @@ __device__ __forceinline__ float reference_score(const float* __restrict__ sorte
     return carry;
 }
 
+// The same score as a PLAIN dependent chain of fp32 additions (round 2, late; BYZ_BULYAN_RESCORE=plain, not the default yet).
+// What three experiments on the re-score say (profiles/r02q_*, r02r_*, r02s_*, r02t_*): 512 entries per integer reduction,
+// ties summed by an exact parity rule with everything independent of the sum hoisted out of the chain, and this literal
+// chain all give the SAME selections and the SAME ~2.5 us per 512 entries as reference_score -- so the time is not the
+// arithmetic, it is the table entries: reference_score asks for a batch one batch ahead (and its conditional loads make
+// hipcc wait for them early), ~2.5 us of HBM latency per batch that nothing overlaps.  Here the entries of FOUR batches are
+// in flight (unconditional loads at clamped positions; what lies past the row is masked when it is used), the entries of a
+// batch (zeros for removed columns and past the prefix) go to LDS in order, and every lane of the wave adds them up left to
+// right from broadcast reads -- the reference's loop, literally.  Measured with ONE batch in flight: identical selections
+// on four matrices up to N = 10,000, 255 vs 262 ms; the four-deep ring is unmeasured.
+__device__ __forceinline__ float reference_score_plain(const float* __restrict__ sorted_val, const uint16_t* __restrict__ sorted_idx,
+                                                       const uint32_t* removed, int n, int u, int take, int lane,
+                                                       float* __restrict__ stage) {
+    constexpr int kDepth = 8;
+    constexpr int kBatch = 64 * kDepth;
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    const uint16_t* order = sorted_idx + static_cast<int64_t>(u) * n;
+    const float* vals = sorted_val + static_cast<int64_t>(u) * n;
+    float carry = 0.0f;
+    int got = 0;
+    struct Buf {
+        int col[kDepth];
+        float v[kDepth];
+    };
+    auto fetch = [&](Buf& b, int r0) __attribute__((always_inline)) {
+#pragma unroll
+        for (int k = 0; k < kDepth; ++k) {
+            int r = r0 + 64 * k + lane;
+            r = r < n ? r : n - 1;                 // nothing conditional about the load itself
+            b.col[k] = order[r];
+            b.v[k] = vals[r];
+        }
+    };
+    auto consume = [&](const Buf& b, int r0) __attribute__((always_inline)) {
+        int chunks = 0;             // chunks of this batch that hold an entry of the prefix
+#pragma unroll
+        for (int k = 0; k < kDepth; ++k) {
+            const bool inside = r0 + 64 * k + lane < n;
+            const int c = b.col[k];
+            const bool live = inside && c != u && !((removed[c >> 5] >> (c & 31)) & 1u);
+            const unsigned long long m = __ballot(live);
+            const int before = __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(m >> 32),
+                                                         __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(m), 0));
+            stage[64 * k + lane] = (live && got + before < take) ? b.v[k] : 0.0f;   // past the prefix: + 0.0 (exact)
+            if (m != 0ull && got < take) chunks = k + 1;
+            got += __popcll(m);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        const f32x4* src = reinterpret_cast<const f32x4*>(stage);
+        // one chunk per trip: 16 broadcast reads (every lane the same addresses) issued together, then the 64 additions --
+        // only the first read's latency is exposed per trip (hipcc folds a hand-pipelined loop back into this shape)
+        for (int k = 0; k < chunks; ++k) {
+            f32x4 e[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) e[i] = src[16 * k + i];
+#pragma unroll
+            for (int i = 0; i < 16; ++i)
+                carry = __fadd_rn(__fadd_rn(__fadd_rn(__fadd_rn(carry, e[i].x), e[i].y), e[i].z), e[i].w);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // the batch is read before the next one overwrites it
+        __builtin_amdgcn_wave_barrier();
+    };
+    Buf a, b, c, d;
+    fetch(a, 0);
+    fetch(b, kBatch);
+    fetch(c, 2 * kBatch);
+    fetch(d, 3 * kBatch);
+    for (int r0 = 0;; r0 += 4 * kBatch) {
+        consume(a, r0);
+        if (r0 + kBatch >= n || got >= take) break;
+        fetch(a, r0 + 4 * kBatch);
+        consume(b, r0 + kBatch);
+        if (r0 + 2 * kBatch >= n || got >= take) break;
+        fetch(b, r0 + 5 * kBatch);
+        consume(c, r0 + 2 * kBatch);
+        if (r0 + 3 * kBatch >= n || got >= take) break;
+        fetch(c, r0 + 6 * kBatch);
+        consume(d, r0 + 3 * kBatch);
+        if (r0 + 4 * kBatch >= n || got >= take) break;
+        fetch(d, r0 + 7 * kBatch);
+    }
+    return carry;
+}
+
 struct GridDecision {
     int mode;        // 0 winner known, 1 round 2, 2 no candidate, 3 exchange timed out
     int winner;
@@ -416,8 +502,9 @@ __global__ __launch_bounds__(kGridThreads) void bulyan_grid_kernel(
     const float* __restrict__ dist, int n, int theta, int drop, int users_count, int corrupted,
     const uint16_t* __restrict__ sorted_idx, const uint16_t* __restrict__ rank_t, const float* __restrict__ sorted_val,
     const double* __restrict__ row_total, const double* __restrict__ row_top, const int32_t* __restrict__ cls,
-    unsigned long long* __restrict__ xchg, float band_scale, int32_t* __restrict__ selection,
+    unsigned long long* __restrict__ xchg, float band_scale, int rescore_plain, int32_t* __restrict__ selection,
     int32_t* __restrict__ status, int32_t* __restrict__ rescored) {
+    __shared__ __attribute__((aligned(16))) float rescore_stage[kGridThreads / 64][512];
     __shared__ Candidate slots[kGridThreads / 64];
     __shared__ double second_slots[kGridThreads / 64];
     __shared__ uint32_t removed[kMaxSelectRows / 32];
@@ -555,7 +642,9 @@ __global__ __launch_bounds__(kGridThreads) void bulyan_grid_kernel(
             Candidate r{static_cast<double>(kKrumInit), 0x7fffffff, -1};
             for (int k = wave; k < n_lead; k += kGridThreads / 64) {
                 const int row = wg * kGridThreads + leaders[k];
-                const float s32 = reference_score(sorted_val, sorted_idx, removed, n, row, take, lane);
+                const float s32 = rescore_plain
+                    ? reference_score_plain(sorted_val, sorted_idx, removed, n, row, take, lane, rescore_stage[wave])
+                    : reference_score(sorted_val, sorted_idx, removed, n, row, take, lane);
                 if (s32 < kKrumInit) {
                     Candidate o{static_cast<double>(s32), visit_position(row), row};
                     if (better(o, r)) r = o;
@@ -694,6 +783,10 @@ int launch_bulyan_loop(byz_ctx* ctx, const float* dist, int64_t n, int64_t theta
     if (const char* e = std::getenv("BYZ_BULYAN_BAND")) {
         if (std::strcmp(e, "rigorous") != 0) band_scale = static_cast<float>(std::atof(e));
     }
+    // BYZ_BULYAN_RESCORE=plain: the re-score as a literal chain of fp32 additions with four batches of table entries in
+    // flight (reference_score_plain; the ring is still to be measured, so not the default)
+    int rescore_plain = 0;
+    if (const char* e = std::getenv("BYZ_BULYAN_RESCORE")) rescore_plain = std::strcmp(e, "plain") == 0 ? 1 : 0;
     BYZ_HIP(hipMemsetAsync(ctx->xchg.ptr, 0, static_cast<size_t>(2 * 3 * kGridMaxWgs) * sizeof(unsigned long long), stream));
     BYZ_HIP(hipMemsetAsync(status_dev, 0, 2 * sizeof(int32_t), stream));
     KernelTimer t(ctx, BYZ_K_BULYAN_LOOP, stream);
@@ -705,7 +798,7 @@ int launch_bulyan_loop(byz_ctx* ctx, const float* dist, int64_t n, int64_t theta
     bulyan_grid_kernel<<<n_wgs, kGridThreads, 0, stream>>>(
         dist, (int)n, (int)theta, (int)drop_count, (int)users_count, (int)corrupted, ctx->sorted_idx.as<uint16_t>(),
         ctx->rank_t.as<uint16_t>(), ctx->sorted_val.as<float>(), ctx->row_total.as<double>(), ctx->row_top.as<double>(), cls,
-        ctx->xchg.as<unsigned long long>(), band_scale, selection_dev, status_dev, status_dev + 1);
+        ctx->xchg.as<unsigned long long>(), band_scale, rescore_plain, selection_dev, status_dev, status_dev + 1);
     return check_launch("bulyan_grid_kernel");
 }
 
