@@ -3,7 +3,8 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libbyzagg.so')
+# BYZ_LIBRARY: another build of the same ABI (the sanitized one, build_native.py --sanitize)
+LIB_PATH = os.environ.get('BYZ_LIBRARY') or os.path.join(_HERE, 'libbyzagg.so')
 
 OK, E_INVALID, E_PRECONDITION, E_HIP, E_UNSUPPORTED, E_NO_WINNER = 0, -1, -2, -3, -4, -5
 

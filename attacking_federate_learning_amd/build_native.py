@@ -56,11 +56,19 @@ def _headers():
     return [os.path.join(CSRC, 'common.hpp'), os.path.join(CSRC, 'lane_exchange.hpp'), os.path.join(HERE, '..', 'include', 'byzagg.h'), __file__]
 
 
-def _compile(src, force):
-    obj = os.path.join(BUILD, src.replace('.hip', '.o'))
+# The host side under AddressSanitizer + UndefinedBehaviorSanitizer: same sources, kernels untouched
+# (-fno-gpu-sanitize), a second library next to the first.  It needs the sanitizer runtime in the process before it is
+# loaded: scripts/run_sanitized.sh sets LD_PRELOAD and BYZ_LIBRARY.
+SAN_BUILD = os.path.join(HERE, 'csrc', 'build_asan')
+SAN_LIB = os.path.join(HERE, 'libbyzagg_asan.so')
+SAN_FLAGS = ['-g', '-fsanitize=address,undefined', '-fno-gpu-sanitize', '-fno-omit-frame-pointer', '-shared-libsan']
+
+
+def _compile(src, force, sanitize=False):
+    obj = os.path.join(SAN_BUILD if sanitize else BUILD, src.replace('.hip', '.o'))
     path = os.path.join(CSRC, src)
     if force or _stale(obj, [path] + _headers()):
-        cmd = [hipcc()] + COMMON_FLAGS + EXTRA_FLAGS.get(src, []) + ['-c', path, '-o', obj]
+        cmd = [hipcc()] + COMMON_FLAGS + (SAN_FLAGS if sanitize else []) + EXTRA_FLAGS.get(src, []) + ['-c', path, '-o', obj]
         proc = subprocess.run(cmd, capture_output=True, text=True)
         if proc.returncode != 0:
             raise RuntimeError('hipcc failed for %s:\n%s\n%s' % (src, proc.stdout, proc.stderr))
@@ -68,23 +76,32 @@ def _compile(src, force):
     return obj, False
 
 
-def build(force=False, verbose=False):
-    """Compile every HIP source for gfx950 and link libbyzagg.so.  Returns the library path."""
-    os.makedirs(BUILD, exist_ok=True)
+def sanitizer_runtime():
+    """Path of the shared ASan runtime that must be LD_PRELOADed before libbyzagg_asan.so is loaded."""
+    proc = subprocess.run([os.path.join(os.path.dirname(hipcc()), '..', 'lib', 'llvm', 'bin', 'clang'),
+                           '-print-file-name=libclang_rt.asan-x86_64.so'], capture_output=True, text=True)
+    path = proc.stdout.strip()
+    return path if os.path.isabs(path) and os.path.exists(path) else None
+
+
+def build(force=False, verbose=False, sanitize=False):
+    """Compile every HIP source for gfx950 and link libbyzagg.so (sanitize=True: libbyzagg_asan.so).  Returns the path."""
+    out_dir, lib = (SAN_BUILD, SAN_LIB) if sanitize else (BUILD, LIB)
+    os.makedirs(out_dir, exist_ok=True)
     with ThreadPoolExecutor(max_workers=len(SOURCES)) as pool:
-        results = list(pool.map(lambda s: _compile(s, force), SOURCES))
+        results = list(pool.map(lambda s: _compile(s, force, sanitize), SOURCES))
     objs = [o for o, _ in results]
-    if force or any(changed for _, changed in results) or _stale(LIB, objs):
-        cmd = [hipcc(), '--offload-arch=' + ARCH, '-shared', '-fPIC', '-o', LIB] + objs
+    if force or any(changed for _, changed in results) or _stale(lib, objs):
+        cmd = [hipcc(), '--offload-arch=' + ARCH, '-shared', '-fPIC', '-o', lib] + (SAN_FLAGS if sanitize else []) + objs
         proc = subprocess.run(cmd, capture_output=True, text=True)
         if proc.returncode != 0:
             raise RuntimeError('link failed:\n%s\n%s' % (proc.stdout, proc.stderr))
         if verbose:
-            print('linked', LIB)
+            print('linked', lib)
     elif verbose:
-        print('up to date:', LIB)
-    return LIB
+        print('up to date:', lib)
+    return lib
 
 
 if __name__ == '__main__':
-    build(force='--force' in sys.argv, verbose=True)
+    build(force='--force' in sys.argv, verbose=True, sanitize='--sanitize' in sys.argv)

@@ -141,3 +141,47 @@ def test_dropin_shims_resolve():
             assert callable(mod.defend['Krum']) and mod.DefenseTypes.Bulyan == 'Bulyan'
         else:
             assert issubclass(mod.DriftAttack, mod.Attack)
+
+
+def test_host_library_under_address_and_ub_sanitizers(tmp_path):
+    """the C++ host side of libbyzagg built with -fsanitize=address,undefined (kernels untouched).
+    Without a GPU only the entry points that never reach a kernel run -- context creation failing on the missing device,
+    argument checks, the name tables -- but they run under the sanitizers, and the sanitized library must export the
+    whole ABI.  With a GPU the same library runs the parity tests: scripts/run_sanitized.sh."""
+    import subprocess
+    import sys
+    from attacking_federate_learning_amd import build_native
+    runtime = build_native.sanitizer_runtime()
+    if runtime is None:
+        pytest.skip('this ROCm installation has no shared ASan runtime')
+    lib = build_native.build(sanitize=True)
+    snippet = tmp_path / 'calls.py'
+    snippet.write_text(
+        'import ctypes, sys\n'
+        'sys.path.insert(0, %r)\n'
+        'from attacking_federate_learning_amd import _native\n'
+        'lib = _native.load()          # resolves every prototype of include/byzagg.h\n'
+        'assert lib.byz_abi_version() == 1\n'
+        'names = [lib.byz_kernel_name(k) for k in range(-2, 14)]\n'
+        'a, b = ctypes.c_int64(0), ctypes.c_int64(0)\n'
+        'assert lib.byz_limits(ctypes.byref(a), ctypes.byref(b)) == 0 and a.value >= 10000\n'
+        'ctx = ctypes.c_void_p()\n'
+        'rc = lib.byz_ctx_create(0, ctypes.byref(ctx))\n'
+        'if rc == 0:\n'
+        '    assert lib.byz_ctx_reserve(ctx, 100, 1000) == 0\n'
+        '    assert lib.byz_ctx_reserve(ctx, -1, 5) == _native.E_INVALID\n'
+        '    lib.byz_ctx_destroy(ctx)\n'
+        'else:\n'
+        '    assert rc == _native.E_HIP and _native.last_error()\n'
+        'assert lib.byz_ctx_reserve(None, 10, 10) == _native.E_INVALID\n'
+        'rows = ctypes.c_int64(0)\n'
+        'assert lib.byz_bulyan_rescored(None, ctypes.byref(rows)) == _native.E_INVALID\n'
+        'assert lib.byz_timing_reset(None) == _native.E_INVALID\n'
+        'lib.byz_ctx_destroy(None)\n'
+        'print("sanitized calls done")\n' % ROOT)
+    env = dict(os.environ, LD_PRELOAD=runtime, BYZ_LIBRARY=lib,
+               ASAN_OPTIONS='detect_leaks=0:protect_shadow_gap=0', UBSAN_OPTIONS='print_stacktrace=1')
+    proc = subprocess.run([sys.executable, str(snippet)], capture_output=True, text=True, env=env, timeout=300)
+    assert proc.returncode == 0, proc.stderr[-2000:]
+    assert 'sanitized calls done' in proc.stdout
+    assert 'AddressSanitizer' not in proc.stderr and 'runtime error' not in proc.stderr, proc.stderr[-2000:]
