@@ -25,6 +25,8 @@
 
 #include "lane_exchange.hpp"
 
+#include <cstdlib>
+
 namespace byz {
 namespace {
 
@@ -523,6 +525,15 @@ int launch_window_rows(byz_ctx* ctx, const float* G, int64_t n_rows, int64_t n_c
     BYZ_SHAPE(4, 8, 512, 1, 6);     //  <=  512
     BYZ_SHAPE(4, 12, 512, 1, 6);    //  <=  768
     BYZ_SHAPE(4, 16, 512, 1, 6);    //  <= 1024
+    // BYZ_TM_BUCKETS=512 (experiment for the 8-wave shapes): half the histogram, so that the workgroup's LDS is what its
+    // gather stacks need (57 KiB + 14 KiB static) and TWO workgroups fit a CU -- one loads while the other selects; the
+    // price is twice as many values per bucket (more candidates per column, more tiles for the general kernel)
+    const char* buckets_env = std::getenv("BYZ_TM_BUCKETS");
+    if (buckets_env != nullptr && std::atoi(buckets_env) == 512) {
+        BYZ_SHAPE(8, 12, 512, 2, 6);
+        BYZ_SHAPE(8, 17, 512, 2, 6);
+        BYZ_SHAPE(8, 20, 512, 2, 6);
+    }
     BYZ_SHAPE(8, 12, 1024, 2, 6);   //  <= 1536
     BYZ_SHAPE(8, 17, 1024, 2, 6);   //  <= 2176
     BYZ_SHAPE(8, 20, 1024, 2, 6);   //  <= 2560

@@ -1,0 +1,58 @@
+"""First GPU visit of the next round (torch-free, ~40 s): the opt-in variants written without a GPU at the end of round 2.
+
+  1. BYZ_BULYAN_RESCORE=plain (literal fp32 chain, four batches of table entries in flight) against the default:
+     selections must be identical; time at N = 4000 and 10,000.
+  2. BYZ_TM_BUCKETS=512 (two workgroups per CU for the 8-wave row-split trimmed mean) against the default at 2080 rows:
+     results must agree to 1e-6; time and tiles handed to the general kernel.
+  3. scripts/small_krum_check.py's timing of the N <= 128 Krum path (unchanged code: a baseline for the tail merge).
+"""
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, 'tests'))
+from attacking_federate_learning_amd.engine import Engine, Distances   # noqa: E402
+from test_gpu_scale import point_distances                             # noqa: E402
+
+
+def main():
+    eng = Engine(0)
+    for n in (4000, 10000):
+        f = int(n * 0.24)
+        dev = Distances(eng.to_device(point_distances(4100 + n, n)), n)
+        got = {}
+        for mode in ('v1', 'plain'):
+            os.environ['BYZ_BULYAN_RESCORE'] = mode
+            eng.bulyan_select(dev, n, f)
+            t0 = time.perf_counter()
+            got[mode] = eng.bulyan_select(dev, n, f).tolist()
+            print('bulyan N=%d %s: %.1f ms, re-scored %d' % (n, mode, 1e3 * (time.perf_counter() - t0), eng.bulyan_rescored()), flush=True)
+        print('  selections', 'identical' if got['v1'] == got['plain'] else 'DIFFERENT', flush=True)
+    os.environ.pop('BYZ_BULYAN_RESCORE', None)
+
+    rows, cols, corrupted = 2080, 1 << 18, 1920
+    rng = np.random.default_rng(5)
+    g = rng.standard_normal((rows, cols), dtype=np.float32)
+    buf = eng.to_device(g)
+    out = {}
+    for mode in ('1024', '512'):
+        os.environ['BYZ_TM_BUCKETS'] = mode
+        o = eng.trimmed_mean(buf, rows, corrupted)
+        eng.synchronize()
+        t0 = time.perf_counter()
+        outs = [eng.trimmed_mean(buf, rows, corrupted) for _ in range(20)]
+        eng.synchronize()
+        dt = (time.perf_counter() - t0) / 20
+        out[mode] = o.numpy()
+        print('trimmed mean %d x %d buckets %s: %.3f ms (%.2f TB/s), tiles redone %d' % (
+            rows, cols, mode, dt * 1e3, 4.0 * rows * cols / dt / 1e12, eng.trimmed_mean_redone()), flush=True)
+        del outs
+    print('  max |difference| between the two: %.3e' % np.abs(out['1024'] - out['512']).max(), flush=True)
+
+
+if __name__ == '__main__':
+    main()
