@@ -261,5 +261,8 @@ int launch_small_distances(byz_ctx* ctx, const float* G, int64_t n_rows, int64_t
                            hipStream_t stream);
 int launch_small_select(byz_ctx* ctx, const float* dist, int64_t n_rows, int64_t prefix_len, const float* G, int64_t n_cols,
                         int64_t ld, int32_t* winner_dev, float* out_row, hipStream_t stream);
+bool krum_small_tail_enabled();
+int launch_small_krum_merged(byz_ctx* ctx, const float* G, int64_t n_rows, int64_t n_cols, int64_t ld, float* dist,
+                             int64_t prefix_len, int32_t* winner_dev, float* out_row, hipStream_t stream);
 
 }  // namespace byz

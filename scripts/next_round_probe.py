@@ -4,7 +4,7 @@
      selections must be identical; time at N = 4000 and 10,000.
   2. BYZ_TM_BUCKETS=512 (two workgroups per CU for the 8-wave row-split trimmed mean) against the default at 2080 rows:
      results must agree to 1e-6; time and tiles handed to the general kernel.
-  3. scripts/small_krum_check.py's timing of the N <= 128 Krum path (unchanged code: a baseline for the tail merge).
+  3. run scripts/small_krum_check.py next: it now also covers BYZ_KRUM_SMALL_TAIL=1 (K3..K5 in one launch), cases and timings.
 """
 import os
 import sys

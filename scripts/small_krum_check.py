@@ -58,13 +58,17 @@ def dist64(g):
     return out
 
 
+MODES = ('0', '1', '1t')   # general path, csrc/krum_small.hip, the same with K3..K5 merged (BYZ_KRUM_SMALL_TAIL=1)
+
+
 def one_case(eng, n, d, f, family, seed):
     g = make(n, d, seed, family)
     buf = eng.to_device(g)
     want = dist64(g)
     res = {}
-    for mode in ('0', '1'):
-        os.environ['BYZ_KRUM_SMALL'] = mode
+    for mode in MODES:
+        os.environ['BYZ_KRUM_SMALL'] = mode[0]
+        os.environ['BYZ_KRUM_SMALL_TAIL'] = '1' if mode.endswith('t') else '0'
         t0 = time.time()
         dm = eng.pairwise_distances(buf).numpy()
         idx = eng.krum(buf, n, f, return_index=True)
@@ -72,7 +76,7 @@ def one_case(eng, n, d, f, family, seed):
         eng.check()
         res[mode] = (dm, idx, row, time.time() - t0)
     ok = True
-    for mode in ('0', '1'):
+    for mode in MODES:
         dm, idx, row, _ = res[mode]
         off = ~np.eye(n, dtype=bool)
         with np.errstate(invalid='ignore', divide='ignore'):
@@ -87,7 +91,7 @@ def one_case(eng, n, d, f, family, seed):
         ok = ok and good
         say('  mode', mode, 'max rel err %.2e' % rel.max(), 'diag', diag_ok, 'sym', sym, 'idx', idx, 'ref idx on own dist', ref_idx,
             'row', row_ok, 'OK' if good else 'FAIL')
-    same_idx = res['0'][1] == res['1'][1]
+    same_idx = len({res[m][1] for m in MODES}) == 1
     dmax = np.nanmax(np.abs(np.where(np.isinf(res['0'][0]), 0, res['0'][0]) - np.where(np.isinf(res['1'][0]), 0, res['1'][0])))
     say('  paths agree on the index:', same_idx, ' max |d0 - d1| = %.3e' % dmax)
     if family in ('attack', 'near'):
@@ -100,11 +104,9 @@ def one_case(eng, n, d, f, family, seed):
 def timing(eng, n, d, f, rounds=200):
     g = make(n, d, 77, 'scaled')
     buf = eng.to_device(g)
-    for mode in ('0', '1', '1u0'):
+    for mode in ('0', '1', '1t'):
         os.environ['BYZ_KRUM_SMALL'] = mode[0]
-        os.environ.pop('BYZ_KRUM_SMALL_UNROLL', None)
-        if 'u' in mode:
-            os.environ['BYZ_KRUM_SMALL_UNROLL'] = mode.split('u')[1]
+        os.environ['BYZ_KRUM_SMALL_TAIL'] = '1' if mode.endswith('t') else '0'
         for _ in range(20):
             eng.krum(buf, n, f)
         eng.synchronize()
