@@ -26,7 +26,7 @@ EXTRA_FLAGS = {'trimmed_mean.hip': ['-fno-honor-nans'],
                # median_window.hip keeps its tile in registers: every loop over the register array must be
                # fully unrolled (a dynamic index would demote the array to scratch), and the staging loop of
                # the larger instantiations exceeds LLVM's default budget for `#pragma unroll`.  NaN semantics
-               # stay on in this file: the padding rows are NaNs.
+               # stay on in this file (the padding rows are +inf; a NaN anywhere in a column makes its result NaN).
                'median_window.hip': ['-mllvm', '-pragma-unroll-threshold=1000000'],
                'gram.hip': ['-mllvm', '-pragma-unroll-threshold=1000000'],
                'gram_planes.hip': ['-mllvm', '-pragma-unroll-threshold=1000000'],

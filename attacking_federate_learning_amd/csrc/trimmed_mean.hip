@@ -168,11 +168,15 @@ __global__ __launch_bounds__(1024) void trimmed_mean_lds_kernel(const float* __r
                                                                 const int32_t* __restrict__ row_index, int keep,
                                                                 float* __restrict__ out) {
     extern __shared__ __attribute__((aligned(16))) f32x4 quad[];  // n_pad entries
+    __shared__ int nan_columns;   // bit e: column c + e holds a NaN (np.median makes the whole result NaN then)
     const int tid = threadIdx.x, nt = blockDim.x;
     const int64_t n_quads = (n_cols + 3) / 4;
     const float pinf = __builtin_inff();
     for (int64_t qd = blockIdx.x; qd < n_quads; qd += gridDim.x) {
         const int64_t c = qd * 4;
+        if (tid == 0) nan_columns = 0;
+        __syncthreads();
+        int seen_nan = 0;
         for (int r = tid; r < n_pad; r += nt) {
             f32x4 v = {pinf, pinf, pinf, pinf};
             if (r < n_rows) {
@@ -186,9 +190,14 @@ __global__ __launch_bounds__(1024) void trimmed_mean_lds_kernel(const float* __r
                     v.z = c + 2 < n_cols ? p[2] : 0.0f;
                     v.w = 0.0f;
                 }
+                // this file is compiled with -fno-honor-nans (the sorting network's min / max): test the bits, not x != x
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    seen_nan |= (__float_as_uint(v[e]) & 0x7fffffffu) > 0x7f800000u ? (1 << e) : 0;
             }
             quad[r] = v;
         }
+        if (seen_nan != 0) atomicOr(&nan_columns, seen_nan);
         __syncthreads();
         for (int k = 2; k <= n_pad; k <<= 1) {
             for (int j = k >> 1; j > 0; j >>= 1) {
@@ -213,6 +222,9 @@ __global__ __launch_bounds__(1024) void trimmed_mean_lds_kernel(const float* __r
             const QuadArray sorted{quad};
             const WindowArgs args{G, ld, row_index, n_rows, keep, c, n_cols};
             window_mean(sorted, args, tid, out);
+            // a NaN anywhere in the column: the reference's np.median is NaN and so is everything after it; the sorted
+            // order above is unspecified for such a column, the result is not
+            if (tid < 4 && ((nan_columns >> tid) & 1) && c + tid < n_cols) out[c + tid] = __uint_as_float(0x7fc00000u);
         }
         __syncthreads();
     }

@@ -387,6 +387,19 @@ def test_trimmed_mean_general_kernel(eng, n, d):
     assert close(eng.trimmed_mean(g, n, c), ideal.trimmed_mean(g, c))
 
 
+def test_trimmed_mean_lds_kernel_returns_nan_for_a_column_with_nan(eng):
+    """Above 5632 rows the LDS bitonic kernel takes over; a NaN anywhere in a column makes np.median -- and with it the
+    reference's result -- NaN there, as it does below 5632 rows, and leaves the other columns alone."""
+    n, d, c = 6000, 10, 100
+    g = gaussian(61, n, d)
+    g[17, 3] = np.nan
+    g[5999, 9] = np.nan
+    got = np.asarray(eng.trimmed_mean(g, n, c))
+    assert np.isnan(got[3]) and np.isnan(got[9])
+    clean = [0, 1, 2, 4, 5, 6, 7, 8]
+    assert close(got[clean], ideal.trimmed_mean(g[:, clean], c))
+
+
 @pytest.mark.parametrize('n,m', [(300, 72), (1000, 240), (130, 129)])
 def test_trimmed_mean_with_many_identical_rows(eng, n, m):
     """More than 64 clients submit the same vector (the attack's normal case): a bucket then holds more equal values
