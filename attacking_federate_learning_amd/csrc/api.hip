@@ -231,6 +231,7 @@ int byz_ctx_reserve(byz_ctx* ctx, int64_t n_rows, int64_t n_cols) {
     BYZ_TRY(ctx->row_top.ensure(static_cast<size_t>(n_rows) * sizeof(double)));
     BYZ_TRY(ctx->stage_out.ensure(static_cast<size_t>(n_cols) * 3 * sizeof(float)));
     BYZ_TRY(ctx->pinned.ensure(static_cast<size_t>(n_rows) * sizeof(int32_t) + 64));
+    if (krum_small_applies(n_rows, n_cols)) BYZ_TRY(reserve_small_workspaces(ctx));
     {   // the Gram's schedule words and the duplicate-row table
         const int64_t T = ceil_div(n_rows, 128);
         BYZ_TRY(ctx->gram_tickets.ensure(static_cast<size_t>(T * (T + 1) / 2 + 8) * sizeof(int32_t)));

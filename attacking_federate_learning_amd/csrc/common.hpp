@@ -257,6 +257,7 @@ int launch_lane_selftest(byz_ctx* ctx, int32_t* out, int32_t* n_patterns, hipStr
 
 // krum_small.hip: the whole of Krum for N <= 128 in five launches
 bool krum_small_applies(int64_t n_rows, int64_t n_cols);
+int reserve_small_workspaces(byz_ctx* ctx);
 int launch_small_distances(byz_ctx* ctx, const float* G, int64_t n_rows, int64_t n_cols, int64_t ld, float* dist,
                            hipStream_t stream);
 int launch_small_select(byz_ctx* ctx, const float* dist, int64_t n_rows, int64_t prefix_len, const float* G, int64_t n_cols,

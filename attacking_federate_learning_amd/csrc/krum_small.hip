@@ -931,6 +931,22 @@ bool krum_small_applies(int64_t n_rows, int64_t n_cols) {
     return krum_small_enabled() && n_rows >= 2 && n_rows <= kMaxRows && n_cols <= (static_cast<int64_t>(1) << 20);
 }
 
+// byz_ctx_reserve's share: everything the N <= 128 path allocates, so that its first call allocates nothing
+int reserve_small_workspaces(byz_ctx* ctx) {
+    const size_t slab_floats = static_cast<size_t>(ctx->num_cus) * kMaxBlocks * kBlockEntries;
+    BYZ_TRY(ctx->gram_partials.ensure((slab_floats + static_cast<size_t>(ctx->num_cus) * kMaxRows) * sizeof(float)));
+    BYZ_TRY(ctx->gram.ensure(static_cast<size_t>(kMaxBlocks) * kBlockEntries * sizeof(double)));
+    BYZ_TRY(ctx->gram_rep.ensure(static_cast<size_t>(kMaxRows) * sizeof(int32_t)));
+    BYZ_TRY(ctx->near_pairs.ensure(static_cast<size_t>(kMaxRows * (kMaxRows - 1) / 2) * sizeof(int2)));
+    BYZ_TRY(ctx->near_partial.ensure((static_cast<size_t>(1) << 20) * sizeof(double)));
+    BYZ_TRY(ctx->scores.ensure(static_cast<size_t>(kMaxRows) * sizeof(float)));
+    if (ctx->small_sync.ptr == nullptr) {
+        BYZ_TRY(ctx->small_sync.ensure(64));
+        BYZ_HIP(hipMemset(ctx->small_sync.ptr, 0, 64));
+    }
+    return BYZ_OK;
+}
+
 // dist (n x n fp32, pitch n) of the n_rows x n_cols matrix G: K1..K3
 static int small_distances(byz_ctx* ctx, const float* G, int64_t n_rows, int64_t n_cols, int64_t ld, float* dist,
                            hipStream_t stream, const TailArgs* tail) {
