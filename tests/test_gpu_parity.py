@@ -313,6 +313,7 @@ def test_small_krum_path_next_to_the_general_path(eng, monkeypatch, n, d, f, fam
 def test_small_krum_path_covers_selection_and_bulyan(eng, monkeypatch, golden):
     """The entry points that share the N <= 128 kernels: krum_select on a given matrix (scores as the reference's sum()
     forms them), Bulyan end to end, and the golden Krum cases through the GENERAL path too (it stays reachable)."""
+    eng.reserve(100, 79510)     # byz_ctx_reserve also pre-sizes the small path's workspaces
     rng = np.random.default_rng(77)
     for n, f in ((2, 0), (3, 1), (17, 4), (100, 24), (128, 31)):
         pts = rng.standard_normal((n, 9)).astype(np.float32)
