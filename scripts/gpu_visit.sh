@@ -1,7 +1,7 @@
 #!/bin/bash
-# r02c: whole GPU suite (no -x: every failure listed), smoke, contract bench, kernel trace of the same command
+# One full GPU visit: whole GPU suite (no -x: every failure listed), smoke, contract bench, kernel trace of the same command
 set -u
-TAG=${1:-r02c}
+TAG=${1:-visit}
 OUT=gpurun_out/$TAG; mkdir -p $OUT
 export TMPDIR=/tmp
 timeout 900 python -m pytest tests -m gpu -q --timeout 200 --durations=15 2>&1 | tail -80 > $OUT/pytest_gpu.txt
