@@ -85,8 +85,9 @@ struct ColumnPlan {   // what sweep 3 needs to know about a column (written by i
 };
 
 // W waves, RPW 16-row blocks per wave (rows <= 16 W RPW), B buckets, SR sort registers per lane (64 SR candidates),
-// LS stack slots per lane and column.
-template <int W, int RPW, int B, int SR, int LS>
+// LS stack slots per lane and column.  H16: 16-bit histogram counters (rows < 65536), two per LDS word -- the 8-wave shapes'
+// LDS then is what their gather stacks need, and TWO workgroups fit a CU (experimental: BYZ_TM_HIST16=1).
+template <int W, int RPW, int B, int SR, int LS, bool H16>
 __global__ __launch_bounds__(64 * W, (W == 4 ? 3 : 4)) void window_rows_kernel(const float* __restrict__ G, int n_rows, int64_t n_cols,
                                                              int64_t ld, const int32_t* __restrict__ row_index, int keep,
                                                              float* __restrict__ out, int32_t* __restrict__ redo) {
@@ -94,9 +95,17 @@ __global__ __launch_bounds__(64 * W, (W == 4 ? 3 : 4)) void window_rows_kernel(c
     constexpr int NCW = kTileCols / W;          // columns an owner wave resolves: 4, 2 or 1
     constexpr int BPL = B / 64;                 // buckets per lane in the owners' scans
     constexpr int CAP = 64 * SR;
-    constexpr int kColWords = B + B / 8;          // a column's histogram, skewed: bucket b sits at word b + b / 8
-    constexpr int kHistWords = kColWords * kTileCols;
+    constexpr int kColWords = B + B / 8;          // a column's histogram, skewed: bucket b sits at slot b + b / 8
+    constexpr int kHistWords = H16 ? kColWords * kTileCols / 2 : kColWords * kTileCols;   // 32-bit words
     extern __shared__ __attribute__((aligned(16))) uint32_t un[];       // max(B x 16, 4 (LS + 1) T) words: the histogram, then the gather stacks
+    auto hist_get = [&](int slot) __attribute__((always_inline)) -> int {
+        if constexpr (H16) return static_cast<int>(reinterpret_cast<const uint16_t*>(un)[slot]);
+        else return static_cast<int>(un[slot]);
+    };
+    auto hist_set = [&](int slot, int v) __attribute__((always_inline)) {
+        if constexpr (H16) reinterpret_cast<uint16_t*>(un)[slot] = static_cast<uint16_t>(v);
+        else un[slot] = static_cast<uint32_t>(v);
+    };
     __shared__ float dense[kTileCols * CAP];
     __shared__ uint32_t tops[T];
     __shared__ uint32_t minmax[2 * kTileCols];
@@ -222,7 +231,9 @@ __global__ __launch_bounds__(64 * W, (W == 4 ? 3 : 4)) void window_rows_kernel(c
                     const int b = static_cast<int>(__builtin_fminf(__builtin_fmaf(x[j][e], inv[e], nlo[e]), static_cast<float>(B) - 0.5f));
                     {
                         const int bb = max(b, 0);
-                        atomicAdd(&un[(4 * q + e) * kColWords + bb + (bb >> 3)], 1u);
+                        const int slot = (4 * q + e) * kColWords + bb + (bb >> 3);
+                        if constexpr (H16) atomicAdd(&un[slot >> 1], 1u << (16 * (slot & 1)));
+                        else atomicAdd(&un[slot], 1u);
                     }
                 }
             }
@@ -250,7 +261,7 @@ __global__ __launch_bounds__(64 * W, (W == 4 ? 3 : 4)) void window_rows_kernel(c
             // sum is <= r
             int run = 0;
 #pragma unroll
-            for (int i = 0; i < BPL; ++i) run += static_cast<int>(un[c * kColWords + hslot(lane * BPL + i)]);
+            for (int i = 0; i < BPL; ++i) run += hist_get(c * kColWords + hslot(lane * BPL + i));
             int scan = run;
 #pragma unroll
             for (int d = 1; d < 64; d <<= 1) {
@@ -261,8 +272,8 @@ __global__ __launch_bounds__(64 * W, (W == 4 ? 3 : 4)) void window_rows_kernel(c
             int below1 = 0, below2 = 0;
 #pragma unroll
             for (int i = 0; i < BPL; ++i) {
-                const int h = static_cast<int>(un[c * kColWords + hslot(lane * BPL + i)]);
-                un[c * kColWords + hslot(lane * BPL + i)] = static_cast<uint32_t>(acc);
+                const int h = hist_get(c * kColWords + hslot(lane * BPL + i));
+                hist_set(c * kColWords + hslot(lane * BPL + i), acc);
                 acc += h;
                 below1 += acc <= r1 ? 1 : 0;
                 below2 += acc <= r2 ? 1 : 0;
@@ -273,7 +284,7 @@ __global__ __launch_bounds__(64 * W, (W == 4 ? 3 : 4)) void window_rows_kernel(c
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             auto cum = [&](int b) {   // values in buckets < b
-                return b <= 0 ? 0 : (b >= B ? n_rows : static_cast<int>(un[c * kColWords + hslot(b)]));
+                return b <= 0 ? 0 : (b >= B ? n_rows : hist_get(c * kColWords + hslot(b)));
             };
             // j* = number of rings j with N(j) < keep (N is monotone); lane l tries j = l, l + 64, ...
             int fewer = 0;
@@ -499,15 +510,15 @@ __global__ __launch_bounds__(64 * W, (W == 4 ? 3 : 4)) void window_rows_kernel(c
 
 int64_t window_rows_max_rows() { return 16 * 16 * 21; }
 
-template <int W, int RPW, int B, int SR, int LS>
+template <int W, int RPW, int B, int SR, int LS, bool H16 = false>
 static int launch_shape(const float* G, int64_t n_rows, int64_t n_cols, int64_t ld, const int32_t* row_index, int64_t keep,
                         float* out, int32_t* redo, hipStream_t stream) {
     const int64_t n_tiles = ceil_div(n_cols, static_cast<int64_t>(kTileCols));
-    constexpr int kHist = (B + B / 8) * kTileCols, kStack = 4 * (LS + 1) * 64 * W;
+    constexpr int kHist = (B + B / 8) * kTileCols / (H16 ? 2 : 1), kStack = 4 * (LS + 1) * 64 * W;
     constexpr size_t lds = static_cast<size_t>(kHist > kStack ? kHist : kStack) * sizeof(uint32_t);
-    BYZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&window_rows_kernel<W, RPW, B, SR, LS>),
+    BYZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&window_rows_kernel<W, RPW, B, SR, LS, H16>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
-    window_rows_kernel<W, RPW, B, SR, LS><<<static_cast<unsigned>(n_tiles), 64 * W, lds, stream>>>(
+    window_rows_kernel<W, RPW, B, SR, LS, H16><<<static_cast<unsigned>(n_tiles), 64 * W, lds, stream>>>(
         G, static_cast<int>(n_rows), n_cols, ld, row_index, static_cast<int>(keep), out, redo);
     return check_launch("window_rows_kernel");
 }
@@ -525,14 +536,15 @@ int launch_window_rows(byz_ctx* ctx, const float* G, int64_t n_rows, int64_t n_c
     BYZ_SHAPE(4, 8, 512, 1, 6);     //  <=  512
     BYZ_SHAPE(4, 12, 512, 1, 6);    //  <=  768
     BYZ_SHAPE(4, 16, 512, 1, 6);    //  <= 1024
-    // BYZ_TM_BUCKETS=512 (experiment for the 8-wave shapes): half the histogram, so that the workgroup's LDS is what its
-    // gather stacks need (57 KiB + 14 KiB static) and TWO workgroups fit a CU -- one loads while the other selects; the
-    // price is twice as many values per bucket (more candidates per column, more tiles for the general kernel)
-    const char* buckets_env = std::getenv("BYZ_TM_BUCKETS");
-    if (buckets_env != nullptr && std::atoi(buckets_env) == 512) {
-        BYZ_SHAPE(8, 12, 512, 2, 6);
-        BYZ_SHAPE(8, 17, 512, 2, 6);
-        BYZ_SHAPE(8, 20, 512, 2, 6);
+    // BYZ_TM_HIST16=1 (experiment for the 8-wave shapes, unmeasured): 16-bit histogram counters, so that the workgroup's LDS
+    // is what its gather stacks need (57 KiB + 14 KiB static instead of 74 + 14) and TWO workgroups fit a CU -- one loads
+    // while the other selects.  (Halving the bucket count instead does not work: scripts/proto/ring_window.py puts 6% of
+    // the columns of a 2080-row, keep-159 tile over the 128-candidate sort with 512 buckets, i.e. most tiles.)
+    const char* hist16_env = std::getenv("BYZ_TM_HIST16");
+    if (hist16_env != nullptr && std::atoi(hist16_env) != 0) {
+        if (blocks <= 8 * 12) return launch_shape<8, 12, 1024, 2, 6, true>(G, n_rows, n_cols, ld, row_index, keep, out, redo, stream);
+        if (blocks <= 8 * 17) return launch_shape<8, 17, 1024, 2, 6, true>(G, n_rows, n_cols, ld, row_index, keep, out, redo, stream);
+        if (blocks <= 8 * 20) return launch_shape<8, 20, 1024, 2, 6, true>(G, n_rows, n_cols, ld, row_index, keep, out, redo, stream);
     }
     BYZ_SHAPE(8, 12, 1024, 2, 6);   //  <= 1536
     BYZ_SHAPE(8, 17, 1024, 2, 6);   //  <= 2176

@@ -2,7 +2,8 @@
 
   1. BYZ_BULYAN_RESCORE=plain (literal fp32 chain, four batches of table entries in flight) against the default:
      selections must be identical; time at N = 4000 and 10,000.
-  2. BYZ_TM_BUCKETS=512 (two workgroups per CU for the 8-wave row-split trimmed mean) against the default at 2080 rows:
+  2. BYZ_TM_HIST16=1 (16-bit histogram counters: two workgroups per CU for the 8-wave row-split trimmed mean) against the
+     default at 2080 rows:
      results must agree to 1e-6; time and tiles handed to the general kernel.
   3. run scripts/small_krum_check.py next: it now also covers BYZ_KRUM_SMALL_TAIL=1 (K3..K5 in one launch), cases and timings.
 """
@@ -39,8 +40,8 @@ def main():
     g = rng.standard_normal((rows, cols), dtype=np.float32)
     buf = eng.to_device(g)
     out = {}
-    for mode in ('1024', '512'):
-        os.environ['BYZ_TM_BUCKETS'] = mode
+    for mode in ('0', '1'):
+        os.environ['BYZ_TM_HIST16'] = mode
         o = eng.trimmed_mean(buf, rows, corrupted)
         eng.synchronize()
         t0 = time.perf_counter()
@@ -48,10 +49,10 @@ def main():
         eng.synchronize()
         dt = (time.perf_counter() - t0) / 20
         out[mode] = o.numpy()
-        print('trimmed mean %d x %d buckets %s: %.3f ms (%.2f TB/s), tiles redone %d' % (
+        print('trimmed mean %d x %d hist16=%s: %.3f ms (%.2f TB/s), tiles redone %d' % (
             rows, cols, mode, dt * 1e3, 4.0 * rows * cols / dt / 1e12, eng.trimmed_mean_redone()), flush=True)
         del outs
-    print('  max |difference| between the two: %.3e' % np.abs(out['1024'] - out['512']).max(), flush=True)
+    print('  max |difference| between the two: %.3e' % np.abs(out['0'] - out['1']).max(), flush=True)
 
 
 if __name__ == '__main__':
