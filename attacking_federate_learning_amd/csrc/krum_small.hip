@@ -6,23 +6,27 @@
 // in-kernel grid barrier 4-7 us (MI355X_MICROARCH.md, price list), so the phases below are separate launches wherever
 // EVERY workgroup needs EVERY other workgroup's output, and one launch wherever one workgroup can carry on alone:
 //
-//   K1 small_gram_kernel     all N rows x a 128-column slice per step: global fp32 -> registers -> (row, slice) power-of-two
-//                            scale -> two fp16 planes in LDS (row-major, 272-byte pitch: conflict-free ds_write_b64 and
-//                            ds_read_b128) -> v_mfma_f32_32x32x16_f16, three per 32 x 32 block and 16 columns
-//                            (m h' + h m' + h h': gram_planes.hip's f16x2 arithmetic, 6e-8 against fp64), lower-triangle
-//                            blocks only, spread over the 8 waves so that no SIMD carries more than 3; the next two slices'
-//                            loads are in flight meanwhile.  One fp32 slab (<= 10 blocks x 4 KiB) per workgroup.
-//   K2 small_reduce_kernel   slabs -> fp64 Gram blocks, 64 entries per workgroup, fixed summation order.
-//   K3 small_distance_kernel ONE workgroup: d_ij = sqrt(max(0, c_ii + c_jj - 2 c_ij)) in fp64, identical rows folded and
-//                            near-duplicate pairs listed exactly as gram.hip does (d^2 < (c_ii + c_jj) / 16); helper workgroups of
-//                            the same launch re-evaluate the listed pairs on the difference itself (defences.py:20) when
-//                            there are any, and leave at once when there are none; identical rows end up with bitwise
-//                            identical distance rows (the exact ties the reference resolves by visit order).
+//   K1 small_gram_kernel     all N rows x a 128-column slice per step, one row of the slice per thread: global fp32 ->
+//                            registers -> (row, slice) power-of-two scale -> two fp16 planes in LDS (row-major, 272-byte
+//                            pitch: conflict-free ds_write_b64 and ds_read_b128) -> v_mfma_f32_32x32x16_f16, three per
+//                            32 x 32 block and 16 columns (m h' + h m' + h h': gram_planes.hip's f16x2 arithmetic, 6e-8
+//                            against fp64), lower-triangle blocks only, spread over the 8 waves so that no SIMD carries
+//                            more than 3; the next two slices' loads are in flight meanwhile.  One fp32 slab (<= 10 blocks
+//                            x 4 KiB) and one compact diagonal per workgroup.
+//   K2 small_reduce_kernel   slabs -> fp64 Gram blocks, 64 entries per workgroup, fixed summation order; c_ii and c_jj by the
+//                            same sums out of the compact diagonals, so d_ij = sqrt(max(0, c_ii + c_jj - 2 c_ij)) is formed
+//                            here, on 160 CUs; two counters record pairs the identity cannot resolve and exact zeros.
+//   K3 small_distance_kernel leaves at once while both counters are zero.  Otherwise ONE workgroup redoes the distances with
+//                            identical rows folded and near-duplicate pairs listed exactly as gram.hip does (d^2 <
+//                            (c_ii + c_jj) / 16), helper workgroups of the same launch re-evaluate the listed pairs on the
+//                            difference itself (defences.py:20), and identical rows end up with bitwise identical distance
+//                            rows (the exact ties the reference resolves by visit order).
 //   K4 small_score_kernel    one wave per row: in-register bitonic sort of the row's distances (values only: equal
 //                            values add up the same in any order), then the SEQUENTIAL fp32 sum of the first n - f of
 //                            them, exactly as Python's sum() forms it (defences.py:33-34).
 //   K5 small_pick_kernel     every workgroup finds the winner itself (visit order 1, 0, 2, ..., strict '<' against 1e20,
 //                            defences.py:27-37) and copies its share of the winning row.
+//   (small_tail_kernel       K3 + K4 + K5 in one launch: BYZ_KRUM_SMALL_TAIL=1, unmeasured.)
 //
 // Algorithmic traffic: 4 N D bytes read once (K1); everything else is O(N^2).  Bound: HBM (N / 4 flop per byte is below
 // the machine balance of the 16-bit matrix pipe for every N <= 128).
