@@ -136,6 +136,7 @@ struct byz_ctx {
     byz::Buffer small;           // misc device scalars (winner index, status words)
     byz::Buffer small_sync;      // krum_small.hip: flag / pair count / arrivals of the distance kernel's helpers
     int32_t small_epoch = 0;     // krum_small.hip: value the flag takes in the current launch
+    bool small_configured = false;   // krum_small.hip: dynamic-LDS attributes set for this context's device
     byz::Buffer stage_in;        // device copy of a host matrix
     byz::Buffer stage_out;       // device result before download
     byz::PinnedBuffer pinned;    // host bounce buffer for small results

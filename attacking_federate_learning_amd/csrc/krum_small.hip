@@ -979,8 +979,7 @@ static int small_distances(byz_ctx* ctx, const float* G, int64_t n_rows, int64_t
     float* slabs = ctx->gram_partials.as<float>();
     float* diag_slabs = slabs + slab_floats;
     int32_t* flags = ctx->small_sync.as<int32_t>() + 4;
-    static bool configured = false;
-    if (!configured) {
+    if (!ctx->small_configured) {   // per context: the attribute belongs to the (function, device) pair
 #define BYZ_ATTR(T, P)                                                                            \
     BYZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&small_gram_kernel<T, P>),          \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, kGramLds))
@@ -999,7 +998,7 @@ static int small_distances(byz_ctx* ctx, const float* G, int64_t n_rows, int64_t
                                     hipFuncAttributeMaxDynamicSharedMemorySize, kK3Lds));
         BYZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&small_tail_kernel),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, kK3Lds));
-        configured = true;
+        ctx->small_configured = true;
     }
     {
         KernelTimer t(ctx, BYZ_K_GRAM, stream);
