@@ -931,8 +931,13 @@ int env_int(const char* name, int fallback) {
 bool krum_small_enabled() { return env_int("BYZ_KRUM_SMALL", 1) != 0; }
 
 bool krum_small_applies(int64_t n_rows, int64_t n_cols) {
-    // fp32 running sums over at most ~32 slices per workgroup keep the Gram at 1e-7; longer rows take the general path
-    return krum_small_enabled() && n_rows >= 2 && n_rows <= kMaxRows && n_cols <= (static_cast<int64_t>(1) << 20);
+    // Up to 2^18 columns every workgroup's slices are unrolled (the forms the GPU parity tests run, and every model of the
+    // reference: D <= 117,706).  The loop form behind them keeps fp32 running sums over at most ~32 slices per workgroup
+    // (1e-7 on the Gram) up to 2^20 columns; it has been timed but not yet parity-tested in its current shape, so rows that
+    // long take the general path unless BYZ_KRUM_SMALL_MAX_COLS raises the limit.
+    int64_t max_cols = env_int("BYZ_KRUM_SMALL_MAX_COLS", 1 << 18);
+    if (max_cols > (static_cast<int64_t>(1) << 20)) max_cols = static_cast<int64_t>(1) << 20;
+    return krum_small_enabled() && n_rows >= 2 && n_rows <= kMaxRows && n_cols <= max_cols;
 }
 
 // byz_ctx_reserve's share: everything the N <= 128 path allocates, so that its first call allocates nothing

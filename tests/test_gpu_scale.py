@@ -436,3 +436,20 @@ def test_near_duplicate_rows_agree_to_rounding_with_and_without_the_identical_ro
     assert abs(with_shortcut[near, group[0]] - true_d) < 1e-5 and abs(without[near, group[0]] - true_d) < 1e-5
     assert np.allclose(with_shortcut[off], without[off], rtol=1e-5, atol=1e-6)
 
+
+def test_small_krum_loop_form_for_long_rows(eng, monkeypatch):
+    """N <= 128 with more than 2^18 columns runs the general path by default; with the limit raised, K1's LOOP form (more
+    than eight slices per workgroup) must give the same distances and the same index."""
+    n, d, f = 100, 300001, 24
+    g = scaled(4321, n, d)
+    base_d = eng.pairwise_distances(g).numpy()
+    base_i = eng.krum(g, n, f, return_index=True)
+    monkeypatch.setenv('BYZ_KRUM_SMALL_MAX_COLS', str(1 << 20))
+    loop_d = eng.pairwise_distances(g).numpy()
+    loop_i = eng.krum(g, n, f, return_index=True)
+    eng.check()
+    off = ~np.eye(n, dtype=bool)
+    assert np.all(np.isinf(np.diag(loop_d))) and np.array_equal(loop_d, loop_d.T)
+    assert np.allclose(loop_d[off], base_d[off], rtol=1e-6, atol=0.0)
+    assert loop_i == base_i == faithful.krum_pick(loop_d, faithful.visit_order(n), n, f)
+
