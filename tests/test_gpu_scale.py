@@ -453,3 +453,21 @@ def test_small_krum_loop_form_for_long_rows(eng, monkeypatch):
     assert np.allclose(loop_d[off], base_d[off], rtol=1e-6, atol=0.0)
     assert loop_i == base_i == faithful.krum_pick(loop_d, faithful.visit_order(n), n, f)
 
+
+@pytest.mark.parametrize('d', [117706, 200000, 262144])
+def test_small_krum_with_four_to_eight_slices_per_workgroup(eng, monkeypatch, d):
+    """D = 117,706 is the reference's Cifar10Net (data_sets.py:33-52): four 128-column slices per workgroup; 200,000 and
+    2^18 take seven and eight.  Same distances and index as the general path."""
+    n, f = 100, 24
+    g = scaled(5000 + d % 1000, n, d)
+    small_d = eng.pairwise_distances(g).numpy()
+    small_i = eng.krum(g, n, f, return_index=True)
+    monkeypatch.setenv('BYZ_KRUM_SMALL', '0')
+    base_d = eng.pairwise_distances(g).numpy()
+    base_i = eng.krum(g, n, f, return_index=True)
+    eng.check()
+    off = ~np.eye(n, dtype=bool)
+    assert np.array_equal(small_d, small_d.T)
+    assert np.allclose(small_d[off], base_d[off], rtol=1e-6, atol=0.0)
+    assert small_i == base_i == faithful.krum_pick(small_d, faithful.visit_order(n), n, f)
+
