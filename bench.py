@@ -229,7 +229,8 @@ class KrumC2(Workload):
     def dominant(self):
         # N <= 128 runs csrc/krum_small.hip (K-sliced fp16x2 Gram, five launches) unless BYZ_KRUM_SMALL=0; its first kernel
         # reports under the same timing slot as the general path's Gram tiles
-        small = self.n <= 128 and self.d <= (1 << 18) and os.environ.get('BYZ_KRUM_SMALL', '1') != '0'
+        small = (self.n <= 128 and self.d <= int(os.environ.get('BYZ_KRUM_SMALL_MAX_COLS', 98304))
+                 and os.environ.get('BYZ_KRUM_SMALL', '1') != '0')
         return {'kernel': 'gram_tile', 'bound': 'hbm', 'work': 4.0 * self.n * self.d + 4.0 * self.n * self.n,
                 'peak': PEAK_HBM, 'unit': 'GB/s', 'scale': 1e9, 'arithmetic': 'f16x2' if small else 'exact',
                 'peak_note': ('csrc/krum_small.hip: K-sliced fp16x2 Gram over all rows (HBM bound: N/4 flop per byte)' if small

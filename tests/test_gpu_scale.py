@@ -438,7 +438,7 @@ def test_near_duplicate_rows_agree_to_rounding_with_and_without_the_identical_ro
 
 
 def test_small_krum_loop_form_for_long_rows(eng, monkeypatch):
-    """N <= 128 with more than 2^18 columns runs the general path by default; with the limit raised, K1's LOOP form (more
+    """N <= 128 with more than 98,304 columns runs the general path by default; with the limit raised, K1's LOOP form (more
     than eight slices per workgroup) must give the same distances and the same index."""
     n, d, f = 100, 300001, 24
     g = scaled(4321, n, d)
@@ -460,6 +460,7 @@ def test_small_krum_with_four_to_eight_slices_per_workgroup(eng, monkeypatch, d)
     2^18 take seven and eight.  Same distances and index as the general path."""
     n, f = 100, 24
     g = scaled(5000 + d % 1000, n, d)
+    monkeypatch.setenv('BYZ_KRUM_SMALL_MAX_COLS', str(1 << 18))   # the default stops at three slices per workgroup
     small_d = eng.pairwise_distances(g).numpy()
     small_i = eng.krum(g, n, f, return_index=True)
     monkeypatch.setenv('BYZ_KRUM_SMALL', '0')
