@@ -45,6 +45,7 @@
 #include "lane_exchange.hpp"
 
 #include <cstdlib>
+#include <cstring>
 
 namespace byz {
 namespace {
@@ -1097,7 +1098,13 @@ struct RingShape {   // buckets, sort registers, list slots by tile height
 template <int RPL>
 constexpr RingShape ring_shape() { return RPL <= 16 ? RingShape{512, 1, 6} : RingShape{1024, 2, 8}; }
 
-template <int RPL, int NC, int WAVES, int MODE>
+// BF (branch-free staging, BYZ_TM_FETCH=bf; found by reading the ISA at the end of round 2, unmeasured): the staging
+// loads below sit behind per-row and per-tile conditions, and hipcc answers a branch around a load with s_waitcnt vmcnt(0)
+// before the next one -- the sixteen 16-byte loads a thread issues per 1000-row tile are sixteen dependent round trips,
+// which at three workgroups per CU is 12 KiB in flight per CU: ~1.5 TB/s, what C3 measures.  With BF every load of a chunk
+// is unconditional (rows past the matrix re-read the last row and become +inf padding when they are stashed; only a ragged
+// last tile keeps the guarded form), so a chunk's loads are in flight together.
+template <int RPL, int NC, int WAVES, int MODE, bool BF = false>
 __global__ __launch_bounds__(64 * WAVES, (RPL * NC <= 64 || WAVES == 16 ? 4 : 2)) void median_window_kernel(
     const float* __restrict__ G, int n_rows, int64_t n_cols, int64_t ld, const int32_t* __restrict__ row_index,
     int keep, float* __restrict__ out, int32_t* __restrict__ redo) {
@@ -1139,7 +1146,22 @@ __global__ __launch_bounds__(64 * WAVES, (RPL * NC <= 64 || WAVES == 16 ? 4 : 2)
     constexpr int PASSES = 64 * JC / ROWS_PER_PASS;   // float4 loads per thread per chunk
     f32x4 tmp[PASSES];
     float poison = 0.0f;   // x * 0 accumulates to NaN as soon as one loaded value is NaN or +-inf
+    const bool full_tile = c_base + COLS <= n_cols;   // uniform: every tile but a ragged last one
     auto fetch = [&](int ch) {
+        if constexpr (BF) {
+            if (full_tile) {
+                int64_t src[PASSES];
+#pragma unroll
+                for (int p = 0; p < PASSES; ++p) {
+                    int row = ch * 64 * JC + ROWS_PER_PASS * p + ld_r;
+                    row = row < n_rows ? row : n_rows - 1;          // padding rows: re-read the last row, fixed in stash()
+                    src[p] = row_index ? row_index[row] : row;
+                }
+#pragma unroll
+                for (int p = 0; p < PASSES; ++p) tmp[p] = *reinterpret_cast<const f32x4u*>(G + src[p] * ld + ld_c);
+                return;
+            }
+        }
 #pragma unroll
         for (int p = 0; p < PASSES; ++p) {
             const int row = ch * 64 * JC + ROWS_PER_PASS * p + ld_r;
@@ -1162,8 +1184,12 @@ __global__ __launch_bounds__(64 * WAVES, (RPL * NC <= 64 || WAVES == 16 ? 4 : 2)
     auto stash = [&](int ch) {
 #pragma unroll
         for (int p = 0; p < PASSES; ++p) {
-            const f32x4 val = tmp[p];
-            if (ch * 64 * JC + ROWS_PER_PASS * p + ld_r < n_rows)
+            f32x4 val = tmp[p];
+            const bool real_row = ch * 64 * JC + ROWS_PER_PASS * p + ld_r < n_rows;
+            if constexpr (BF) {
+                if (!real_row) val = f32x4{pinf, pinf, pinf, pinf};   // (the guarded form loaded nothing here)
+            }
+            if (real_row)
                 poison = __builtin_fmaf(val.x + val.y, 0.0f, __builtin_fmaf(val.z + val.w, 0.0f, poison));
             *reinterpret_cast<f32x4*>(transit + (ROWS_PER_PASS * p + ld_r) * STRIDE + ld_q) = val;
         }
@@ -1254,8 +1280,19 @@ int launch_ring(byz_ctx* ctx, const float* G, int64_t n_rows, int64_t n_cols, in
         rc = launch_window_rows(ctx, G, n_rows, n_cols, ld, row_index, keep, out, redo, stream);
     if (rc == BYZ_E_UNSUPPORTED) {
         if constexpr (NC == 4 && WAVES == 4 && RPL >= 4) {
-            median_window_kernel<RPL, 4, 4, 1><<<static_cast<unsigned>(n_tiles), 256, 0, stream>>>(
-                G, static_cast<int>(n_rows), n_cols, ld, row_index, static_cast<int>(keep), out, redo);
+            const char* fetch_env = std::getenv("BYZ_TM_FETCH");
+            const bool branch_free = fetch_env != nullptr && std::strcmp(fetch_env, "bf") == 0;
+            if constexpr (RPL <= 16) {   // the shapes the default path uses (<= 1024 rows): both forms are built
+                if (branch_free)
+                    median_window_kernel<RPL, 4, 4, 1, true><<<static_cast<unsigned>(n_tiles), 256, 0, stream>>>(
+                        G, static_cast<int>(n_rows), n_cols, ld, row_index, static_cast<int>(keep), out, redo);
+                else
+                    median_window_kernel<RPL, 4, 4, 1><<<static_cast<unsigned>(n_tiles), 256, 0, stream>>>(
+                        G, static_cast<int>(n_rows), n_cols, ld, row_index, static_cast<int>(keep), out, redo);
+            } else {
+                median_window_kernel<RPL, 4, 4, 1><<<static_cast<unsigned>(n_tiles), 256, 0, stream>>>(
+                    G, static_cast<int>(n_rows), n_cols, ld, row_index, static_cast<int>(keep), out, redo);
+            }
             BYZ_TRY(check_launch("median_window_kernel<ring>"));
         } else {
             ctx->redo_valid = false;

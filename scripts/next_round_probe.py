@@ -5,7 +5,9 @@
   2. BYZ_TM_HIST16=1 (16-bit histogram counters: two workgroups per CU for the 8-wave row-split trimmed mean) against the
      default at 2080 rows:
      results must agree to 1e-6; time and tiles handed to the general kernel.
-  3. run scripts/small_krum_check.py next: it now also covers BYZ_KRUM_SMALL_TAIL=1 (K3..K5 in one launch), cases and timings.
+  3. BYZ_TM_FETCH=bf (branch-free staging loads of the <= 1024-row trimmed-mean kernel: the default issues its sixteen
+     loads per tile one round trip at a time) against the default at 1000 rows: results must be BITWISE equal; time.
+  4. run scripts/small_krum_check.py next: it now also covers BYZ_KRUM_SMALL_TAIL=1 (K3..K5 in one launch), cases and timings.
 """
 import os
 import sys
@@ -53,6 +55,28 @@ def main():
             rows, cols, mode, dt * 1e3, 4.0 * rows * cols / dt / 1e12, eng.trimmed_mean_redone()), flush=True)
         del outs
     print('  max |difference| between the two: %.3e' % np.abs(out['0'] - out['1']).max(), flush=True)
+    os.environ.pop('BYZ_TM_HIST16', None)
+
+    rows, cols, corrupted = 1000, 1 << 18, 200
+    g = rng.standard_normal((rows, cols), dtype=np.float32)
+    buf = eng.to_device(g)
+    out = {}
+    for mode in ('default', 'bf'):
+        if mode == 'bf':
+            os.environ['BYZ_TM_FETCH'] = 'bf'
+        else:
+            os.environ.pop('BYZ_TM_FETCH', None)
+        o = eng.trimmed_mean(buf, rows, corrupted)
+        eng.synchronize()
+        t0 = time.perf_counter()
+        outs = [eng.trimmed_mean(buf, rows, corrupted) for _ in range(40)]
+        eng.synchronize()
+        dt = (time.perf_counter() - t0) / 40
+        out[mode] = o.numpy()
+        print('trimmed mean %d x %d staging %s: %.3f ms (%.2f TB/s), tiles redone %d' % (
+            rows, cols, mode, dt * 1e3, 4.0 * rows * cols / dt / 1e12, eng.trimmed_mean_redone()), flush=True)
+        del outs
+    print('  bitwise equal:', bool(np.array_equal(out['default'], out['bf'], equal_nan=True)), flush=True)
 
 
 if __name__ == '__main__':
