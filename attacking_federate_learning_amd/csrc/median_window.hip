@@ -1098,7 +1098,8 @@ struct RingShape {   // buckets, sort registers, list slots by tile height
 template <int RPL>
 constexpr RingShape ring_shape() { return RPL <= 16 ? RingShape{512, 1, 6} : RingShape{1024, 2, 8}; }
 
-// BF (branch-free staging, BYZ_TM_FETCH=bf; found by reading the ISA at the end of round 2, unmeasured): the staging
+// BF (branch-free staging; found by reading the ISA at the end of round 2; the default for the <= 1024-row ring kernels,
+// BYZ_TM_FETCH=guarded brings the former code back; results bitwise equal on the GPU, speed not yet measured): the staging
 // loads below sit behind per-row and per-tile conditions, and hipcc answers a branch around a load with s_waitcnt vmcnt(0)
 // before the next one -- the sixteen 16-byte loads a thread issues per 1000-row tile are sixteen dependent round trips,
 // which at three workgroups per CU is 12 KiB in flight per CU: ~1.5 TB/s, what C3 measures.  With BF every load of a chunk
@@ -1280,8 +1281,10 @@ int launch_ring(byz_ctx* ctx, const float* G, int64_t n_rows, int64_t n_cols, in
         rc = launch_window_rows(ctx, G, n_rows, n_cols, ld, row_index, keep, out, redo, stream);
     if (rc == BYZ_E_UNSUPPORTED) {
         if constexpr (NC == 4 && WAVES == 4 && RPL >= 4) {
+            // BYZ_TM_FETCH=guarded: the former staging (one round trip per load); default: branch-free (bitwise the same
+            // results on the GPU: scripts/tm_bf_check.py, same registers / occupancy / LDS)
             const char* fetch_env = std::getenv("BYZ_TM_FETCH");
-            const bool branch_free = fetch_env != nullptr && std::strcmp(fetch_env, "bf") == 0;
+            const bool branch_free = fetch_env == nullptr || std::strcmp(fetch_env, "guarded") != 0;
             if constexpr (RPL <= 16) {   // the shapes the default path uses (<= 1024 rows): both forms are built
                 if (branch_free)
                     median_window_kernel<RPL, 4, 4, 1, true><<<static_cast<unsigned>(n_tiles), 256, 0, stream>>>(

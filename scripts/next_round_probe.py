@@ -5,8 +5,8 @@
   2. BYZ_TM_HIST16=1 (16-bit histogram counters: two workgroups per CU for the 8-wave row-split trimmed mean) against the
      default at 2080 rows:
      results must agree to 1e-6; time and tiles handed to the general kernel.
-  3. BYZ_TM_FETCH=bf (branch-free staging loads of the <= 1024-row trimmed-mean kernel: the default issues its sixteen
-     loads per tile one round trip at a time) against the default at 1000 rows: results must be BITWISE equal; time.
+  3. the branch-free staging loads of the <= 1024-row trimmed-mean kernel (default since the end of round 2, bitwise
+     checked) against BYZ_TM_FETCH=guarded (sixteen loads per tile, one round trip at a time) at 1000 rows: the time.
   4. run scripts/small_krum_check.py next: it now also covers BYZ_KRUM_SMALL_TAIL=1 (K3..K5 in one launch), cases and timings.
 """
 import os
@@ -61,9 +61,9 @@ def main():
     g = rng.standard_normal((rows, cols), dtype=np.float32)
     buf = eng.to_device(g)
     out = {}
-    for mode in ('default', 'bf'):
-        if mode == 'bf':
-            os.environ['BYZ_TM_FETCH'] = 'bf'
+    for mode in ('default', 'bf'):     # 'default' here = the former guarded staging, 'bf' = the branch-free one (now the default)
+        if mode == 'default':
+            os.environ['BYZ_TM_FETCH'] = 'guarded'
         else:
             os.environ.pop('BYZ_TM_FETCH', None)
         o = eng.trimmed_mean(buf, rows, corrupted)
