@@ -189,6 +189,7 @@ void byz_ctx_destroy(byz_ctx* ctx) {
     ctx->gram_compact.release();
     ctx->dist.release();
     ctx->near_pairs.release();
+    ctx->near_rows.release();
     ctx->gram_rep.release();
     ctx->near_sq.release();
     ctx->near_partial.release();

@@ -117,6 +117,7 @@ struct byz_ctx {
     byz::Buffer gram_rep;        // first row with bitwise equal Gram entries (candidate identical row), per row
     byz::Buffer near_pairs;      // near-duplicate pairs (int2) whose distance is re-evaluated on the difference
     byz::Buffer near_sq;         // their squared distances (fp64)
+    byz::Buffer near_rows;       // listed pairs per row (counts, then offsets): what makes the list's order canonical
     byz::Buffer near_partial;    // per (pair, column chunk) partial sums
     int64_t near_pair_capacity = 0;
     byz::Buffer dist;            // n x n fp32 distances (when the caller does not pass one)

@@ -556,10 +556,26 @@ __global__ __launch_bounds__(256) void gram_rep_kernel(const double* __restrict_
     if (lane == 0) rep[i] = best;
 }
 
+// The pair list must have ONE order on every GPU: the multi-GPU paths all-reduce the per-rank sums of squared differences
+// element by element (sharded.py), so slot p has to mean the same (i, j) on every rank.  A list filled through
+// atomicAdd(pair_count, 1) is ordered by wave timing.  So the list is built in three steps, and its order
+// -- ascending i, then ascending j -- is a function of the Gram alone (which the all-reduce leaves bitwise identical on
+// every rank): distance_kernel counts the listed pairs of every row (the count does not depend on the order of the atomics),
+// pair_offsets_kernel turns the counts into offsets (one workgroup, rows in order), pair_fill_kernel re-evaluates the rows
+// that have any and writes their pairs in column order.
+__device__ __forceinline__ bool pair_is_listed(const double* __restrict__ gram, int64_t n, const int32_t* __restrict__ rep,
+                                               int64_t i, int64_t j, double cii) {
+    const double cjj = gram[j * n + j];
+    const double d2 = cii + cjj - 2.0 * gram[i * n + j];
+    if (!(d2 < kNearEps * (cii + cjj))) return false;
+    const int ri = rep[i], rj = rep[j];
+    // representatives pair with each other; a folded row only with its representative (the proof of identity)
+    return (ri == i && rj == j) || ri == j;
+}
+
 __global__ __launch_bounds__(256) void distance_kernel(const double* __restrict__ gram, int64_t n,
                                                        float* __restrict__ dist, const int32_t* __restrict__ rep,
-                                                       int2* __restrict__ pairs, int32_t* __restrict__ pair_count,
-                                                       int pair_capacity) {
+                                                       int32_t* __restrict__ row_pairs) {
     const int64_t j = static_cast<int64_t>(blockIdx.x) * 64 + (threadIdx.x & 63);
     const int64_t i = static_cast<int64_t>(blockIdx.y) * 4 + (threadIdx.x >> 6);
     if (i >= n || j >= n) return;
@@ -571,17 +587,68 @@ __global__ __launch_bounds__(256) void distance_kernel(const double* __restrict_
         const double d2 = cii + cjj - 2.0 * gram[i * n + j];
         // rounding can leave a tiny negative value for near-identical rows; NaN (poisoned input) must stay NaN
         d = static_cast<float>(sqrt(d2 < 0.0 ? 0.0 : d2));
-        if (i > j && d2 < kNearEps * (cii + cjj)) {
-            const int ri = rep[i], rj = rep[j];
-            // representatives pair with each other; a folded row only with its representative (the proof of identity)
-            const bool listed = (ri == i && rj == j) || ri == j;
-            if (listed) {
-                const int slot = atomicAdd(pair_count, 1);
-                if (slot < pair_capacity) pairs[slot] = make_int2(static_cast<int>(i), static_cast<int>(j));
-            }
-        }
+        if (i > j && pair_is_listed(gram, n, rep, i, j, cii)) atomicAdd(&row_pairs[i], 1);
     }
     dist[i * n + j] = d;
+}
+
+// row_pairs[i] (counts) -> exclusive offsets, in place; *pair_count = the total.  One workgroup: n <= a few 10^4.
+__global__ __launch_bounds__(1024) void pair_offsets_kernel(int32_t* __restrict__ row_pairs, int64_t n,
+                                                            int32_t* __restrict__ pair_count) {
+    __shared__ int32_t wave_total[16];
+    __shared__ int32_t carry;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (int64_t base = 0; base < n; base += 1024) {
+        const int64_t i = base + threadIdx.x;
+        const int32_t c = i < n ? row_pairs[i] : 0;
+        int32_t scan = c;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int32_t up = __shfl_up(scan, d, 64);
+            if (lane >= d) scan += up;
+        }
+        if (lane == 63) wave_total[wave] = scan;
+        __syncthreads();
+        int32_t before = carry;
+        for (int w = 0; w < wave; ++w) before += wave_total[w];
+        // saturate instead of wrapping: beyond the capacity the call fails anyway (kStatusPairOverflow)
+        const int64_t at = static_cast<int64_t>(before) + scan - c;
+        if (i < n) row_pairs[i] = at > 0x3fffffff ? 0x3fffffff : static_cast<int32_t>(at);
+        __syncthreads();
+        if (threadIdx.x == 1023) {
+            const int64_t total = static_cast<int64_t>(before) + scan;
+            carry = total > 0x3fffffff ? 0x3fffffff : static_cast<int32_t>(total);
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *pair_count = carry;
+}
+
+// one wave per row; rows without listed pairs (all of them, unless clients nearly coincide) leave after one load
+__global__ __launch_bounds__(256) void pair_fill_kernel(const double* __restrict__ gram, int64_t n,
+                                                        const int32_t* __restrict__ rep,
+                                                        const int32_t* __restrict__ row_pairs,
+                                                        const int32_t* __restrict__ pair_count, int2* __restrict__ pairs,
+                                                        int pair_capacity) {
+    const int64_t i = static_cast<int64_t>(blockIdx.x) * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (i >= n) return;
+    int at = row_pairs[i];
+    const int stop = i + 1 < n ? row_pairs[i + 1] : *pair_count;
+    if (stop == at) return;
+    const double cii = gram[i * n + i];
+    for (int64_t j0 = 0; j0 < i && at < stop; j0 += 64) {
+        const int64_t j = j0 + lane;
+        const bool listed = j < i && pair_is_listed(gram, n, rep, i, j, cii);
+        const unsigned long long m = __ballot(listed);
+        if (listed) {
+            const int slot = at + __builtin_popcountll(m & ((1ull << lane) - 1ull));
+            if (slot < pair_capacity) pairs[slot] = make_int2(static_cast<int>(i), static_cast<int>(j));
+        }
+        at += __builtin_popcountll(m);
+    }
 }
 
 // sum over a column chunk of (g_i - g_j)^2: the difference in fp32 as the reference forms it, squares and sums in
@@ -756,6 +823,11 @@ static int launch_gram_rows(byz_ctx* ctx, const float* G, int64_t n_rows, int64_
         return BYZ_OK;
     }
     const int64_t stages = ceil_div(n_cols, BK);
+    // Everything that decides the ARITHMETIC (mode, split count, chunking) is derived from `plan_tiles`, the share size
+    // every rank computes alike, never from this rank's own tile count: shares differ by one tile between ranks, and ranks
+    // that summed in different orders would give identical rows' c_ii and c_ij (owned by different ranks) different bits
+    // -- which defeats gram_rep's folding of identical rows and floods the near-pair list.
+    const int64_t plan_tiles = ceil_div(n_tiles_all, share_count);
     // split-K.  Two workgroups fit a CU (LDS), so the chip runs `slots` workgroups at a time; the grid is
     // n_tiles * splits of them, all of equal length.  Pick the split count whose last round of workgroups
     // is (nearly) full -- 528 tiles x 2 splits would leave the chip one third idle, 528 x 31 does not --
@@ -765,16 +837,16 @@ static int launch_gram_rows(byz_ctx* ctx, const float* G, int64_t n_rows, int64_
     // few tiles and a short K (the reference's own sizes: N = 100, D = 79,510 is ONE tile): allow slabs of 128
     // columns so that the tile count x slab count still covers the chip
     int64_t min_stages = env_int("BYZ_GRAM_MIN_STAGES", 0);
-    if (min_stages <= 0) min_stages = n_tiles * (stages / 16) < slots ? 4 : 16;
+    if (min_stages <= 0) min_stages = plan_tiles * (stages / 16) < slots ? 4 : 16;
     int64_t max_splits = stages / min_stages;
     if (max_splits < 1) max_splits = 1;
     if (max_splits > 4096) max_splits = 4096;
     int64_t splits = 1;
     {
         double best = -1.0;
-        const int64_t want = ceil_div(slots * 3, n_tiles);   // at least ~3 rounds when K allows it
+        const int64_t want = ceil_div(slots * 3, plan_tiles);   // at least ~3 rounds when K allows it
         for (int64_t s = 1; s <= max_splits; ++s) {
-            const int64_t wgs = n_tiles * s;
+            const int64_t wgs = plan_tiles * s;
             const double eff = static_cast<double>(wgs) / static_cast<double>(ceil_div(wgs, slots) * slots);
             // prefer fuller last rounds; among equals the fewer slabs; below `want` only if nothing else fits
             const double score = eff - (s < want ? 0.05 : 0.0) - 1e-4 * static_cast<double>(s > want ? s - want : 0);
@@ -787,7 +859,7 @@ static int launch_gram_rows(byz_ctx* ctx, const float* G, int64_t n_rows, int64_
     // one tile (N <= 128, the reference's own sizes): one workgroup per CU.  More slabs cost more in slab traffic
     // and in the reduction than they gain in streaming parallelism (measured at N = 100, D = 79,510: 85 us per Krum
     // round with 256 slabs, 100 us with 512, 97 us with 128)
-    if (n_tiles == 1 && splits > ctx->num_cus) splits = ctx->num_cus;
+    if (plan_tiles == 1 && splits > ctx->num_cus) splits = ctx->num_cus;
     const int forced = env_int("BYZ_GRAM_SPLITS", 0);
     if (forced > 0) splits = forced;
     if (splits < 1) splits = 1;
@@ -799,12 +871,12 @@ static int launch_gram_rows(byz_ctx* ctx, const float* G, int64_t n_rows, int64_
     //   split   bf16 x 3: every fp32 value is split exactly into three bf16 planes and six bf16 MFMAs per block stand
     //           in for the fp32 product.  Default for N > 256.
     const char* mode_env = std::getenv("BYZ_GRAM_MODE");
-    const std::string mode_s = mode_env ? mode_env : (n_tiles >= 4 ? "split" : "exact");
+    const std::string mode_s = mode_env ? mode_env : (n_tiles_all >= 4 ? "split" : "exact");
     const bool dma = (ld % 4 == 0) && (reinterpret_cast<uintptr_t>(G) % 16 == 0) && env_int("BYZ_GRAM_NO_DMA", 0) == 0;
     const bool split_mode = dma && (mode_s == "split" || mode_s == "f16x2");   // f16x2 exists only on pre-split operands
     // chunked schedule (see the kernel): many tiles and a long K
     const int64_t chunk_stages = env_int("BYZ_GRAM_CHUNK_COLS", 8192) / BK;
-    const bool chunked = n_tiles >= 256 && stages > 2 * chunk_stages && env_int("BYZ_GRAM_NO_CHUNKS", 0) == 0 &&
+    const bool chunked = plan_tiles >= 256 && stages > 2 * chunk_stages && env_int("BYZ_GRAM_NO_CHUNKS", 0) == 0 &&
                          chunk_stages * BK <= 8192;   // a chunk must end before level 1 spills to the slab
     if (chunked) splits = ceil_div(stages, chunk_stages);
     const int64_t stages_per_split = chunked ? chunk_stages : ceil_div(stages, splits);
@@ -1006,15 +1078,23 @@ int launch_distances_from_gram(byz_ctx* ctx, const double* gram, int64_t n, floa
     BYZ_REQUIRE(gram && dist && n > 0, "distances: bad arguments");
     BYZ_TRY(ensure_pair_buffers(ctx, n));
     BYZ_TRY(ctx->gram_rep.ensure(static_cast<size_t>(n) * sizeof(int32_t)));
-    BYZ_HIP(hipMemsetAsync(near_pair_count_word(ctx), 0, sizeof(int32_t), stream));
+    BYZ_TRY(ctx->near_rows.ensure(static_cast<size_t>(n) * sizeof(int32_t)));
+    int32_t* row_pairs = ctx->near_rows.as<int32_t>();
+    BYZ_HIP(hipMemsetAsync(row_pairs, 0, static_cast<size_t>(n) * sizeof(int32_t), stream));
     {
         KernelTimer t(ctx, BYZ_K_DISTANCES, stream);
         gram_rep_kernel<<<static_cast<unsigned>(ceil_div(n, 4)), 256, 0, stream>>>(gram, n, ctx->gram_rep.as<int32_t>());
         BYZ_TRY(check_launch("gram_rep_kernel"));
         dim3 grid(static_cast<unsigned>(ceil_div(n, 64)), static_cast<unsigned>(ceil_div(n, 4)));
-        distance_kernel<<<grid, 256, 0, stream>>>(gram, n, dist, ctx->gram_rep.as<int32_t>(), ctx->near_pairs.as<int2>(),
-                                                  near_pair_count_word(ctx), (int)ctx->near_pair_capacity);
+        distance_kernel<<<grid, 256, 0, stream>>>(gram, n, dist, ctx->gram_rep.as<int32_t>(), row_pairs);
         BYZ_TRY(check_launch("distance_kernel"));
+        // the pair list in its canonical order (ascending i, then j): see pair_is_listed
+        pair_offsets_kernel<<<1, 1024, 0, stream>>>(row_pairs, n, near_pair_count_word(ctx));
+        BYZ_TRY(check_launch("pair_offsets_kernel"));
+        pair_fill_kernel<<<static_cast<unsigned>(ceil_div(n, 4)), 256, 0, stream>>>(
+            gram, n, ctx->gram_rep.as<int32_t>(), row_pairs, near_pair_count_word(ctx), ctx->near_pairs.as<int2>(),
+            (int)ctx->near_pair_capacity);
+        BYZ_TRY(check_launch("pair_fill_kernel"));
     }
     if (G != nullptr) {
         BYZ_TRY(launch_near_pair_sqdist(ctx, G, n_cols, ld, nullptr, ctx->near_sq.as<double>(), stream));

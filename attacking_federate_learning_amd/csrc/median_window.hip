@@ -1098,14 +1098,11 @@ struct RingShape {   // buckets, sort registers, list slots by tile height
 template <int RPL>
 constexpr RingShape ring_shape() { return RPL <= 16 ? RingShape{512, 1, 6} : RingShape{1024, 2, 8}; }
 
-// BF (branch-free staging; found by reading the ISA at the end of round 2; the default for the <= 1024-row ring kernels,
-// BYZ_TM_FETCH=guarded brings the former code back; results bitwise equal on the GPU, speed not yet measured): the staging
-// loads below sit behind per-row and per-tile conditions, and hipcc answers a branch around a load with s_waitcnt vmcnt(0)
-// before the next one -- the sixteen 16-byte loads a thread issues per 1000-row tile are sixteen dependent round trips,
-// which at three workgroups per CU is 12 KiB in flight per CU: ~1.5 TB/s, what C3 measures.  With BF every load of a chunk
-// is unconditional (rows past the matrix re-read the last row and become +inf padding when they are stashed; only a ragged
-// last tile keeps the guarded form), so a chunk's loads are in flight together.
-template <int RPL, int NC, int WAVES, int MODE, bool BF = false>
+// (A branch-free form of the staging loads -- every load of a chunk unconditional, padding rows re-reading the last row --
+// was built at the end of round 2 on the strength of the ISA (s_waitcnt vmcnt(0) in front of every guarded load) and measured
+// in round 3: bitwise the same results, 1.256 ms against 0.648 ms at 1000 rows x 2^18 columns
+// (profiles/r03a_optin_variants_probe.txt).  It was removed; the guarded loads stay.)
+template <int RPL, int NC, int WAVES, int MODE>
 __global__ __launch_bounds__(64 * WAVES, (RPL * NC <= 64 || WAVES == 16 ? 4 : 2)) void median_window_kernel(
     const float* __restrict__ G, int n_rows, int64_t n_cols, int64_t ld, const int32_t* __restrict__ row_index,
     int keep, float* __restrict__ out, int32_t* __restrict__ redo) {
@@ -1147,22 +1144,7 @@ __global__ __launch_bounds__(64 * WAVES, (RPL * NC <= 64 || WAVES == 16 ? 4 : 2)
     constexpr int PASSES = 64 * JC / ROWS_PER_PASS;   // float4 loads per thread per chunk
     f32x4 tmp[PASSES];
     float poison = 0.0f;   // x * 0 accumulates to NaN as soon as one loaded value is NaN or +-inf
-    const bool full_tile = c_base + COLS <= n_cols;   // uniform: every tile but a ragged last one
     auto fetch = [&](int ch) {
-        if constexpr (BF) {
-            if (full_tile) {
-                int64_t src[PASSES];
-#pragma unroll
-                for (int p = 0; p < PASSES; ++p) {
-                    int row = ch * 64 * JC + ROWS_PER_PASS * p + ld_r;
-                    row = row < n_rows ? row : n_rows - 1;          // padding rows: re-read the last row, fixed in stash()
-                    src[p] = row_index ? row_index[row] : row;
-                }
-#pragma unroll
-                for (int p = 0; p < PASSES; ++p) tmp[p] = *reinterpret_cast<const f32x4u*>(G + src[p] * ld + ld_c);
-                return;
-            }
-        }
 #pragma unroll
         for (int p = 0; p < PASSES; ++p) {
             const int row = ch * 64 * JC + ROWS_PER_PASS * p + ld_r;
@@ -1187,9 +1169,6 @@ __global__ __launch_bounds__(64 * WAVES, (RPL * NC <= 64 || WAVES == 16 ? 4 : 2)
         for (int p = 0; p < PASSES; ++p) {
             f32x4 val = tmp[p];
             const bool real_row = ch * 64 * JC + ROWS_PER_PASS * p + ld_r < n_rows;
-            if constexpr (BF) {
-                if (!real_row) val = f32x4{pinf, pinf, pinf, pinf};   // (the guarded form loaded nothing here)
-            }
             if (real_row)
                 poison = __builtin_fmaf(val.x + val.y, 0.0f, __builtin_fmaf(val.z + val.w, 0.0f, poison));
             *reinterpret_cast<f32x4*>(transit + (ROWS_PER_PASS * p + ld_r) * STRIDE + ld_q) = val;
@@ -1281,21 +1260,8 @@ int launch_ring(byz_ctx* ctx, const float* G, int64_t n_rows, int64_t n_cols, in
         rc = launch_window_rows(ctx, G, n_rows, n_cols, ld, row_index, keep, out, redo, stream);
     if (rc == BYZ_E_UNSUPPORTED) {
         if constexpr (NC == 4 && WAVES == 4 && RPL >= 4) {
-            // BYZ_TM_FETCH=guarded: the former staging (one round trip per load); default: branch-free (bitwise the same
-            // results on the GPU: scripts/tm_bf_check.py, same registers / occupancy / LDS)
-            const char* fetch_env = std::getenv("BYZ_TM_FETCH");
-            const bool branch_free = fetch_env == nullptr || std::strcmp(fetch_env, "guarded") != 0;
-            if constexpr (RPL <= 16) {   // the shapes the default path uses (<= 1024 rows): both forms are built
-                if (branch_free)
-                    median_window_kernel<RPL, 4, 4, 1, true><<<static_cast<unsigned>(n_tiles), 256, 0, stream>>>(
-                        G, static_cast<int>(n_rows), n_cols, ld, row_index, static_cast<int>(keep), out, redo);
-                else
-                    median_window_kernel<RPL, 4, 4, 1><<<static_cast<unsigned>(n_tiles), 256, 0, stream>>>(
-                        G, static_cast<int>(n_rows), n_cols, ld, row_index, static_cast<int>(keep), out, redo);
-            } else {
-                median_window_kernel<RPL, 4, 4, 1><<<static_cast<unsigned>(n_tiles), 256, 0, stream>>>(
-                    G, static_cast<int>(n_rows), n_cols, ld, row_index, static_cast<int>(keep), out, redo);
-            }
+            median_window_kernel<RPL, 4, 4, 1><<<static_cast<unsigned>(n_tiles), 256, 0, stream>>>(
+                G, static_cast<int>(n_rows), n_cols, ld, row_index, static_cast<int>(keep), out, redo);
             BYZ_TRY(check_launch("median_window_kernel<ring>"));
         } else {
             ctx->redo_valid = false;

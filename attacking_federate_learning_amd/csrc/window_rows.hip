@@ -86,9 +86,9 @@ struct ColumnPlan {   // what sweep 3 needs to know about a column (written by i
 
 // W waves, RPW 16-row blocks per wave (rows <= 16 W RPW), B buckets, SR sort registers per lane (64 SR candidates),
 // LS stack slots per lane and column.  H16: 16-bit histogram counters (rows < 65536), two per LDS word -- the 8-wave shapes'
-// LDS then is what their gather stacks need, and TWO workgroups fit a CU (experimental: BYZ_TM_HIST16=1).
+// LDS then is what their gather stacks need, and TWO workgroups fit a CU (the default: see launch_window_rows).
 template <int W, int RPW, int B, int SR, int LS, bool H16>
-__global__ __launch_bounds__(64 * W, (W == 4 ? 3 : 4)) void window_rows_kernel(const float* __restrict__ G, int n_rows, int64_t n_cols,
+__global__ __launch_bounds__(64 * W, (W == 4 ? (H16 ? 4 : 3) : 4)) void window_rows_kernel(const float* __restrict__ G, int n_rows, int64_t n_cols,
                                                              int64_t ld, const int32_t* __restrict__ row_index, int keep,
                                                              float* __restrict__ out, int32_t* __restrict__ redo) {
     constexpr int T = 64 * W;
@@ -532,25 +532,28 @@ int launch_window_rows(byz_ctx* ctx, const float* G, int64_t n_rows, int64_t n_c
     const int64_t blocks = ceil_div(n_rows, 16);
 #define BYZ_SHAPE(W, RPW, B, SR, LS) \
     if (blocks <= (W) * (RPW)) return launch_shape<W, RPW, B, SR, LS>(G, n_rows, n_cols, ld, row_index, keep, out, redo, stream)
-    BYZ_SHAPE(4, 4, 512, 1, 6);     //  <=  256 rows
-    BYZ_SHAPE(4, 8, 512, 1, 6);     //  <=  512
-    BYZ_SHAPE(4, 12, 512, 1, 6);    //  <=  768
-    BYZ_SHAPE(4, 16, 512, 1, 6);    //  <= 1024
-    // BYZ_TM_HIST16=1 (experiment for the 8-wave shapes, unmeasured): 16-bit histogram counters, so that the workgroup's LDS
-    // is what its gather stacks need (57 KiB + 14 KiB static instead of 74 + 14) and TWO workgroups fit a CU -- one loads
-    // while the other selects.  (Halving the bucket count instead does not work: scripts/proto/ring_window.py puts 6% of
-    // the columns of a 2080-row, keep-159 tile over the 128-candidate sort with 512 buckets, i.e. most tiles.)
+    // 16-bit histogram counters (rows < 65536, two per LDS word) wherever the histogram, not the gather stacks, sets the
+    // workgroup's LDS: the 8-wave shapes then need 57 + 14 KiB instead of 74 + 14 and TWO workgroups fit a CU -- one loads while
+    // the other selects.  Measured in round 3 (profiles/r03a_optin_variants_probe.txt): 2080 rows x 2^18 columns 1.916 -> 1.181 ms
+    // (1.14 -> 1.85 TB/s), results bitwise equal, the same tiles redone.  BYZ_TM_HIST16=0 keeps 32-bit counters.
+    // (Halving the bucket count instead does not work: scripts/proto/ring_window.py puts 6% of the columns of a 2080-row,
+    // keep-159 tile over the 128-candidate sort with 512 buckets, i.e. most tiles.)
     const char* hist16_env = std::getenv("BYZ_TM_HIST16");
-    if (hist16_env != nullptr && std::atoi(hist16_env) != 0) {
-        if (blocks <= 8 * 12) return launch_shape<8, 12, 1024, 2, 6, true>(G, n_rows, n_cols, ld, row_index, keep, out, redo, stream);
-        if (blocks <= 8 * 17) return launch_shape<8, 17, 1024, 2, 6, true>(G, n_rows, n_cols, ld, row_index, keep, out, redo, stream);
-        if (blocks <= 8 * 20) return launch_shape<8, 20, 1024, 2, 6, true>(G, n_rows, n_cols, ld, row_index, keep, out, redo, stream);
-    }
-    BYZ_SHAPE(8, 12, 1024, 2, 6);   //  <= 1536
-    BYZ_SHAPE(8, 17, 1024, 2, 6);   //  <= 2176
-    BYZ_SHAPE(8, 20, 1024, 2, 6);   //  <= 2560
-    BYZ_SHAPE(16, 14, 1024, 4, 6);  //  <= 3584
-    BYZ_SHAPE(16, 21, 1024, 4, 6);  //  <= 5376
+    const bool hist16 = hist16_env == nullptr || std::atoi(hist16_env) != 0;
+#define BYZ_SHAPE16(W, RPW, B, SR, LS)                                                                                   \
+    if (blocks <= (W) * (RPW))                                                                                           \
+        return hist16 ? launch_shape<W, RPW, B, SR, LS, true>(G, n_rows, n_cols, ld, row_index, keep, out, redo, stream) \
+                      : launch_shape<W, RPW, B, SR, LS>(G, n_rows, n_cols, ld, row_index, keep, out, redo, stream)
+    BYZ_SHAPE16(4, 4, 512, 1, 6);     //  <=  256 rows
+    BYZ_SHAPE16(4, 8, 512, 1, 6);     //  <=  512
+    BYZ_SHAPE16(4, 12, 512, 1, 6);    //  <=  768
+    BYZ_SHAPE16(4, 16, 512, 1, 6);    //  <= 1024
+    BYZ_SHAPE16(8, 12, 1024, 2, 6);   //  <= 1536
+    BYZ_SHAPE16(8, 17, 1024, 2, 6);   //  <= 2176
+    BYZ_SHAPE16(8, 20, 1024, 2, 6);   //  <= 2560
+    BYZ_SHAPE(16, 14, 1024, 4, 6);    //  <= 3584   (16 waves: the gather stacks set the LDS, 16-bit counters gain nothing)
+    BYZ_SHAPE(16, 21, 1024, 4, 6);    //  <= 5376
+#undef BYZ_SHAPE16
 #undef BYZ_SHAPE
     return BYZ_E_UNSUPPORTED;
 }

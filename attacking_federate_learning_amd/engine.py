@@ -365,7 +365,12 @@ class Engine:
         idx = int(idx.value)
         return idx if (keys is None or idx < 0) else keys[idx]
 
-    def krum(self, g, users_count, corrupted_count, distances=None, return_index=False):
+    def krum(self, g, users_count, corrupted_count, distances=None, return_index=False, check=True):
+        """defences.krum (defences.py:23-42).  Device-resident `g` without `return_index`: the winning row is copied on
+        the device and nothing needs to cross to the host, but a kernel can only FLAG a failure there (a Gram chunk that
+        never got its ticket, helpers that lost their worker: the sticky status word) -- so by default the call ends with
+        `self.check(stream)` (one synchronisation) and raises instead of returning a row picked from invalid distances.
+        `check=False` keeps the call asynchronous; the caller then owes an `engine.check()` before it uses the result."""
         if not return_index:
             # defences.py:24-25 (the message says +3, the check is +1)
             assert users_count >= 2 * corrupted_count + 1, (
@@ -387,7 +392,11 @@ class Engine:
         _check(self.lib.byz_krum_dev(self.ctx, _vp(m.ptr), m.rows, m.cols, m.ld, int(users_count),
                                      int(corrupted_count), 0, _vp(ptr), ctypes.byref(idx) if return_index else None,
                                      _vp(m.stream)))
-        return int(idx.value) if return_index else out
+        if return_index:
+            return int(idx.value)      # (the library read the status word together with the index)
+        if check:
+            self.check(m.stream)
+        return out
 
     def _row(self, g, idx):
         """Row `idx` of the caller's matrix, in the caller's own container type (negative idx as numpy)."""

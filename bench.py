@@ -224,7 +224,9 @@ class KrumC2(Workload):
         self.g = make_matrix(torch, n, d, seed, device)
 
     def step(self):
-        self.last = self.eng.krum(self.g, self.n, self.f)
+        # asynchronous (the winning row is copied on the device); timed_steps() ends with eng.check(), which raises if any
+        # kernel of the timed rounds flagged a failure
+        self.last = self.eng.krum(self.g, self.n, self.f, check=False)
 
     def dominant(self):
         # N <= 128 runs csrc/krum_small.hip (K-sliced fp16x2 Gram, five launches) unless BYZ_KRUM_SMALL=0; its first kernel
@@ -380,6 +382,7 @@ def timed_steps(torch, dist, wl, eng, steps, warmup, world, events=True):
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t0
+    eng.check()           # the sticky device status word: a kernel of the timed steps that flagged a failure raises here
     per_kernel = eng.timing_read()
     eng.timing(False)
     if world > 1:
