@@ -823,11 +823,12 @@ static int launch_gram_rows(byz_ctx* ctx, const float* G, int64_t n_rows, int64_
         return BYZ_OK;
     }
     const int64_t stages = ceil_div(n_cols, BK);
-    // Everything that decides the ARITHMETIC (mode, split count, chunking) is derived from `plan_tiles`, the share size
-    // every rank computes alike, never from this rank's own tile count: shares differ by one tile between ranks, and ranks
-    // that summed in different orders would give identical rows' c_ii and c_ij (owned by different ranks) different bits
-    // -- which defeats gram_rep's folding of identical rows and floods the near-pair list.
-    const int64_t plan_tiles = ceil_div(n_tiles_all, share_count);
+    // Everything that decides the ARITHMETIC (mode, split count, chunking) is derived from the tile count of the WHOLE
+    // triangle, never from this rank's share of it: (i) shares differ by one tile between ranks, and ranks that summed in
+    // different orders would give identical rows' c_ii and c_ij (owned by different ranks) different bits -- which defeats
+    // gram_rep's folding of identical rows and floods the near-pair list; (ii) the sum of the W shares then is
+    // BITWISE the Gram one GPU computes alone (tests/test_gpu_sharded.py), so sharded and unsharded runs select alike.
+    const int64_t plan_tiles = n_tiles_all;
     // split-K.  Two workgroups fit a CU (LDS), so the chip runs `slots` workgroups at a time; the grid is
     // n_tiles * splits of them, all of equal length.  Pick the split count whose last round of workgroups
     // is (nearly) full -- 528 tiles x 2 splits would leave the chip one third idle, 528 x 31 does not --
@@ -1100,7 +1101,13 @@ int launch_distances_from_gram(byz_ctx* ctx, const double* gram, int64_t n, floa
         BYZ_TRY(launch_near_pair_sqdist(ctx, G, n_cols, ld, nullptr, ctx->near_sq.as<double>(), stream));
         return launch_near_pair_apply(ctx, ctx->near_sq.as<double>(), n, dist, stream);
     }
-    return canonicalise_duplicates(ctx, n, dist, stream);
+    // Without G the matrix is NOT canonicalised here: a zero that the Gram identity produced by cancellation (two clients
+    // that nearly coincide) is not an identity, and folding such a row into its neighbour would overwrite its whole
+    // distance row with the neighbour's before the caller's near-pair step could correct the one entry (found by
+    // tests/test_gpu_sharded.py in round 3: distances of a near-duplicate row off by 4e-6).  Every zero -- true or not --
+    // is on the pair list (0 < eps (c_ii + c_jj)), so a caller that sees byz_near_pairs_count() == 0 has no identical rows
+    // to canonicalise, and any other caller must finish with byz_near_pairs_apply_dev, which canonicalises on proven zeros.
+    return BYZ_OK;
 }
 
 }  // namespace byz

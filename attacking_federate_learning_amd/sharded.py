@@ -326,8 +326,8 @@ class ShardedAggregator:
         nbytes = 0
         landed = []    # (contiguous landing buffer, strided destination): a block of a pitch-padded matrix is not contiguous
         for peer in range(self.world):
-            if peer == self.rank:
-                continue
+            if peer == self.rank and not self.always_collective:
+                continue        # (BYZ_FORCE_COLLECTIVES=1: the rank's own block goes through RCCL too, send-to-self)
             global_peer = self.dist.get_global_rank(self.group, peer) if self.group is not None else peer
             if blocks_out[peer].numel():
                 ops.append(self.dist.P2POp(self.dist.isend, blocks_out[peer], global_peer, group=self.group))
@@ -389,9 +389,11 @@ class ShardedAggregator:
         all_of_mine = len(mine) == rows_local.shape[0] and np.array_equal(mine, np.arange(rows_local.shape[0]))
         picked = rows_local if all_of_mine else rows_local.index_select(0, mine_t)
         blocks_in = [out[int(starts[p]):int(starts[p + 1])] for p in range(self.world)]
-        blocks_in[self.rank].copy_(picked[:, lo:hi])
-        if self.world > 1:
-            blocks_out = [picked[:, bounds[p][0]:bounds[p][1]].contiguous() if p != self.rank else picked[:0]
+        through_rccl = self.always_collective          # the rank's own block as a send-to-self (tests the P2P path on one GPU)
+        if not through_rccl:
+            blocks_in[self.rank].copy_(picked[:, lo:hi])
+        if self.world > 1 or through_rccl:
+            blocks_out = [picked[:, bounds[p][0]:bounds[p][1]].contiguous() if (p != self.rank or through_rccl) else picked[:0]
                           for p in range(self.world)]
             self._exchange(name, blocks_out, blocks_in)
         plain = np.array_equal(row_index, np.arange(len(wanted_rows)))

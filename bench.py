@@ -143,6 +143,18 @@ class BulyanSharded(Workload):
                                        total_columns=self.d_total)
             self.last = (out, sel)
 
+    def verify(self):
+        """After the timed region: the last step's selection holds theta distinct clients and its output is finite (the
+        full-size parity checks proper are tests/test_gpu_fullsize.py; this only refuses to print a rate for garbage)."""
+        out, sel = self.last[0], self.last[1]
+        sel = np.asarray(sel.numpy() if hasattr(sel, 'numpy') else sel).reshape(-1)
+        theta = self.n - 2 * self.f
+        if len(sel) != theta or len(set(sel.tolist())) != theta or sel.min() < 0 or sel.max() >= self.n:
+            raise SystemExit('bench: the selection of the last step is not %d distinct clients' % theta)
+        if not bool(self.torch.isfinite(out).all()):
+            raise SystemExit('bench: the aggregated vector of the last step is not finite')
+        return {'selection_distinct': theta, 'output_finite': True}
+
     def dtype(self):
         # fp32 data and fp32 results; for N > 256 the Gram contraction runs as an exact three-way bf16 split of every
         # fp32 operand on the bf16 matrix cores (six bf16 MFMAs per fp32 product block, fp32 accumulate)
@@ -614,6 +626,8 @@ def main():
         'kernels': kernel_table(per_kernel, args.steps),
         'collectives': collectives,
     }
+    if hasattr(wl, 'verify'):
+        line['verified_after_timing'] = wl.verify()
     if args.workload in ('c4', 'c5s') and (args.layout == 'both' or (world > 1 and args.layout == 'columns'
                                                                     and os.environ.get('BYZ_BENCH_ONE_LAYOUT') != '1')):
         # the other layout, same K steps: north_star names client sharding with an all-gather of row tiles; which one is

@@ -98,6 +98,9 @@ int byz_distances_from_gram_dev(byz_ctx* ctx, const double* gram_dev, int64_t n_
 /* re-evaluate every pair with d^2 < (c_ii + c_jj)/16 on the difference itself.  A caller that only holds   */
 /* a column slice of G (byz_distances_from_gram_dev on an all-reduced Gram) finishes the same step itself:  */
 /* count -> per-rank sums of squared differences over the local columns -> (all-reduce) -> apply.           */
+/* The list is ordered (ascending i, then j): slot p is the same pair on every GPU that holds the same Gram. */
+/* A count > 0 OBLIGES the caller to finish with byz_near_pairs_apply_dev: until then listed entries hold    */
+/* the Gram identity's value (possibly 0 by cancellation) and identical rows are not yet canonicalised.      */
 int byz_near_pairs_count(byz_ctx* ctx, int64_t* count_host, void* stream);
 int byz_near_pairs_sqdist_dev(byz_ctx* ctx, const float* G_dev, int64_t n_rows, int64_t n_cols, int64_t ld,
                               const int32_t* row_index_dev, double* sq_dev, void* stream);

@@ -1,0 +1,110 @@
+"""One rank of ShardedAggregator(HipKernels) over RCCL (backend "nccl"), run by tests/test_gpu_sharded.py at world size 1
+with BYZ_FORCE_COLLECTIVES=1 (every collective issued although there is nobody else) -- and usable as it is under
+`python -m torch.distributed.run --nproc-per-node W` on a multi-GPU node: every rank checks its results against the
+unsharded engine on its own GPU and rank 0 prints one JSON line.
+
+Both layouts of attacking_federate_learning_amd/sharded.py, on a matrix with f identical rows (the attack) and two pairs of
+nearly coincident honest rows: drift attack, Krum, trimmed mean, no_defense, Bulyan.
+"""
+import json
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def main():
+    import torch
+    import torch.distributed as dist
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    torch.cuda.set_device(local_rank)
+    device = torch.device('cuda', local_rank)
+    dist.init_process_group('nccl', device_id=device)
+    rank, world = dist.get_rank(), dist.get_world_size()
+
+    from attacking_federate_learning_amd.engine import Engine
+    from attacking_federate_learning_amd.sharded import HipKernels, ShardedAggregator
+    eng = Engine(local_rank)
+    agg = ShardedAggregator(HipKernels(eng))
+    problems = []
+
+    def expect(cond, what):
+        if not cond:
+            problems.append(what)
+
+    n, d, f = int(os.environ.get('BYZ_TEST_N', 600)), int(os.environ.get('BYZ_TEST_D', 20001)), None
+    f = int(n * 0.24)
+    gen = torch.Generator(device=device).manual_seed(4242)          # every rank builds the same matrix
+    g = torch.randn((n, d), device=device, generator=gen)
+    perm = torch.from_numpy(np.random.default_rng(4242).permutation(n)).to(device)
+    g.mul_((1.0 + 0.5 * perm.to(torch.float32) / n)[:, None])
+    g[f + 3] = g[f + 2] + 1e-4 * torch.randn(d, device=device, generator=gen)
+    g[n - 1] = g[n - 7] + 3e-4 * torch.randn(d, device=device, generator=gen)
+    honest = g.clone()
+
+    # ---- the unsharded engine on this GPU: what every layout must reproduce
+    ref = honest.clone()
+    drift_w, mean_w, std_w = eng.drift_attack(ref[:f], 1.5, write_back=True)
+    dist_w = torch.from_numpy(eng.pairwise_distances(ref).numpy())
+    krum_w = eng.krum(ref, n, f, return_index=True)
+    tm_w = eng.trimmed_mean(ref, n, f)
+    nd_w = eng.no_defense(ref)
+    bul_w, sel_w = eng.bulyan(ref, n, f, return_selection=True)
+    sel_w = sel_w.cpu().numpy().tolist()
+    off = ~torch.eye(n, dtype=torch.bool)
+
+    def same_distances(got, label):
+        got = torch.from_numpy(got.numpy())
+        expect(torch.equal(got[off] == 0, dist_w[off] == 0), label + ': exact zeros differ')
+        rel = ((got[off] - dist_w[off]).abs() / dist_w[off].clamp_min(1e-30)).nan_to_num(0.0)
+        expect(float(rel.max()) < 2e-6, '%s: distances differ by %.2e' % (label, float(rel.max())))
+
+    # ---- columns layout: client-sharded rows -> column slices through the personalised exchange
+    rows_per = [n // world + (1 if r < n % world else 0) for r in range(world)]
+    start = sum(rows_per[:rank])
+    mine = honest[start:start + rows_per[rank]].clone()
+    g_local = agg.reshard_clients_to_columns(mine, rows_per)
+    lo, hi = agg.column_slices(d)[rank]
+    expect(torch.equal(g_local, honest[:, lo:hi]), 'reshard_clients_to_columns')
+    drift, _, _ = agg.drift_attack(g_local, f, 1.5, write_back=True, gather=True, total_columns=d)
+    expect(torch.allclose(drift, drift_w, rtol=1e-6, atol=1e-6), 'columns: drift')
+    same_distances(agg.global_distances(g_local), 'columns')
+    expect(agg.krum(g_local, n, f, return_index=True) == krum_w, 'columns: krum index')
+    row = agg.krum(g_local, n, f, gather=True, total_columns=d)
+    expect(torch.allclose(row, ref[krum_w], rtol=1e-5, atol=1e-6), 'columns: krum row')
+    expect(torch.allclose(agg.trimmed_mean(g_local, n, f, gather=True, total_columns=d), tm_w, rtol=1e-5, atol=1e-5), 'columns: trimmed mean')
+    expect(torch.allclose(agg.no_defense(g_local, gather=True, total_columns=d), nd_w, rtol=1e-5, atol=1e-6), 'columns: no_defense')
+    out, sel = agg.bulyan(g_local, n, f, gather=True, return_selection=True, total_columns=d)
+    expect(sel.tolist() == sel_w, 'columns: bulyan selection')
+    expect(torch.allclose(out, bul_w, rtol=1e-5, atol=1e-5), 'columns: bulyan vector')
+
+    # ---- clients layout (north_star): rows stay where the clients left them
+    mine = honest[start:start + rows_per[rank]].clone()
+    drift2, _, _ = agg.drift_attack_clients(mine, rows_per, f, 1.5)
+    expect(torch.allclose(drift2, drift_w, rtol=1e-5, atol=1e-6), 'clients: drift')
+    same_distances(agg.client_distances(mine, rows_per, panel_columns=4096), 'clients')
+    expect(agg.krum_clients(mine, rows_per, n, f, return_index=True) == krum_w, 'clients: krum index')
+    row2 = agg.krum_clients(mine, rows_per, n, f)
+    expect(torch.allclose(row2, ref[krum_w], rtol=1e-5, atol=1e-6), 'clients: krum row')
+    out2, sel2 = agg.bulyan_clients(mine, rows_per, n, f, return_selection=True)
+    expect(sel2.tolist() == sel_w, 'clients: bulyan selection')
+    expect(torch.allclose(out2, bul_w, rtol=1e-5, atol=1e-5), 'clients: bulyan vector')
+
+    comm = agg.comm_report()
+    eng.check()
+    flag = torch.tensor([len(problems)], device=device)
+    dist.all_reduce(flag)
+    if rank == 0:
+        print(json.dumps({'ok': int(flag.item()) == 0, 'problems': problems, 'world': world, 'n': n, 'd': d,
+                          'comm': {k: {'calls': v['calls'], 'MB': v['bytes'] / 1e6, 'ms': round(v['ms'], 3)} for k, v in comm.items()}}),
+              flush=True)
+    dist.destroy_process_group()
+    return 0 if not problems else 1
+
+
+if __name__ == '__main__':
+    sys.exit(main())

@@ -1,0 +1,277 @@
+"""The multi-rank HIP path on ONE GPU (needs an MI355X): SURVEY.md 8(e) -- "validate sharded == unsharded on one GPU by
+looping shards through the same kernels; smoke-test the RCCL path at nranks = 1".
+
+Everything `world > 1` runs on a rank's GPU is exercised here through the C ABI, with the collectives replaced by sums on
+the device (an all-reduce of W tensors is their sum; an all-gather is a concatenation):
+
+  * byz_gram_share_dev: the W shares of a panel's Gram tiles SUM to the Gram one GPU computes alone -- bitwise, in every
+    arithmetic (fp32-input MFMA, fused bf16 x 3, pre-split bf16 x 3 planes, pre-split fp16 x 2 planes), with and without
+    the row indirection that skips the padding rows of an uneven all-gather;
+  * the columns layout (reference server.py:81-83 sharded by column): per-slice fp64 Grams over uneven slices with the
+    padded row pitch -> sum -> distances -> byz_near_pairs_count / _sqdist / _apply -> selection -> per-slice second stage;
+  * the clients layout (north_star; reference main.py:26-32): column panels of the gathered rows -> every rank's tile share
+    -> sum -> distances -> near pairs over the panels;
+  * ShardedAggregator(HipKernels) itself under BYZ_FORCE_COLLECTIVES=1 at world size 1, both layouts: all_gather_into_tensor,
+    all_reduce, batch_isend_irecv (send-to-self) and broadcast go through RCCL (tests/sharded_rccl_worker.py, own process).
+
+The inputs carry what makes the sharded path hard: f bitwise identical rows (the attack, malicious.py:26-27) and honest
+rows that nearly coincide (pairs the Gram identity cannot resolve, defences.py:20).
+"""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+MAL_PROP = 0.24
+
+
+@pytest.fixture(scope='module')
+def torch():
+    import torch as t
+    return t
+
+
+def scaled(torch, n, d, seed, device, pitch=None):
+    """'scaled' family as an (n, d) view of an (n, pitch) buffer."""
+    gen = torch.Generator(device=device).manual_seed(seed)
+    pitch = pitch or d
+    buf = torch.empty((n, pitch), dtype=torch.float32, device=device)
+    g = buf[:, :d]
+    g.normal_(generator=gen)
+    perm = torch.from_numpy(np.random.default_rng(seed).permutation(n)).to(device)
+    g.mul_((1.0 + 0.5 * perm.to(torch.float32) / n)[:, None])
+    return g
+
+
+def plant(torch, g, f, near):
+    """rows 0..f-1 := one vector (mean - 1.5 std of them, the attack); for every (a, b, eps) in `near`: row a := row b + eps * noise."""
+    if f:
+        head = g[:f]
+        vec = head.mean(dim=0) - 1.5 * head.var(dim=0, unbiased=False).sqrt()
+        g[:f] = vec
+    gen = torch.Generator(device=g.device).manual_seed(99)
+    for a, b, eps in near:
+        g[a] = g[b] + eps * torch.randn(g.shape[1], device=g.device, generator=gen)
+    return g
+
+
+def ceil4(x):
+    return -(-x // 4) * 4
+
+
+def column_bounds(d, world):
+    base, extra = divmod(d, world)
+    out, start = [], 0
+    for r in range(world):
+        stop = start + base + (1 if r < extra else 0)
+        out.append((start, stop))
+        start = stop
+    return out
+
+
+# ---- (a) the shares of a panel's Gram sum to the Gram, bitwise ------------------------------------------------------
+@pytest.mark.parametrize('n,d,mode', [
+    (3000, 3 * 8192 + 64, None),        # long K, many tiles: operands pre-split into fp16 x 2 planes (BENCH's arithmetic)
+    (3000, 3 * 8192 + 64, 'split'),     # the same through bf16 x 3 planes
+    (1000, 5000, None),                 # fused bf16 x 3 kernel, split-K
+    (256, 3001, None),                  # three tiles: fp32-input MFMA; ld % 4 != 0 -> register-staged loads
+    (130, 777, None),
+])
+@pytest.mark.parametrize('with_index', [False, True])
+def test_gram_shares_sum_to_the_gram(eng, torch, monkeypatch, n, d, mode, with_index):
+    if mode is None:
+        monkeypatch.delenv('BYZ_GRAM_MODE', raising=False)
+    else:
+        monkeypatch.setenv('BYZ_GRAM_MODE', mode)
+    device = torch.device('cuda', eng.device)
+    g = scaled(torch, n, d, 7000 + n, device)
+    full = eng.gram(g).clone()
+    eng.check()
+    panel, row_index = g, None
+    if with_index:
+        # an uneven all-gather: 3 ranks' rows padded to n_max each, the padding rows poisoned
+        rows_per = [n // 3 + (1 if r < n % 3 else 0) for r in range(3)]
+        rows_per[0] -= 5
+        rows_per[2] += 5
+        n_max = max(rows_per)
+        panel = torch.full((3 * n_max, d), float('nan'), dtype=torch.float32, device=device)
+        idx, at = [], 0
+        for r, cnt in enumerate(rows_per):
+            panel[r * n_max:r * n_max + cnt] = g[at:at + cnt]
+            idx.append(r * n_max + np.arange(cnt))
+            at += cnt
+        row_index = torch.from_numpy(np.concatenate(idx).astype(np.int32)).to(device)
+    for world in (2, 3, 8):
+        total = torch.zeros_like(full)
+        for share in range(world):
+            part = eng.gram_share(panel, row_index, world, share)
+            eng.check()
+            # a share is zero outside its tiles: at least (world - 1) / world of it at these sizes (whole tiles)
+            total.add_(part)
+        assert torch.equal(total, full), 'W=%d: max |sum of shares - gram| = %.3e' % (
+            world, float((total - full).abs().max()))
+    assert bool(torch.isfinite(full).all())
+
+
+# ---- (b) W ranks emulated one after the other ---------------------------------------------------------------------------
+def unsharded(eng, torch, g, n, f):
+    dist = torch.from_numpy(eng.pairwise_distances(g).numpy())
+    out, sel = eng.bulyan(g, n, f, return_selection=True)
+    idx = eng.krum(g, n, f, return_index=True)
+    return dist, out.cpu(), sel.cpu().numpy().tolist(), idx
+
+
+def check_against_unsharded(torch, want, got, label, g=None):
+    dist_w, out_w, sel_w, idx_w = want
+    dist_g, out_g, sel_g, idx_g = got
+    n = dist_w.shape[0]
+    off = ~torch.eye(n, dtype=torch.bool)
+    # identical rows: exact zeros on both sides, and bitwise identical distance rows (ties must survive sharding)
+    assert torch.equal(dist_g[off] == 0, dist_w[off] == 0), label
+    rel = ((dist_g - dist_w).abs() / dist_w.clamp_min(1e-30)).nan_to_num(0.0)
+    rel[~off] = 0.0
+    worst = int(rel.argmax())
+    wi, wj = worst // n, worst % n
+    truth = float('nan') if g is None else float((g[wi].double() - g[wj].double()).norm())
+    assert float(rel.max()) < 2e-6, '%s: distances differ by %.2e relative at (%d, %d): sharded %.9g, one GPU %.9g, fp64 %.9g' % (
+        label, float(rel.max()), wi, wj, float(dist_g[wi, wj]), float(dist_w[wi, wj]), truth)
+    assert idx_g == idx_w, label
+    assert sel_g == sel_w, '%s: selections differ first at pick %d' % (
+        label, next(i for i, (a, b) in enumerate(zip(sel_g, sel_w)) if a != b))
+    assert torch.allclose(out_g, out_w, rtol=1e-5, atol=1e-5), '%s: max |d| = %.3e' % (label, float((out_g - out_w).abs().max()))
+
+
+@pytest.mark.parametrize('n,d,world', [(1200, 24641, 3), (3000, 3 * 16400 + 1, 3), (640, 9000, 8)])
+def test_columns_layout_looped_over_the_shards_equals_one_gpu(eng, torch, n, d, world):
+    """columns layout, rank by rank: uneven slices (widths differ by one) with the 16-byte row pitch of
+    `reshard_rows_to_columns`, the Gram all-reduce as a sum on the device, the near-pair exchange as a sum of the per-slice
+    vectors (slot p must mean the same pair for every slice: the list order is canonical), selection, per-slice second stage."""
+    from attacking_federate_learning_amd.sharded import HipKernels
+    device = torch.device('cuda', eng.device)
+    f = int(n * MAL_PROP)
+    g = plant(torch, scaled(torch, n, d, 7100 + n, device, pitch=ceil4(d)), f,
+              [(f + 3, f + 2, 1e-4), (n - 1, n - 7, 3e-4)])
+    want = unsharded(eng, torch, g, n, f)
+    kern = HipKernels(eng)
+    slices = []
+    for lo, hi in column_bounds(d, world):
+        view = torch.empty((n, ceil4(hi - lo)), dtype=torch.float32, device=device)[:, :hi - lo]
+        view.copy_(g[:, lo:hi])
+        slices.append(view)
+    gram = None
+    for v in slices:
+        part = kern.gram(v)
+        gram = part if gram is None else gram.add_(part)
+    dist = eng.distances_from_gram(gram, n)
+    count = eng.near_pairs_count()
+    assert count >= 2 + (f - 1), 'the planted near-duplicate pairs and the identity proofs of the folded rows must be listed'
+    sq = None
+    for v in slices:
+        part = eng.near_pairs_sqdist(v, count)
+        sq = part if sq is None else sq.add_(part)
+    eng.near_pairs_apply(sq, dist)
+    idx = eng.krum_select(dist, n, f)
+    sel = eng.bulyan_select(dist, n, f, on_device=True)
+    out = torch.cat([kern.trimmed_mean(v, 2 * f, row_index=sel) for v in slices])
+    got = (torch.from_numpy(dist.numpy()), out.cpu(), sel.numpy().tolist(), idx)
+    check_against_unsharded(torch, want, got, 'columns W=%d' % world, g)
+
+
+@pytest.mark.parametrize('n,d,world,panel_cols', [(1200, 24640, 3, 8192), (3000, 2 * 16400, 2, 16400), (520, 6000, 8, 2048)])
+def test_clients_layout_looped_over_the_shards_equals_one_gpu(eng, torch, n, d, world, panel_cols):
+    """clients layout, rank by rank: uneven row shares gathered panel by panel into a padded (W n_max)-row buffer, every
+    rank's share of the panel's Gram tiles through the row indirection, all shares and panels summed (the all-reduce), the
+    near pairs re-evaluated over the panels, then the second stage through `reshard_rows_to_columns`' pitch-padded slices."""
+    from attacking_federate_learning_amd.sharded import HipKernels
+    device = torch.device('cuda', eng.device)
+    f = int(n * MAL_PROP)
+    g = plant(torch, scaled(torch, n, d, 7200 + n, device), f, [(f + 3, f + 2, 1e-4), (n - 1, n - 7, 3e-4)])
+    want = unsharded(eng, torch, g, n, f)
+    kern = HipKernels(eng)
+    rows_per = [n // world + (1 if r < n % world else 0) for r in range(world)]
+    rows_per[0] += 3
+    rows_per[-1] -= 3
+    n_max = max(rows_per)
+    starts = np.concatenate([[0], np.cumsum(rows_per)])
+    row_index = torch.from_numpy(np.concatenate(
+        [r * n_max + np.arange(rows_per[r]) for r in range(world)]).astype(np.int32)).to(device)
+    gram, panels = None, []
+    for lo in range(0, d, panel_cols):
+        width = min(panel_cols, d - lo)
+        panel = torch.full((world * n_max, width), float('nan'), dtype=torch.float32, device=device)
+        for r in range(world):
+            panel[r * n_max:r * n_max + rows_per[r]] = g[int(starts[r]):int(starts[r + 1]), lo:lo + width]
+        panels.append(panel)
+        for share in range(world):
+            part = kern.gram_share(panel, row_index, world, share)
+            gram = part if gram is None else gram.add_(part)
+    eng.check()
+    dist = eng.distances_from_gram(gram, n)
+    count = eng.near_pairs_count()
+    assert count >= 2 + (f - 1)
+    sq = None
+    for panel in panels:
+        part = eng.near_pairs_sqdist(panel, count, row_index=row_index)
+        sq = part if sq is None else sq.add_(part)
+    eng.near_pairs_apply(sq, dist)
+    idx = eng.krum_select(dist, n, f)
+    sel = eng.bulyan_select(dist, n, f)
+    # second stage: the selected rows as column slices in owner order, the caller's order through row_index
+    outs = []
+    owner = np.searchsorted(starts, sel, side='right') - 1
+    stacked = np.concatenate([sel[owner == r] for r in range(world)])
+    position = {int(row): k for k, row in enumerate(stacked)}
+    order = torch.from_numpy(np.asarray([position[int(row)] for row in sel], dtype=np.int32)).to(device)
+    picked = g[torch.from_numpy(stacked.astype(np.int64)).to(device)]
+    for lo, hi in column_bounds(d, world):
+        view = torch.empty((len(sel), ceil4(hi - lo)), dtype=torch.float32, device=device)[:, :hi - lo]
+        view.copy_(picked[:, lo:hi])
+        outs.append(kern.trimmed_mean(view, 2 * f, row_index=order))
+    got = (torch.from_numpy(dist.numpy()), torch.cat(outs).cpu(), [int(s) for s in sel], idx)
+    check_against_unsharded(torch, want, got, 'clients W=%d' % world, g)
+
+
+def test_pair_list_order_is_canonical(eng, torch):
+    """The multi-GPU paths add the ranks' per-pair vectors element by element: slot p must be the same pair on every GPU,
+    so the list is ordered (ascending i, then j) whatever order the waves ran in.  Twelve planted pairs, listed twice."""
+    device = torch.device('cuda', eng.device)
+    n, d = 700, 4096
+    near = [(40 + 50 * k, 15 + 50 * k, 1e-4 * (k + 1)) for k in range(12)]
+    g = plant(torch, scaled(torch, n, d, 7300, device), 0, near)
+    gram = eng.gram(g)
+    wants = sorted((a, b) if a > b else (b, a) for a, b, _ in near)
+    for _ in range(2):
+        dist = eng.distances_from_gram(gram, n)
+        count = eng.near_pairs_count()
+        assert count == len(near)
+        sq = eng.near_pairs_sqdist(g, count)
+        exact = torch.stack([((g[a] - g[b]).double() ** 2).sum() for a, b in wants])
+        assert torch.allclose(sq, exact, rtol=1e-12), 'slot p is not the p-th pair in (i, j) order'
+        eng.near_pairs_apply(sq, dist)
+        dd = torch.from_numpy(dist.numpy())
+        for (a, b), e in zip(wants, exact.cpu()):
+            assert abs(float(dd[a, b]) - float(e.sqrt())) <= 1e-6 * float(e.sqrt())
+
+
+# ---- (c) the orchestration itself over RCCL at world size 1 -------------------------------------------------------------
+def test_sharded_aggregator_over_rccl_at_world_size_one(eng):
+    """ShardedAggregator(HipKernels) with BYZ_FORCE_COLLECTIVES=1: every collective of both layouts is issued through RCCL
+    (all_reduce, all_gather_into_tensor, batch_isend_irecv as send-to-self, broadcast) and the results equal the unsharded
+    engine's.  Own process: torch.distributed state stays out of the test session."""
+    env = dict(os.environ, BYZ_FORCE_COLLECTIVES='1', MASTER_ADDR='127.0.0.1', MASTER_PORT='29533', RANK='0',
+               WORLD_SIZE='1', LOCAL_RANK='0', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    proc = subprocess.run([sys.executable, os.path.join(ROOT, 'tests', 'sharded_rccl_worker.py')], env=env,
+                          capture_output=True, text=True, timeout=600)
+    assert proc.returncode == 0, proc.stdout[-3000:] + proc.stderr[-3000:]
+    # (RCCL prints its banner through C stdio, which a pipe buffers until exit: the JSON line is not the last one)
+    report = json.loads([ln for ln in proc.stdout.splitlines() if ln.startswith('{')][-1])
+    assert report['ok'], report
+    for name in ('allreduce_gram', 'allreduce_near_pairs', 'allgather_row_tiles', 'allgather_output',
+                 'reshard_selected_rows', 'reshard_clients_to_columns', 'broadcast_row', 'allreduce_attack_stats'):
+        assert report['comm'].get(name, {}).get('calls', 0) >= 1, (name, report['comm'])

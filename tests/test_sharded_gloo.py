@@ -40,8 +40,31 @@ class OracleKernels:
                 position += 1
         return torch.from_numpy(out)
 
+    # ---- near-duplicate pairs: the same protocol as libbyzagg (gram.hip): distances_from_gram lists every pair i > j with
+    # d^2 < (c_ii + c_jj) / 16 in CANONICAL order (ascending i, then j -- a function of the all-reduced Gram alone, so
+    # slot p means the same pair on every rank), and POISONS their Gram-identity distances, so that a result is only right
+    # if the count -> per-rank sums of squared differences -> all-reduce -> apply path really ran across the ranks.
+    def __init__(self):
+        self.pairs = []
+
     def near_pairs_count(self):
-        return 0            # the fp64 stand-in resolves every pair through the Gram
+        return len(self.pairs)
+
+    def near_pairs_sqdist(self, panel, count, row_index=None):
+        rows = panel.numpy()
+        if row_index is not None:
+            rows = rows[np.asarray(row_index)]
+        assert count == len(self.pairs)
+        sq = np.zeros(count, dtype=np.float64)
+        for p, (i, j) in enumerate(self.pairs):
+            diff = (rows[i] - rows[j]).astype(np.float32).astype(np.float64)      # fp32 difference (defences.py:20)
+            sq[p] = float((diff * diff).sum())
+        return torch.from_numpy(sq)
+
+    def near_pairs_apply(self, sq, dist):
+        sq = sq.numpy()
+        for p, (i, j) in enumerate(self.pairs):
+            dist[i, j] = dist[j, i] = np.float32(np.sqrt(sq[p]))
 
     def distances_from_gram(self, gram, local_columns=None, all_reduce=None):
         c = gram.numpy()
@@ -50,6 +73,15 @@ class OracleKernels:
         d2 = np.minimum(d2, d2.T)
         d = np.sqrt(d2).astype(np.float32)
         np.fill_diagonal(d, np.inf)
+        n = len(d)
+        self.pairs = [(i, j) for i in range(n) for j in range(i) if d2[i, j] < (sq[i] + sq[j]) / 16.0]
+        for i, j in self.pairs:
+            d[i, j] = d[j, i] = np.nan
+        if local_columns is not None and self.pairs:
+            part = self.near_pairs_sqdist(local_columns, len(self.pairs))
+            if all_reduce is not None:
+                all_reduce(part)
+            self.near_pairs_apply(part, d)
         return d
 
     def krum_select(self, d, users_count, corrupted_count):
@@ -83,6 +115,10 @@ def make_matrix(n, d, f, seed=5):
     rng = np.random.default_rng(seed)
     g = rng.standard_normal((n, d)).astype(np.float32)
     g *= (1.0 + 0.5 * rng.permutation(n) / n).astype(np.float32)[:, None]
+    # two honest clients that nearly coincide with two others (beyond the malicious rows 0..f-1): pairs the Gram identity
+    # cannot resolve, which the ranks re-evaluate on the difference itself and sum through the small all-reduce
+    g[7] = g[6] + np.float32(1e-3) * rng.standard_normal(d).astype(np.float32)
+    g[11] = g[10] + np.float32(2e-3) * rng.standard_normal(d).astype(np.float32)
     return g
 
 
@@ -166,6 +202,9 @@ def test_ranks_equal_the_unsharded_oracle(world, n, d, f):
         if world > 1:
             assert r['comm']['allgather_row_tiles']['calls'] >= 2 and r['comm']['allgather_row_tiles']['bytes'] > 0
             assert 'reshard_selected_rows' in r['comm'] and 'allreduce_gram' in r['comm']
+            # the near-duplicate pairs (two planted ones + the attack's identical rows) went through the exchange, in both
+            # layouts (the stub poisons their Gram-identity distances: the results above are right only if they did)
+            assert r['comm']['allreduce_near_pairs']['calls'] >= 2
 
 
 def test_column_slices_cover_everything():
