@@ -253,6 +253,9 @@ int64_t trimmed_mean_max_rows();
 // window_rows.hip: the row-split ring selection (first stage of the trimmed mean)
 int launch_window_rows(byz_ctx* ctx, const float* G, int64_t n_rows, int64_t n_cols, int64_t ld, const int32_t* row_index,
                        int64_t keep, float* out, int32_t* redo, hipStream_t stream);
+// window_lean.hip: the instruction-lean form of the row-split ring selection (round 3)
+int launch_window_lean(byz_ctx* ctx, const float* G, int64_t n_rows, int64_t n_cols, int64_t ld, const int32_t* row_index,
+                       int64_t keep, float* out, int32_t* redo, hipStream_t stream);
 int64_t select_max_rows();
 
 int launch_lane_selftest(byz_ctx* ctx, int32_t* out, int32_t* n_patterns, hipStream_t stream);

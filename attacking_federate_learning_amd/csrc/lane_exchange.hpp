@@ -20,7 +20,10 @@ __device__ __forceinline__ float lane_xor(float v, int mask, int lane) {
         case 7: r = __builtin_amdgcn_update_dpp(0, b, 0x141, 0xF, 0xF, true); break;  // row_half_mirror
         case 8: r = __builtin_amdgcn_update_dpp(0, b, 0x128, 0xF, 0xF, true); break;  // row_ror:8
         case 15: r = __builtin_amdgcn_update_dpp(0, b, 0x140, 0xF, 0xF, true); break; // row_mirror
-        case 4: r = __builtin_amdgcn_ds_swizzle(b, 0x101F); break;                     // xor 4
+        case 4:   // xor 4 inside a 16-lane row without the LDS pipe: banks 0, 2 take lane + 4, banks 1, 3 lane - 4
+            r = __builtin_amdgcn_update_dpp(0, b, 0x104, 0xF, 0x5, false);             // row_shl:4
+            r = __builtin_amdgcn_update_dpp(r, b, 0x114, 0xF, 0xA, false);             // row_shr:4
+            break;
         case 16: r = __builtin_amdgcn_ds_swizzle(b, 0x401F); break;                    // xor 16
         case 31: r = __builtin_amdgcn_ds_swizzle(b, 0x7C1F); break;                    // xor 31
         default: r = __builtin_amdgcn_ds_bpermute((lane ^ mask) << 2, b); break;       // 32, 63

@@ -1256,7 +1256,11 @@ int launch_ring(byz_ctx* ctx, const float* G, int64_t n_rows, int64_t n_cols, in
     // 8.5 vs 9.1 ms at 2080 rows x 2^20, 12.5 vs 16.3 ms at 5200 rows x 2^19); 1 -> always; 0 -> never
     const char* e = std::getenv("BYZ_TM_ROWS");
     int rc = BYZ_E_UNSUPPORTED;
-    if (e ? std::atoi(e) != 0 : n_rows > 1024)
+    // BYZ_TM_LEAN (default 1): window_lean.hip, round 3's form of the row-split kernel, for every height it covers
+    const char* lean_env = std::getenv("BYZ_TM_LEAN");
+    if (lean_env == nullptr || std::atoi(lean_env) != 0)
+        rc = launch_window_lean(ctx, G, n_rows, n_cols, ld, row_index, keep, out, redo, stream);
+    if (rc == BYZ_E_UNSUPPORTED && (e ? std::atoi(e) != 0 : n_rows > 1024))
         rc = launch_window_rows(ctx, G, n_rows, n_cols, ld, row_index, keep, out, redo, stream);
     if (rc == BYZ_E_UNSUPPORTED) {
         if constexpr (NC == 4 && WAVES == 4 && RPL >= 4) {

@@ -12,7 +12,7 @@ DEFAULT_SETS=("SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES 
 if [ -n "${SETS:-}" ]; then IFS=';' read -ra USE <<< "$SETS"; else USE=("${DEFAULT_SETS[@]}"); fi
 for set in "${USE[@]}"; do
   i=$((i+1))
-  timeout 600 rocprofv3 --pmc $set --kernel-trace -d $OUT/pmc$i -o p --output-format csv -- python $GRAFT_REPO_ROOT/scripts/run_one.py "$@" > $OUT/pmc$i.log 2>&1
+  timeout 600 rocprofv3 --pmc $set --kernel-trace -d $OUT/pmc$i -o p --output-format csv -- python $GRAFT_REPO_ROOT/scripts/${RUNNER:-run_one.py} "$@" > $OUT/pmc$i.log 2>&1
   f=$(find $OUT/pmc$i -name '*counter_collection.csv' | head -1)
   python3 - "$f" <<'PY'
 import csv, sys, collections
