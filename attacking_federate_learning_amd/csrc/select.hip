@@ -330,92 +330,25 @@ __device__ __forceinline__ bool gather_granule_pair(const unsigned long long* sl
     return true;
 }
 
-// The reference's score of row u at this pick (defences.py:33-34): ascending live distances, sequential fp32 sum of
-// the first `take`.  One wave; the result is wave-uniform.  Adding +0.0 for a skipped entry is exact.
-// The row's ascending values and their columns come from the tables row_sort_kernel wrote (two coalesced loads per 64
-// entries, the next 64 already in flight); the left-to-right sum runs as a DPP chain: s[l] = s[l - 1] + x[l] issued 63
-// times fixes lane l at step l, one VALU instruction per element instead of a readlane + add pair.
-__device__ __forceinline__ float reference_score(const float* __restrict__ sorted_val, const uint16_t* __restrict__ sorted_idx,
-                                                 const uint32_t* removed, int n, int u, int take, int lane) {
-    constexpr int kDepth = 8;   // 64-entry chunks loaded per batch: the tables are not cache resident, one load latency per batch
-    const uint16_t* order = sorted_idx + static_cast<int64_t>(u) * n;
-    const float* vals = sorted_val + static_cast<int64_t>(u) * n;
-    float carry = 0.0f;
-    int got = 0;
-    int col_next[kDepth];
-    float v_next[kDepth];
-    auto fetch = [&](int r0) __attribute__((always_inline)) {
-#pragma unroll
-        for (int k = 0; k < kDepth; ++k) {
-            const int r = r0 + 64 * k + lane;
-            col_next[k] = r < n ? order[r] : u;     // a row's own column marks "not an entry"
-            v_next[k] = r < n ? vals[r] : 0.0f;
-        }
-    };
-    fetch(0);
-    for (int r0 = 0; r0 < n && got < take; r0 += 64 * kDepth) {
-        int col[kDepth];
-        float v[kDepth];
-#pragma unroll
-        for (int k = 0; k < kDepth; ++k) {
-            col[k] = col_next[k];
-            v[k] = v_next[k];
-        }
-        if (r0 + 64 * kDepth < n) fetch(r0 + 64 * kDepth);
-#pragma unroll
-        for (int k = 0; k < kDepth; ++k) {
-            if (got >= take) break;     // wave-uniform
-            const bool live = col[k] != u && !((removed[col[k] >> 5] >> (col[k] & 31)) & 1u);
-            const unsigned long long m = __ballot(live);
-            if (m == 0ull) continue;
-            const int before = __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(m >> 32),
-                                                         __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(m), 0));
-            const float x = (live && got + before < take) ? v[k] : 0.0f;   // past the prefix the reference sums: + 0.0
-            got += __popcll(m);
-            // Fast path.  While the running sum stays inside one binade [2^E, 2^(E+1)) it is a multiple of q = ulp(2^E),
-            // and adding x rounds to the nearest multiple of q: fl(s + x) = s + q rn(x / q) unless x / q lies exactly
-            // half way (then the parity of s decides).  So a chunk without such a tie and without a binade crossing
-            // adds q * sum(rn(x_l / q)) -- integers, any order.  Everything else takes the sequential chain below.
-            {
-                const int eb = static_cast<int>((__float_as_uint(carry) >> 23) & 0xffu);
-                if (eb >= 40 && eb <= 220) {
-                    const float invq = __uint_as_float(static_cast<uint32_t>(277 - eb) << 23);   // 2^(23 - E)
-                    const float qf = __uint_as_float(static_cast<uint32_t>(eb - 23) << 23);       // 2^(E - 23)
-                    const float t = x * invq;                                                     // exact
-                    const float r = __builtin_rintf(t);
-                    const bool odd_one = !(t < 16777216.0f) || __builtin_fabsf(t - r) == 0.5f;
-                    if (__ballot(odd_one) == 0ull) {
-                        const int total = wave_sum_int(static_cast<int>(r));                      // < 2^30
-                        const int base = static_cast<int>(carry * invq);                          // [2^23, 2^24)
-                        if (total < (1 << 24) && base + total < (1 << 24)) {
-                            carry = __fadd_rn(carry, static_cast<float>(total) * qf);             // every step exact
-                            continue;
-                        }
-                    }
-                }
-            }
-            float s = __fadd_rn(carry, x);          // lane 0 is final
-            // lanes whose source lane does not exist (lane 0) keep their value; 2 wait states between a VALU write and
-            // a DPP read of the same register
-#pragma unroll
-            for (int l = 1; l < 64; ++l)
-                asm volatile("s_nop 1\n\tv_add_f32_dpp %0, %0, %1 wave_shr:1 row_mask:0xf bank_mask:0xf" : "+v"(s) : "v"(x));
-            carry = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(s), 63));
-        }
-    }
-    return carry;
-}
-
-// The same score as a PLAIN dependent chain of fp32 additions (round 2, late; BYZ_BULYAN_RESCORE=plain, not the default yet).
-// What three experiments on the re-score say (profiles/r02q_*, r02r_*, r02s_*, r02t_*): 512 entries per integer reduction,
-// ties summed by an exact parity rule with everything independent of the sum hoisted out of the chain, and this literal
-// chain all give the SAME selections and the SAME ~2.5 us per 512 entries as reference_score -- so the time is not the
-// arithmetic, it is the table entries: reference_score asks for a batch one batch ahead (and its conditional loads make
-// hipcc wait for them early), ~2.5 us of HBM latency per batch that nothing overlaps.  Here the entries of FOUR batches are
-// in flight (unconditional loads at clamped positions; what lies past the row is masked when it is used), the entries of a
-// batch (zeros for removed columns and past the prefix) go to LDS in order, and every lane of the wave adds them up left to
-// right from broadcast reads -- the reference's loop, literally.  Measured with ONE batch in flight: identical selections
-// on four matrices up to N = 10,000, 255 vs 262 ms; the four-deep ring is unmeasured.
+// The reference's score of row u at this pick (defences.py:33-34): ascending live distances, sequential fp32 sum of the
+// first `take`, as a PLAIN dependent chain of fp32 additions.  One wave; the result is wave-uniform.  The row's ascending
+// values and their columns come from the tables row_sort_kernel wrote; the entries of FOUR batches of 512 are in flight
+// (unconditional loads at clamped positions; what lies past the row is masked when it is used), the entries of a batch
+// (zeros for removed columns and past the prefix: adding +0.0 is exact) go to LDS in order, and every lane of the wave adds
+// them up left to right from broadcast reads -- the reference's loop, literally.
+//
+// Two cleverer forms were built and measured against this one, selections identical in every case (profiles/r02q .. r02t,
+// profiles/r03a, r03k): round 2's integer rule per 64 entries (while the running sum stays inside one binade it is a
+// multiple of q = ulp and fl(s + x) = s + q rn(x / q) barring exact ties, so a chunk adds q * sum(rn(x_i / q)) in any
+// order; everything else ran as a 63-step DPP chain), and round 3's version of it per 512 entries with a checkpoint behind
+// every row's first 512 entries (invalidated when a removed winner ranks inside that prefix).  At N = 10,000 they take
+// 260 / 254 / 234 ms against this form's 253; at N = 4000 40.6 / -- / 41.6 against 36.7.  Round 3's counters say why the
+// arithmetic does not matter: a 7600-entry re-score is ~76,000 cycles of ONE wave alone on its SIMD, of which ~2000 per
+// 512 entries go into loading the entries and testing their columns against the `removed` bitmap, ~1100 into a clean
+// integer batch, and ~5000 into each of the six batches per chain that hold a tie or a binade crossing -- dependent
+// instructions at ten or more cycles apiece whatever they compute.  What would help is several waves per contender (the
+// liveness step of later batches while the sum runs over earlier ones); that restructuring is not done.  Both forms were
+// removed again; this one is the only re-score.
 __device__ __forceinline__ float reference_score_plain(const float* __restrict__ sorted_val, const uint16_t* __restrict__ sorted_idx,
                                                        const uint32_t* removed, int n, int u, int take, int lane,
                                                        float* __restrict__ stage) {
@@ -502,7 +435,7 @@ __global__ __launch_bounds__(kGridThreads) void bulyan_grid_kernel(
     const float* __restrict__ dist, int n, int theta, int drop, int users_count, int corrupted,
     const uint16_t* __restrict__ sorted_idx, const uint16_t* __restrict__ rank_t, const float* __restrict__ sorted_val,
     const double* __restrict__ row_total, const double* __restrict__ row_top, const int32_t* __restrict__ cls,
-    unsigned long long* __restrict__ xchg, float band_scale, int rescore_plain, int32_t* __restrict__ selection,
+    unsigned long long* __restrict__ xchg, float band_scale, int32_t* __restrict__ selection,
     int32_t* __restrict__ status, int32_t* __restrict__ rescored) {
     __shared__ __attribute__((aligned(16))) float rescore_stage[kGridThreads / 64][512];
     __shared__ Candidate slots[kGridThreads / 64];
@@ -642,9 +575,7 @@ __global__ __launch_bounds__(kGridThreads) void bulyan_grid_kernel(
             Candidate r{static_cast<double>(kKrumInit), 0x7fffffff, -1};
             for (int k = wave; k < n_lead; k += kGridThreads / 64) {
                 const int row = wg * kGridThreads + leaders[k];
-                const float s32 = rescore_plain
-                    ? reference_score_plain(sorted_val, sorted_idx, removed, n, row, take, lane, rescore_stage[wave])
-                    : reference_score(sorted_val, sorted_idx, removed, n, row, take, lane);
+                const float s32 = reference_score_plain(sorted_val, sorted_idx, removed, n, row, take, lane, rescore_stage[wave]);
                 if (s32 < kKrumInit) {
                     Candidate o{static_cast<double>(s32), visit_position(row), row};
                     if (better(o, r)) r = o;
@@ -783,12 +714,6 @@ int launch_bulyan_loop(byz_ctx* ctx, const float* dist, int64_t n, int64_t theta
     if (const char* e = std::getenv("BYZ_BULYAN_BAND")) {
         if (std::strcmp(e, "rigorous") != 0) band_scale = static_cast<float>(std::atof(e));
     }
-    // The re-score is a literal chain of fp32 additions with four batches of table entries in flight
-    // (reference_score_plain).  Measured in round 3 against the integer-path form of round 2 (BYZ_BULYAN_RESCORE=v1, kept
-    // for the comparison): identical selections, 36.8 vs 40.5 ms at N = 4000, 253 vs 260 ms at N = 10,000
-    // (profiles/r03a_optin_variants_probe.txt).
-    int rescore_plain = 1;
-    if (const char* e = std::getenv("BYZ_BULYAN_RESCORE")) rescore_plain = std::strcmp(e, "v1") == 0 ? 0 : 1;
     BYZ_HIP(hipMemsetAsync(ctx->xchg.ptr, 0, static_cast<size_t>(2 * 3 * kGridMaxWgs) * sizeof(unsigned long long), stream));
     BYZ_HIP(hipMemsetAsync(status_dev, 0, 2 * sizeof(int32_t), stream));
     KernelTimer t(ctx, BYZ_K_BULYAN_LOOP, stream);
@@ -800,7 +725,7 @@ int launch_bulyan_loop(byz_ctx* ctx, const float* dist, int64_t n, int64_t theta
     bulyan_grid_kernel<<<n_wgs, kGridThreads, 0, stream>>>(
         dist, (int)n, (int)theta, (int)drop_count, (int)users_count, (int)corrupted, ctx->sorted_idx.as<uint16_t>(),
         ctx->rank_t.as<uint16_t>(), ctx->sorted_val.as<float>(), ctx->row_total.as<double>(), ctx->row_top.as<double>(), cls,
-        ctx->xchg.as<unsigned long long>(), band_scale, rescore_plain, selection_dev, status_dev, status_dev + 1);
+        ctx->xchg.as<unsigned long long>(), band_scale, selection_dev, status_dev, status_dev + 1);
     return check_launch("bulyan_grid_kernel");
 }
 

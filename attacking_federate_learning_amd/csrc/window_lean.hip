@@ -163,7 +163,7 @@ __global__ __launch_bounds__(64 * W, 4) void window_lean_kernel(const float* __r
     __shared__ uint32_t tops[T];
     __shared__ uint32_t minmax[2 * kTileCols];
     __shared__ ColumnPlan plan[kTileCols];
-    __shared__ float part_sum[W * 4 * kTileCols];
+    __shared__ float part_sum[W * kTileCols];
     __shared__ float colres[kTileCols];
     __shared__ int flags[2];   // [0] non-finite input seen, [1] the tile is not resolved here
 
@@ -483,8 +483,14 @@ __global__ __launch_bounds__(64 * W, 4) void window_lean_kernel(const float* __r
                 top[2 * ep] += hit0 ? 1 : 0;
                 top[2 * ep + 1] += hit1 ? 1 : 0;
             }
-            acc[2 * ep] = row_quad_sum(acc[2 * ep]);
-            acc[2 * ep + 1] = row_quad_sum(acc[2 * ep + 1]);
+            // one partial per wave and column, in a fixed order: inside the 16-lane row, then across the four rows
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                float a = row_quad_sum(acc[2 * ep + h]);
+                a = __fadd_rn(a, lane_xor(a, 16, lane));
+                a = __fadd_rn(a, lane_xor(a, 32, lane));
+                acc[2 * ep + h] = a;
+            }
         }
         bool overflow = false;
         uint32_t packed = 0u;
@@ -498,10 +504,9 @@ __global__ __launch_bounds__(64 * W, 4) void window_lean_kernel(const float* __r
             flags[1] = 1;
             atomicAdd(&g_lean_reasons[6], 1u);
         }
-        if ((rr & 3) == 0) {
-            const int slot = (wave * 4 + (rr >> 2)) * kTileCols + 4 * q;
+        if (rr == 0) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) part_sum[slot + e] = acc[e];
+            for (int e = 0; e < 4; ++e) part_sum[wave * kTileCols + 4 * q + e] = acc[e];
         }
     }
     __syncthreads();
@@ -622,7 +627,7 @@ __global__ __launch_bounds__(64 * W, 4) void window_lean_kernel(const float* __r
                 const int n_within = wave_sum_i(within);
                 float sum = wave_sum_f(part, lane);
                 // ... plus the decided-in rings, summed by sweep B: the partials in a fixed order
-                for (int p = 0; p < W * 4; ++p) sum = __fadd_rn(sum, part_sum[p * kTileCols + c]);
+                for (int p = 0; p < W; ++p) sum = __fadd_rn(sum, part_sum[p * kTileCols + c]);
                 if (lane == 0) {
                     if (n_within != need[k] || !(thr == thr)) {
                         flags[1] = 1;
