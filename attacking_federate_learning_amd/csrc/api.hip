@@ -181,6 +181,7 @@ void byz_ctx_destroy(byz_ctx* ctx) {
     ctx->gram_tickets.release();
     ctx->gram_planes.release();
     ctx->plane_order.release();
+    ctx->split_redo.release();
     ctx->plane_unscale.release();
     ctx->dup_rep.release();
     ctx->row_signature.release();

@@ -102,6 +102,7 @@ struct byz_ctx {
     byz::Buffer gram_planes;     // pre-split Gram: the bf16 planes of one super-chunk of columns, in MFMA fragment order
     byz::Buffer plane_unscale;   // pre-split Gram, f16x2: 2^-shift of every (chunk, row) of the super-chunk (fp64)
     byz::Buffer plane_order;     // pre-split Gram: (256-row block, 128-row block) of every workgroup tile
+    byz::Buffer split_redo;      // pre-split Gram: (chunk, row block) pairs whose sampled scale did not hold (count first)
     std::vector<int32_t> plane_order_host;
     int64_t plane_order_T = -1;
     int64_t plane_order_share = 1 * 65536 + 0;

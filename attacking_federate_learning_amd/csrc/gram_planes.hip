@@ -149,13 +149,16 @@ __global__ __launch_bounds__(256) void plane_split_bf16_kernel(const float* __re
 __global__ __launch_bounds__(256) void plane_split_f16_kernel(const float* __restrict__ G, int64_t n_rows, int64_t n_cols,
                                                               int64_t ld, const int32_t* __restrict__ row_index, int64_t k0,
                                                               int64_t n_steps, u32x4* __restrict__ planes,
-                                                              double* __restrict__ unscale, int64_t rows_pad) {
+                                                              double* __restrict__ unscale, int64_t rows_pad,
+                                                              const int32_t* __restrict__ redo) {
     __shared__ __attribute__((aligned(16))) float tile[32][kSplitCols + 4];
     __shared__ float row_scale[32];
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
-    const int64_t rb = blockIdx.y;
-    const int64_t chunk = blockIdx.x;
+    // redo != nullptr: the (chunk, row block) pairs the streaming kernel listed (redo[0] of them), one per workgroup
+    if (redo != nullptr && static_cast<int>(blockIdx.x) >= redo[0]) return;
+    const int64_t rb = redo != nullptr ? redo[2 + 2 * blockIdx.x] : blockIdx.y;
+    const int64_t chunk = redo != nullptr ? redo[1 + 2 * blockIdx.x] : blockIdx.x;
     const int r = tid >> 3, c = tid & 7;
     int64_t row = rb * 32 + r;
     if (row > n_rows - 1) row = n_rows - 1;
@@ -218,6 +221,127 @@ __global__ __launch_bounds__(256) void plane_split_f16_kernel(const float* __res
             out[64] = m;
         }
         __syncthreads();
+    }
+}
+
+// f16x2 in ONE pass over G (round 3).  The two-pass kernel above reads every element twice -- once for the row's largest
+// magnitude over the chunk, once to split -- and the second read does not come out of L2 (the resident workgroups hold far
+// more than 4 MiB of 1 MiB blocks): 320 GB read + 164 GB written per 160 GB of G, at copy speed.
+// The scale does not have to put the chunk's largest magnitude into [2^14, 2^15): fp16 rounding is invariant under a power
+// of two as long as nothing overflows and the large elements' low plane stays normal, i.e. as long as
+//     2^7 <= (largest magnitude) * 2^shift < 2^16.
+// So the shift comes from a SAMPLE of the row's chunk (16 groups of 8 columns, every 512 columns: 512 of its 32,768 bytes)
+// placed at [2^9, 2^10) -- six binades of head room above, two below -- the chunk is then split as it streams by, and the
+// true largest magnitude, which falls out of the same pass, says whether the assumption held.  Where it did not (an outlier
+// 64 times the sampled maximum, a chunk whose sampled columns are all zero, inf / NaN) the (row block, chunk) goes on a
+// list and the two-pass kernel redoes exactly those.  For every other block the planes are bit for bit what the exact
+// scale would give, scaled by a power of two that `unscale` undoes.
+constexpr int kSampleGroups = 16;
+__global__ __launch_bounds__(256) void plane_split_f16_stream_kernel(const float* __restrict__ G, int64_t n_rows, int64_t n_cols,
+                                                                     int64_t ld, const int32_t* __restrict__ row_index, int64_t k0,
+                                                                     int64_t n_steps, u32x4* __restrict__ planes,
+                                                                     double* __restrict__ unscale, int64_t rows_pad,
+                                                                     int32_t* __restrict__ redo) {
+    __shared__ __attribute__((aligned(16))) float tile[2][32][kSplitCols + 4];
+    __shared__ float row_scale[32];
+    __shared__ int block_bad;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int64_t rb = blockIdx.y;
+    const int64_t chunk = blockIdx.x;
+    const int r = tid >> 3, c = tid & 7;
+    int64_t row = rb * 32 + r;
+    if (row > n_rows - 1) row = n_rows - 1;
+    if (row_index != nullptr) row = row_index[row];
+    const float* src = G + row * ld;
+    const int64_t kbeg = k0 + chunk * kChunkCols;
+    if (tid == 0) block_bad = 0;
+    // ---- the sample: thread c of the row's eight takes groups 2 c and 2 c + 1 (eight columns each)
+    int shift = 0;
+    {
+        float mx = 0.0f;
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+            const int64_t k = kbeg + (2 * c + g) * (kChunkCols / kSampleGroups);
+            const f32x4 a = load4_tail(src, k, n_cols), b = load4_tail(src, k + 4, n_cols);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) mx = __builtin_fmaxf(mx, __builtin_fmaxf(__builtin_fabsf(a[e]), __builtin_fabsf(b[e])));
+        }
+#pragma unroll
+        for (int msk = 1; msk < 8; msk <<= 1) mx = __builtin_fmaxf(mx, __shfl_xor(mx, msk, 64));
+        // (NaN never wins an fmax and inf gives an out-of-range exponent: both are caught by the streaming pass)
+        if (mx >= 1.17549435e-38f && mx <= 3.0e38f) {
+            shift = 9 - (static_cast<int>((__float_as_uint(mx) >> 23) & 0xffu) - 127);   // mx 2^shift in [2^9, 2^10)
+            if (shift > 126) shift = 126;
+            if (shift < -126) shift = -126;
+        }
+        if (c == 0) row_scale[r] = __uint_as_float(static_cast<uint32_t>(shift + 127) << 23);
+    }
+    // ---- the stream: sub-block s + 1 is in flight while sub-block s is transposed through LDS and split
+    const int64_t step_base = chunk * kChunkSteps;
+    const float scale = __uint_as_float(static_cast<uint32_t>(shift + 127) << 23);
+    float true_max = 0.0f;
+    bool bad = false;
+    f32x4 cur[4], nxt[4];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) cur[p] = load4_tail(src, k0 + step_base * 16 + 4 * c + 32 * p, n_cols);
+    __syncthreads();   // row_scale
+    for (int sub = 0; sub < kChunkCols / kSplitCols; ++sub) {
+        const int64_t step0 = step_base + sub * (kSplitCols / 16);
+        if (step0 >= n_steps) break;   // uniform
+        const bool more = sub + 1 < kChunkCols / kSplitCols && step0 + kSplitCols / 16 < n_steps;
+        if (more) {
+#pragma unroll
+            for (int p = 0; p < 4; ++p) nxt[p] = load4_tail(src, k0 + (step0 + kSplitCols / 16) * 16 + 4 * c + 32 * p, n_cols);
+        }
+        float (*t)[kSplitCols + 4] = tile[sub & 1];
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            *reinterpret_cast<f32x4*>(&t[r][4 * c + 32 * p]) = cur[p];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float a = __builtin_fabsf(cur[p][e]);
+                bad = bad || !(a <= 3.0e38f);
+                true_max = __builtin_fmaxf(true_max, a);
+            }
+        }
+        __syncthreads();   // one barrier per sub-block: the other tile is free again once everybody has passed this one
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int sl = 2 * wave + i;
+            const int64_t step = step0 + sl;
+            if (step >= n_steps) continue;
+            const int frow = lane & 31, kk = sl * 16 + 8 * (lane >> 5);
+            const f32x4 lo4 = *reinterpret_cast<const f32x4*>(&t[frow][kk]);
+            const f32x4 hi4 = *reinterpret_cast<const f32x4*>(&t[frow][kk + 4]);
+            u32x4 h, m;
+            split_f16x2(lo4, hi4, row_scale[frow], h, m);
+            u32x4* out = planes + ((rb * n_steps + step) * 2) * 64 + lane;
+            out[0] = h;
+            out[64] = m;
+        }
+        if (more) {
+#pragma unroll
+            for (int p = 0; p < 4; ++p) cur[p] = nxt[p];
+        }
+    }
+    // ---- did the sampled scale hold?  2^7 <= max 2^shift < 2^16 (an all-zero chunk holds with any scale)
+#pragma unroll
+    for (int msk = 1; msk < 8; msk <<= 1) {
+        true_max = __builtin_fmaxf(true_max, __shfl_xor(true_max, msk, 64));
+        bad = bad || (__shfl_xor(bad ? 1 : 0, msk, 64) != 0);
+    }
+    const float scaled = true_max * scale;
+    const bool holds = !bad && (true_max == 0.0f || (scaled >= 128.0f && scaled < 65536.0f));
+    if (c == 0) {
+        unscale[chunk * rows_pad + rb * 32 + r] = __longlong_as_double(static_cast<long long>(1023 - shift) << 52);
+        if (!holds) block_bad = 1;
+    }
+    __syncthreads();
+    if (tid == 0 && block_bad != 0) {
+        const int at = atomicAdd(redo, 1);
+        redo[1 + 2 * at] = static_cast<int32_t>(chunk);
+        redo[2 + 2 * at] = static_cast<int32_t>(rb);
     }
 }
 
@@ -592,8 +716,33 @@ int launch_gram_planes(byz_ctx* ctx, const float* G, int64_t n_rows, int64_t n_c
             KernelTimer t(ctx, BYZ_K_PLANE_SPLIT, stream);
             if (f16) {
                 const dim3 grid(static_cast<unsigned>(n_chunks), static_cast<unsigned>(rows_pad / 32));
-                plane_split_f16_kernel<<<grid, 256, 0, stream>>>(G, n_rows, n_cols, ld, row_index, k0, n_steps, planes,
-                                                                 unscale, rows_pad);
+                if (env_int("BYZ_GRAM_SPLIT_TWO_PASS", 0) != 0) {   // round 2's kernel for everything (the comparison)
+                    plane_split_f16_kernel<<<grid, 256, 0, stream>>>(G, n_rows, n_cols, ld, row_index, k0, n_steps, planes,
+                                                                     unscale, rows_pad, nullptr);
+                } else {
+                    // one pass with a sampled scale; the blocks where it did not hold are listed and redone exactly
+                    const int64_t pairs = n_chunks * (rows_pad / 32);
+                    BYZ_TRY(ctx->split_redo.ensure(static_cast<size_t>(1 + 2 * pairs) * sizeof(int32_t)));
+                    int32_t* redo = ctx->split_redo.as<int32_t>();
+                    BYZ_HIP(hipMemsetAsync(redo, 0, sizeof(int32_t), stream));
+                    plane_split_f16_stream_kernel<<<grid, 256, 0, stream>>>(G, n_rows, n_cols, ld, row_index, k0, n_steps, planes,
+                                                                            unscale, rows_pad, redo);
+                    BYZ_TRY(check_launch("plane_split_f16_stream_kernel"));
+                    // (sized for a few thousand listed blocks; the surplus workgroups leave at once.  More than that --
+                    // pathological data -- and the whole super-chunk is simply redone by the two-pass kernel.)
+                    const int64_t fix = pairs < 4096 ? pairs : 4096;
+                    plane_split_f16_kernel<<<static_cast<unsigned>(fix), 256, 0, stream>>>(G, n_rows, n_cols, ld, row_index, k0,
+                                                                                           n_steps, planes, unscale, rows_pad, redo);
+                    if (pairs > fix) {
+                        BYZ_TRY(check_launch("plane_split_f16_kernel<redo>"));
+                        int32_t listed = 0;
+                        BYZ_HIP(hipMemcpyAsync(&listed, redo, sizeof(int32_t), hipMemcpyDeviceToHost, stream));
+                        BYZ_HIP(hipStreamSynchronize(stream));
+                        if (listed > fix)
+                            plane_split_f16_kernel<<<grid, 256, 0, stream>>>(G, n_rows, n_cols, ld, row_index, k0, n_steps, planes,
+                                                                             unscale, rows_pad, nullptr);
+                    }
+                }
             } else {
                 const dim3 grid(static_cast<unsigned>(ceil_div(n_steps, kSplitCols / 16)), static_cast<unsigned>(rows_pad / 32));
                 plane_split_bf16_kernel<<<grid, 256, 0, stream>>>(G, n_rows, n_cols, ld, row_index, k0, n_steps, planes);
