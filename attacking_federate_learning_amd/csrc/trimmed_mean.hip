@@ -37,7 +37,7 @@ namespace {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
 
-constexpr int kGeneralMaxRows = 8192;
+constexpr int kGeneralMaxRows = 16384;   // = the selection kernels' limit: defend['TrimmedMean'] then serves every N that Krum / Bulyan do
 
 using namespace lanes;
 
@@ -157,42 +157,50 @@ __device__ __forceinline__ void window_mean(const Sorted& sorted, const WindowAr
     }
 }
 
-// ---- general kernel: LDS bitonic over [rank][4 columns] ------------------------------------------
-struct QuadArray {
-    const f32x4* base;
-    __device__ __forceinline__ f32x4 at(int rank) const { return base[rank]; }
+// ---- general kernel: LDS bitonic over [rank][V columns] ------------------------------------------
+// V = 4 columns per pass up to 8192 rows (128 KiB of LDS); V = 2 up to 16,384 rows (round 3: the reference has no row limit,
+// defences.py:44-52, and configs[4]'s N = 10,000 client matrix used to come back BYZ_E_UNSUPPORTED).  A column of more
+// than 5376 rows is not a case any BASELINE configuration times: this path is about being there, not about speed.
+template <int V>
+struct ColumnArray {
+    typedef float vec_t __attribute__((ext_vector_type(V)));
+    const vec_t* base;
+    __device__ __forceinline__ f32x4 at(int rank) const {
+        const vec_t v = base[rank];
+        if constexpr (V == 4) return f32x4{v[0], v[1], v[2], v[3]};
+        else return f32x4{v[0], v[1], v[0], v[1]};   // (columns 2, 3 of the quad are never written: see n_cols below)
+    }
 };
 
+template <int V>
 __global__ __launch_bounds__(1024) void trimmed_mean_lds_kernel(const float* __restrict__ G, int n_rows, int n_pad,
                                                                 int64_t n_cols, int64_t ld,
                                                                 const int32_t* __restrict__ row_index, int keep,
                                                                 float* __restrict__ out) {
-    extern __shared__ __attribute__((aligned(16))) f32x4 quad[];  // n_pad entries
+    typedef float vec_t __attribute__((ext_vector_type(V)));
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];  // n_pad entries of V floats
+    vec_t* const quad = reinterpret_cast<vec_t*>(lds_raw);
     __shared__ int nan_columns;   // bit e: column c + e holds a NaN (np.median makes the whole result NaN then)
     const int tid = threadIdx.x, nt = blockDim.x;
-    const int64_t n_quads = (n_cols + 3) / 4;
+    const int64_t n_quads = (n_cols + V - 1) / V;
     const float pinf = __builtin_inff();
     for (int64_t qd = blockIdx.x; qd < n_quads; qd += gridDim.x) {
-        const int64_t c = qd * 4;
+        const int64_t c = qd * V;
         if (tid == 0) nan_columns = 0;
         __syncthreads();
         int seen_nan = 0;
         for (int r = tid; r < n_pad; r += nt) {
-            f32x4 v = {pinf, pinf, pinf, pinf};
+            vec_t v;
+#pragma unroll
+            for (int e = 0; e < V; ++e) v[e] = pinf;
             if (r < n_rows) {
                 const int64_t src = row_index ? row_index[r] : r;
                 const float* p = G + src * ld + c;
-                if (c + 4 <= n_cols) {
-                    v = *reinterpret_cast<const f32x4u*>(p);
-                } else {
-                    v.x = p[0];
-                    v.y = c + 1 < n_cols ? p[1] : 0.0f;
-                    v.z = c + 2 < n_cols ? p[2] : 0.0f;
-                    v.w = 0.0f;
-                }
+#pragma unroll
+                for (int e = 0; e < V; ++e) v[e] = c + e < n_cols ? p[e] : 0.0f;
                 // this file is compiled with -fno-honor-nans (the sorting network's min / max): test the bits, not x != x
 #pragma unroll
-                for (int e = 0; e < 4; ++e)
+                for (int e = 0; e < V; ++e)
                     seen_nan |= (__float_as_uint(v[e]) & 0x7fffffffu) > 0x7f800000u ? (1 << e) : 0;
             }
             quad[r] = v;
@@ -204,11 +212,11 @@ __global__ __launch_bounds__(1024) void trimmed_mean_lds_kernel(const float* __r
                 for (int idx = tid; idx < (n_pad >> 1); idx += nt) {
                     const int i = ((idx & ~(j - 1)) << 1) | (idx & (j - 1));
                     const int p = i | j;
-                    const f32x4 a = quad[i], b = quad[p];
+                    const vec_t a = quad[i], b = quad[p];
                     const bool up = (i & k) == 0;
-                    f32x4 lo, hi;
+                    vec_t lo, hi;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
+                    for (int e = 0; e < V; ++e) {
                         lo[e] = __builtin_fminf(a[e], b[e]);
                         hi[e] = __builtin_fmaxf(a[e], b[e]);
                     }
@@ -219,12 +227,13 @@ __global__ __launch_bounds__(1024) void trimmed_mean_lds_kernel(const float* __r
             }
         }
         if (tid < 64) {
-            const QuadArray sorted{quad};
-            const WindowArgs args{G, ld, row_index, n_rows, keep, c, n_cols};
+            const ColumnArray<V> sorted{quad};
+            // (V = 2: the window code works on quads; columns beyond c + V are cut off through its column bound)
+            const WindowArgs args{G, ld, row_index, n_rows, keep, c, n_cols < c + V ? n_cols : c + V};
             window_mean(sorted, args, tid, out);
             // a NaN anywhere in the column: the reference's np.median is NaN and so is everything after it; the sorted
             // order above is unspecified for such a column, the result is not
-            if (tid < 4 && ((nan_columns >> tid) & 1) && c + tid < n_cols) out[c + tid] = __uint_as_float(0x7fc00000u);
+            if (tid < V && ((nan_columns >> tid) & 1) && c + tid < n_cols) out[c + tid] = __uint_as_float(0x7fc00000u);
         }
         __syncthreads();
     }
@@ -256,13 +265,21 @@ int launch_trimmed_mean_sorted(byz_ctx* ctx, const float* G, int64_t n_rows, int
         return BYZ_E_UNSUPPORTED;
     }
     const int64_t n_pad = next_pow2(n_rows);
-    const int64_t n_quads = ceil_div(n_cols, 4);
+    const int vec = n_pad <= 8192 ? 4 : 2;
+    const int64_t n_quads = ceil_div(n_cols, vec);
     const int64_t grid = n_quads < static_cast<int64_t>(ctx->num_cus) * 2 ? n_quads : static_cast<int64_t>(ctx->num_cus) * 2;
-    const size_t lds = static_cast<size_t>(n_pad) * sizeof(f32x4);
-    BYZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&trimmed_mean_lds_kernel),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
-    trimmed_mean_lds_kernel<<<static_cast<unsigned>(grid), 1024, lds, stream>>>(G, (int)n_rows, (int)n_pad, n_cols, ld,
-                                                                                row_index, (int)keep, out);
+    const size_t lds = static_cast<size_t>(n_pad) * vec * sizeof(float);
+    if (vec == 4) {
+        BYZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&trimmed_mean_lds_kernel<4>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
+        trimmed_mean_lds_kernel<4><<<static_cast<unsigned>(grid), 1024, lds, stream>>>(G, (int)n_rows, (int)n_pad, n_cols, ld,
+                                                                                       row_index, (int)keep, out);
+    } else {
+        BYZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&trimmed_mean_lds_kernel<2>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
+        trimmed_mean_lds_kernel<2><<<static_cast<unsigned>(grid), 1024, lds, stream>>>(G, (int)n_rows, (int)n_pad, n_cols, ld,
+                                                                                       row_index, (int)keep, out);
+    }
     return check_launch("trimmed_mean_lds_kernel");
 }
 

@@ -243,7 +243,7 @@ class KrumC2(Workload):
     def dominant(self):
         # N <= 128 runs csrc/krum_small.hip (K-sliced fp16x2 Gram, five launches) unless BYZ_KRUM_SMALL=0; its first kernel
         # reports under the same timing slot as the general path's Gram tiles
-        small = (self.n <= 128 and self.d <= int(os.environ.get('BYZ_KRUM_SMALL_MAX_COLS', 98304))
+        small = (self.n <= 128 and self.d <= int(os.environ.get('BYZ_KRUM_SMALL_MAX_COLS', 262144))
                  and os.environ.get('BYZ_KRUM_SMALL', '1') != '0')
         return {'kernel': 'gram_tile', 'bound': 'hbm', 'work': 4.0 * self.n * self.d + 4.0 * self.n * self.n,
                 'peak': PEAK_HBM, 'unit': 'GB/s', 'scale': 1e9, 'arithmetic': 'f16x2' if small else 'exact',
@@ -450,6 +450,35 @@ def kernel_table(per_kernel, steps):
             for name, v in per_kernel.items()}
 
 
+XGMI_LINK = 153e9          # B/s per direction and link (MI355X_MICROARCH.md; 7 links per GPU, point to point)
+
+
+def projected_scaling(wl, kernels, ms_per_step):
+    """PROJECTION, not a measurement (one GPU is all this bench can see unless the driver starts it on more):
+    the columns layout's round on W GPUs from this GPU's measured per-kernel times.  Per column and therefore divided by W:
+    the Gram tiles, the operand split, the second-stage trimmed mean, the column statistics of the attack.  Replicated on
+    every rank, not divided: the row sorts and the Bulyan selection loop.  Added: ONE ring all-reduce of the N x N fp64 Gram
+    (2 (W - 1) / W of its bytes through one xGMI link: the per-link bound, no credit for the mesh's other six links) and the
+    all-gather of the D-vector.  For configs[4]'s slice (c5s) the measured shard already IS one of eight: W = 8 only."""
+    per_column = sum(kernels.get(k, {}).get('ms_per_step', 0.0) for k in ('gram_tile', 'plane_split', 'trimmed_mean', 'column_stats',
+                                                                           'gram_reduce'))
+    kernel_total = sum(v['ms_per_step'] for v in kernels.values())
+    outside = max(ms_per_step - kernel_total, 0.0)        # host gaps, memsets, launches between the kernels
+    replicated = kernel_total - per_column
+    gram_bytes = 8.0 * wl.n * wl.n
+    out = {'label': 'PROJECTED from this GPU\'s measured kernels + an xGMI link model; not measured on W GPUs',
+           'layout': 'columns', 'link_GBps': XGMI_LINK / 1e9, 'per_column_ms': per_column, 'replicated_ms': replicated + outside}
+    shard_is_one_of = 8 if wl.with_attack else 1
+    for w in ((8,) if wl.with_attack else (2, 4, 8)):
+        split = w // shard_is_one_of
+        allreduce = 2.0 * (w - 1) / w * gram_bytes / XGMI_LINK * 1e3
+        allgather = (w - 1) / w * 4.0 * wl.d_total * shard_is_one_of / XGMI_LINK * 1e3
+        ms = per_column / split + replicated + outside + allreduce + allgather
+        out['gpus_%d' % w] = {'ms_per_step': ms, 'rounds_per_s': 1e3 / ms, 'allreduce_gram_ms': allreduce, 'allgather_output_ms': allgather,
+                              'params_total': wl.d_total * shard_is_one_of}
+    return out
+
+
 def load_traffic_table():
     """HBM bytes per launch from the committed rocprofv3 --pmc passes (profiles/*traffic*.json), doubled on the
     read side as MI355X_MICROARCH.md section HBM prescribes for gfx950.  None when no pass has been recorded."""
@@ -628,6 +657,8 @@ def main():
     }
     if hasattr(wl, 'verify'):
         line['verified_after_timing'] = wl.verify()
+    if world == 1 and isinstance(wl, BulyanSharded) and wl.layout == 'columns':
+        line['projected'] = projected_scaling(wl, line['kernels'], ms_per_step)
     if args.workload in ('c4', 'c5s') and (args.layout == 'both' or (world > 1 and args.layout == 'columns'
                                                                     and os.environ.get('BYZ_BENCH_ONE_LAYOUT') != '1')):
         # the other layout, same K steps: north_star names client sharding with an all-gather of row tiles; which one is

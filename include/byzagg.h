@@ -57,7 +57,9 @@ int byz_ctx_device(const byz_ctx* ctx);
 /* BYZ_E_UNSUPPORTED when the near-duplicate pair list overflowed.  Entry points with a host output do this */
 /* themselves.                                                                                             */
 int byz_ctx_check(byz_ctx* ctx, void* stream);
-/* largest supported row count for the selection kernels (rows of G), and for trimmed_mean */
+/* largest supported row count for the selection kernels (rows of G: Krum, Bulyan) and for trimmed_mean: */
+/* 16,384 both (the reference has no limit; BASELINE's largest configuration has 10,000 clients).  Beyond  */
+/* them the calls return BYZ_E_UNSUPPORTED.  trimmed_mean runs its fast kernels up to 5376 rows.          */
 int byz_limits(int64_t* max_rows_select, int64_t* max_rows_trimmed);
 
 /* ---- raw device memory, so that a host without torch can still drive the library ------- */

@@ -380,7 +380,7 @@ def test_trimmed_mean_heavy_ties_match_the_reference_rule(eng, n, c):
 
 
 @pytest.mark.parametrize('n,d', [(1025, 64), (1500, 130), (2080, 257), (2561, 40), (4096, 36), (5200, 50), (5632, 17),
-                                 (6000, 20)])
+                                 (6000, 20), (8192, 9), (8193, 6), (10000, 7), (16384, 5)])
 def test_trimmed_mean_general_kernel(eng, n, d):
     g = gaussian(6000 + n, n, d)
     c = n // 4
