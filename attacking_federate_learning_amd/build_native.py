@@ -18,7 +18,7 @@ LIB = os.path.join(HERE, 'libbyzagg.so')
 ARCH = 'gfx950'
 
 SOURCES = ['api.hip', 'column_stats.hip', 'gram.hip', 'select.hip', 'trimmed_mean.hip', 'median_window.hip',
-           'round_edges.hip', 'dedup.hip', 'gram_planes.hip', 'window_rows.hip', 'krum_small.hip', 'window_lean.hip']
+           'round_edges.hip', 'dedup.hip', 'gram_planes.hip', 'krum_small.hip', 'window_lean.hip']
 # The sorting network only orders finite values and +/-inf padding; NaN inputs are unspecified in the
 # reference as well.  Without this flag every v_min/v_max is preceded by a
 # canonicalising v_max (sNaN quieting), +30% VALU work in the hot kernel.
@@ -30,7 +30,6 @@ EXTRA_FLAGS = {'trimmed_mean.hip': ['-fno-honor-nans'],
                'median_window.hip': ['-mllvm', '-pragma-unroll-threshold=1000000'],
                'gram.hip': ['-mllvm', '-pragma-unroll-threshold=1000000'],
                'gram_planes.hip': ['-mllvm', '-pragma-unroll-threshold=1000000'],
-               'window_rows.hip': ['-mllvm', '-pragma-unroll-threshold=1000000'],
                'window_lean.hip': ['-mllvm', '-pragma-unroll-threshold=1000000'],
                'krum_small.hip': ['-mllvm', '-pragma-unroll-threshold=1000000'],
                # numpy arithmetic, operation by operation: no FMA contraction

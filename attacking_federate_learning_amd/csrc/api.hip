@@ -401,12 +401,8 @@ int byz_krum_dev(byz_ctx* ctx, const float* G, int64_t n_rows, int64_t n_cols, i
         // the reference's own sizes: five short launches (krum_small.hip), the row copy is part of the last one
         ctx->row_map_rows = 0;
         const int64_t prefix = python_prefix_len(n_rows - 1, users_count - corrupted_count);
-        if (krum_small_tail_enabled()) {
-            BYZ_TRY(launch_small_krum_merged(ctx, G, n_rows, n_cols, ld, ctx->dist.as<float>(), prefix, winner, out_row, s));
-        } else {
-            BYZ_TRY(launch_small_distances(ctx, G, n_rows, n_cols, ld, ctx->dist.as<float>(), s));
-            BYZ_TRY(launch_small_select(ctx, ctx->dist.as<float>(), n_rows, prefix, G, n_cols, ld, winner, out_row, s));
-        }
+        BYZ_TRY(launch_small_distances(ctx, G, n_rows, n_cols, ld, ctx->dist.as<float>(), s));
+        BYZ_TRY(launch_small_select(ctx, ctx->dist.as<float>(), n_rows, prefix, G, n_cols, ld, winner, out_row, s));
     } else {
         BYZ_TRY(launch_gram(ctx, G, n_rows, n_cols, ld, ctx->gram.as<double>(), s));
         BYZ_TRY(launch_distances_from_gram(ctx, ctx->gram.as<double>(), n_rows, ctx->dist.as<float>(), s, G, n_cols, ld));

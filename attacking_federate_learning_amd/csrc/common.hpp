@@ -251,10 +251,7 @@ int launch_bulyan_loop(byz_ctx* ctx, const float* dist, int64_t n, int64_t theta
 int launch_trimmed_mean(byz_ctx* ctx, const float* G, int64_t n_rows, int64_t n_cols, int64_t ld,
                         const int32_t* row_index, int64_t keep, float* out, hipStream_t stream);
 int64_t trimmed_mean_max_rows();
-// window_rows.hip: the row-split ring selection (first stage of the trimmed mean)
-int launch_window_rows(byz_ctx* ctx, const float* G, int64_t n_rows, int64_t n_cols, int64_t ld, const int32_t* row_index,
-                       int64_t keep, float* out, int32_t* redo, hipStream_t stream);
-// window_lean.hip: the instruction-lean form of the row-split ring selection (round 3)
+// window_lean.hip: the row-split ring selection, first stage of the trimmed mean (round 3)
 int launch_window_lean(byz_ctx* ctx, const float* G, int64_t n_rows, int64_t n_cols, int64_t ld, const int32_t* row_index,
                        int64_t keep, float* out, int32_t* redo, hipStream_t stream);
 int64_t select_max_rows();
@@ -268,8 +265,4 @@ int launch_small_distances(byz_ctx* ctx, const float* G, int64_t n_rows, int64_t
                            hipStream_t stream);
 int launch_small_select(byz_ctx* ctx, const float* dist, int64_t n_rows, int64_t prefix_len, const float* G, int64_t n_cols,
                         int64_t ld, int32_t* winner_dev, float* out_row, hipStream_t stream);
-bool krum_small_tail_enabled();
-int launch_small_krum_merged(byz_ctx* ctx, const float* G, int64_t n_rows, int64_t n_cols, int64_t ld, float* dist,
-                             int64_t prefix_len, int32_t* winner_dev, float* out_row, hipStream_t stream);
-
 }  // namespace byz

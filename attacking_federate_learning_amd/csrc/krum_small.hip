@@ -26,7 +26,6 @@
 //                            them, exactly as Python's sum() forms it (defences.py:33-34).
 //   K5 small_pick_kernel     every workgroup finds the winner itself (visit order 1, 0, 2, ..., strict '<' against 1e20,
 //                            defences.py:27-37) and copies its share of the winning row.
-//   (small_tail_kernel       K3 + K4 + K5 in one launch: BYZ_KRUM_SMALL_TAIL=1, unmeasured.)
 //
 // Algorithmic traffic: 4 N D bytes read once (K1); everything else is O(N^2).  Bound: HBM (N / 4 flop per byte is below
 // the machine balance of the 16-bit matrix pipe for every N <= 128).
@@ -741,184 +740,11 @@ __global__ __launch_bounds__(256) void small_pick_kernel(const float* __restrict
     for (int64_t k = k0 + tid; k < k1; k += 256) out_row[k] = src[k];
 }
 
-// ---- K3 + K4 + K5 in one launch (BYZ_KRUM_SMALL_TAIL=1; written at the end of round 2 without a GPU, off by default) -------
-// The three short launches after K2 cost ~3.5 us of host time and ~1.7 us of boundary each, more than their work.  One grid
-// of 1 + H workgroups instead:
-//   * every workgroup reads K2's two counters; only when they are not zero does workgroup 0 redo the distances
-//     (distance_worker) with the others as its helpers, and then everybody waits for its "distances final" flag;
-//   * workgroups 0 .. ceil(n / 8) - 1 score 8 rows each (one wave per row, K4's code) and arrive at a counter; the last one
-//     to arrive finds the winner (K5's code) and publishes it as ONE 8-byte granule {epoch, winner};
-//   * with a row to copy, every workgroup waits for that granule and copies its share.
-// Waits: none for an index-only call without near-duplicate rows; otherwise one fan-in of <= 16 arrivals and one broadcast.
-// All workgroups must be resident (one per CU: 146 KiB of LDS each); every wait is bounded (status bit 3).
-struct TailArgs {
-    DistanceArgs d;
-    int prefix_len;
-    float* scores;
-    int32_t* winner;
-    float* out_row;      // nullptr: index only
-};
-
-__device__ __forceinline__ bool wait_for_word(const int32_t* word, int32_t want) {   // thread 0 only
-    unsigned spins = 0;
-    while (__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != want) {
-        __builtin_amdgcn_s_sleep(8);
-        if (++spins > kSpinLimit) return false;
-    }
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    return true;
-}
-
-__global__ __launch_bounds__(kThreads) void small_tail_kernel(TailArgs a) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-    __shared__ int shared_word;
-    const DistanceArgs& p = a.d;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int n = p.n_rows;
-    const int scorers = (n + 7) / 8;
-
-    // ---- the distances, if K2 could not finish them
-    if (p.sync[4] != 0 || p.sync[5] != 0) {   // uniform over the grid
-        if (blockIdx.x == 0) {
-            distance_worker(p, lds);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-            if (tid == 0) {   // final (or abandoned, with the status word set): let the others go on either way
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __hip_atomic_store(p.sync + 6, p.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // this CU's L1 may hold K2's version of the distances
-            }
-        } else {
-            distance_helper(p, lds);
-            __syncthreads();
-            if (tid == 0) shared_word = wait_for_word(p.sync + 6, p.epoch) ? 1 : 0;
-            __syncthreads();
-            if (shared_word == 0) {
-                if (tid == 0) atomicOr(p.status, kStatusSmallTimeout);
-                return;
-            }
-        }
-        __syncthreads();
-    }
-
-    // ---- scores: one wave per row (K4)
-    bool last = false;
-    if (static_cast<int>(blockIdx.x) < scorers) {
-        float* sorted = reinterpret_cast<float*>(lds) + wave * kMaxRows;
-        const int u = 8 * blockIdx.x + wave;
-        if (u < n) {
-            float x[1][2];
-#pragma unroll
-            for (int r = 0; r < 2; ++r) {
-                const int c = r + 2 * lane;
-                x[0][r] = (c < n && c != u) ? p.dist[static_cast<int64_t>(u) * n + c] : __builtin_inff();
-            }
-            lanes::wave_bitonic_sort<2, 1>(x, lane);
-            sorted[2 * lane] = x[0][0];
-            sorted[2 * lane + 1] = x[0][1];
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-            if (lane == 0) {
-                float s = 0.0f;
-                for (int r = 0; r < a.prefix_len; ++r) s = __fadd_rn(s, sorted[r]);
-                a.scores[u] = s;
-            }
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (tid == 0) {
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            const int before = __hip_atomic_fetch_add(p.sync + 7, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            int mine = 0;
-            if (before == scorers - 1) {
-                __hip_atomic_store(p.sync + 7, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // for the next call
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-                mine = 1;
-            }
-            shared_word = mine;
-        }
-        __syncthreads();
-        last = shared_word != 0;
-        __syncthreads();
-    }
-
-    // ---- the winner (K5), by the last scorer to arrive
-    unsigned long long* granule = reinterpret_cast<unsigned long long*>(p.sync + 8);
-    if (last) {
-        if (tid < 64) {
-            float best = kKrumInit;
-            int pos = 0x7fffffff, row = -1;
-#pragma unroll
-            for (int r = 0; r < 2; ++r) {
-                const int u = tid + 64 * r;
-                if (u < n) {
-                    const float sc = a.scores[u];
-                    const int vp = visit_position(u);
-                    if (sc < kKrumInit && (sc < best || (sc == best && vp < pos))) {
-                        best = sc;
-                        pos = vp;
-                        row = u;
-                    }
-                }
-            }
-#pragma unroll
-            for (int m = 32; m > 0; m >>= 1) {
-                const float ob = __shfl_xor(best, m, 64);
-                const int op = __shfl_xor(pos, m, 64);
-                const int orow = __shfl_xor(row, m, 64);
-                if (op != 0x7fffffff && (pos == 0x7fffffff || ob < best || (ob == best && op < pos))) {
-                    best = ob;
-                    pos = op;
-                    row = orow;
-                }
-            }
-            if (tid == 0) {
-                const int w = n < 2 ? -1 : row;
-                *a.winner = w;
-                shared_word = w;
-                if (a.out_row != nullptr)   // one 8-byte store: {winner, epoch} cannot be seen half written
-                    __hip_atomic_store(granule, (static_cast<unsigned long long>(static_cast<uint32_t>(p.epoch)) << 32) |
-                                                    static_cast<uint32_t>(w), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-        }
-        __syncthreads();
-    }
-    if (a.out_row == nullptr) return;
-
-    // ---- the winning row, a share per workgroup
-    if (!last) {
-        if (tid == 0) {
-            unsigned spins = 0;
-            unsigned long long g = 0ull;
-            int w = -2;
-            for (;;) {
-                g = __hip_atomic_load(granule, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (static_cast<int32_t>(g >> 32) == p.epoch) {
-                    w = static_cast<int32_t>(static_cast<uint32_t>(g));
-                    break;
-                }
-                __builtin_amdgcn_s_sleep(8);
-                if (++spins > kSpinLimit) break;
-            }
-            shared_word = w;
-        }
-        __syncthreads();
-        if (shared_word == -2) {
-            if (tid == 0) atomicOr(p.status, kStatusSmallTimeout);
-            return;
-        }
-    }
-    int64_t r = shared_word;
-    if (r < 0) r += n;   // numpy's G[-1]: the reference returns the last row when nothing won
-    const float* src = p.G + r * p.ld;
-    const int64_t per = (p.n_cols + gridDim.x - 1) / gridDim.x;
-    const int64_t k0 = per * blockIdx.x;
-    const int64_t k1 = k0 + per < p.n_cols ? k0 + per : p.n_cols;
-    for (int64_t k = k0 + tid; k < k1; k += kThreads) a.out_row[k] = src[k];
-}
+// (K3 + K4 + K5 in ONE launch -- `small_tail_kernel`, written at the end of round 2 -- was measured in round 3 and removed:
+// 30.5 against 30.4 us per round at D = 79,510.  The kernel trace (profiles/r03o_*) says why: the merged kernel takes 8.9 us
+// where the three it replaces take 4.5 + 4.7 + 4.6, and the trace shows 10 us between its launches.  What a round costs
+// on the GPU is K1 (16.0 us: 31.8 MB at 2.0 TB/s) plus four trivial dependent kernels at ~4.5 us EACH -- the price of a
+// kernel boundary with its cache write-back on this part, not their work.)
 
 int env_int(const char* name, int fallback) {
     const char* v = std::getenv(name);
@@ -957,7 +783,7 @@ int reserve_small_workspaces(byz_ctx* ctx) {
 
 // dist (n x n fp32, pitch n) of the n_rows x n_cols matrix G: K1..K3
 static int small_distances(byz_ctx* ctx, const float* G, int64_t n_rows, int64_t n_cols, int64_t ld, float* dist,
-                           hipStream_t stream, const TailArgs* tail) {
+                           hipStream_t stream) {
     BYZ_REQUIRE(G && dist && n_rows >= 1 && n_rows <= kMaxRows && n_cols > 0 && ld >= n_cols,
                 "small distances: bad shape %lld x %lld ld %lld", (long long)n_rows, (long long)n_cols, (long long)ld);
     const int n = static_cast<int>(n_rows);
@@ -999,8 +825,6 @@ static int small_distances(byz_ctx* ctx, const float* G, int64_t n_rows, int64_t
         BYZ_ATTR(false, 8);
 #undef BYZ_ATTR
         BYZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&small_distance_kernel),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, kK3Lds));
-        BYZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&small_tail_kernel),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, kK3Lds));
         ctx->small_configured = true;
     }
@@ -1054,38 +878,15 @@ static int small_distances(byz_ctx* ctx, const float* G, int64_t n_rows, int64_t
         int helpers = env_int("BYZ_KRUM_SMALL_HELPERS", n_cols >= 4096 ? ctx->num_cus / 2 : 0);
         if (helpers > ctx->num_cus - 1) helpers = ctx->num_cus - 1;
         if (helpers < 0) helpers = 0;
-        if (tail == nullptr) {
-            small_distance_kernel<<<static_cast<unsigned>(1 + helpers), kThreads, kK3Lds, stream>>>(p);
-            BYZ_TRY(check_launch("small_distance_kernel"));
-        } else {   // K3 + K4 + K5 in one launch: the grid also holds the ceil(n / 8) scoring workgroups
-            TailArgs a = *tail;
-            a.d = p;
-            int grid = 1 + helpers;
-            if (grid < (n + 7) / 8) grid = (n + 7) / 8;
-            small_tail_kernel<<<static_cast<unsigned>(grid), kThreads, kK3Lds, stream>>>(a);
-            BYZ_TRY(check_launch("small_tail_kernel"));
-        }
+        small_distance_kernel<<<static_cast<unsigned>(1 + helpers), kThreads, kK3Lds, stream>>>(p);
+        BYZ_TRY(check_launch("small_distance_kernel"));
     }
     return BYZ_OK;
 }
 
 int launch_small_distances(byz_ctx* ctx, const float* G, int64_t n_rows, int64_t n_cols, int64_t ld, float* dist,
                            hipStream_t stream) {
-    return small_distances(ctx, G, n_rows, n_cols, ld, dist, stream, nullptr);
-}
-
-// BYZ_KRUM_SMALL_TAIL=1: K1, K2 and the merged tail (small_tail_kernel) -- three launches for a whole Krum call
-bool krum_small_tail_enabled() { return env_int("BYZ_KRUM_SMALL_TAIL", 0) != 0; }
-
-int launch_small_krum_merged(byz_ctx* ctx, const float* G, int64_t n_rows, int64_t n_cols, int64_t ld, float* dist,
-                             int64_t prefix_len, int32_t* winner_dev, float* out_row, hipStream_t stream) {
-    BYZ_TRY(ctx->scores.ensure(static_cast<size_t>(kMaxRows) * sizeof(float)));
-    TailArgs a;
-    a.prefix_len = static_cast<int>(prefix_len);
-    a.scores = ctx->scores.as<float>();
-    a.winner = winner_dev;
-    a.out_row = out_row;
-    return small_distances(ctx, G, n_rows, n_cols, ld, dist, stream, &a);
+    return small_distances(ctx, G, n_rows, n_cols, ld, dist, stream);
 }
 
 // scores (ctx->scores) and the winner (winner_dev) from a distance matrix of n <= 128 rows; out_row (optional): the copy of

@@ -775,328 +775,14 @@ __device__ __forceinline__ void finish_tile(float (&x)[NC][RPL], const float (&m
     }
 }
 
-// ---------------------------------------------------------------------------------------------------------------
-// Ring selection: the fast path for tiles of 256 .. 2560 rows (everything it cannot resolve is re-done by the general
-// kernel above, tile by tile, through a redo list).
-//
-// Per column, ONE histogram over B equal-width buckets of [min, max] (bucket index monotone in the value) yields, from
-// its prefix sums alone: bm1, bm2 = the buckets of the median ranks; ring(b) = max(bm1 - b, b - bm2, 0);
-// N(j) = number of values in rings <= j; j* = min j with N(j) >= keep; slack s = 1 + (bm2 - bm1).  A value of ring j
-// deviates from the median -- wherever inside its bucket(s) the median lies -- by between (j - 1) w and (j + s) w
-// (w = bucket width), so
-//     rings <= j* - 1 - s   belong to the `keep` nearest values          ("decided in":  N_in of them),
-//     rings >= j* + s + 1   do not                                        ("decided out"),
-//     rings j* - s .. j* + s are undecided: at most 2 (2 s + 1) buckets, a few dozen values.
-// ONE gather pass collects the median buckets and the undecided rings; ONE 64-lane sort by value gives the median
-// exactly (np.median's fp32 mean of the two middles); |fl(x - med)| over those sorted values falls and then rises (a
-// bitonic sequence), so ONE six-step merge yields T = the (keep - N_in)-th smallest undecided deviation; ONE last pass
-// sums fl(x - med) over |.| <= T.  That is the reference's window whenever exactly `keep` values pass (ties, and the rare
-// column where a decided-in value exceeds T, go to the general kernel).  scripts/proto/ring_window.py is this
-// selection in numpy: bit for bit the oracle on every column it resolves.
-//
-// ~30 vector instructions per value in four sweeps over the registers (histogram 5, gather 13, sum 5, staging 7)
-// against ~100 for the bucket/probing paths, and ~20 KB of code against 105-127 KB.
-// ---------------------------------------------------------------------------------------------------------------
-template <int B>
-__device__ __forceinline__ int cum_field(const uint32_t* cum, int b, int c, int n_rows) {
-    // number of the column's values in buckets < b (exclusive prefix); padding rows sit past bucket B - 1
-    if (b <= 0) return 0;
-    if (b >= B) return n_rows;
-    const uint32_t w = cum[b * 2 + (c >> 1)];
-    return static_cast<int>((c & 1) ? (w >> 16) : (w & 0xffffu));
-}
-
-template <int RPL, int B, int SR, int LSLOTS>
-__device__ __forceinline__ bool finish_fast(const float (&x)[4][RPL], const float (&mn)[4], const float (&mx)[4],
-                                            bool suspicious, int groups, int n_rows, int keep, int lane, int wave,
-                                            uint32_t* hist, uint32_t* lists01, uint32_t* lists23, float* dense,
-                                            int64_t c_base, int64_t n_cols, float* __restrict__ out) {
-    constexpr int NC = 4;
-    constexpr int GS = RPL >= 4 ? 4 : RPL;
-    constexpr int BPL = B / 64;                  // buckets per lane in the scan
-    constexpr int CAP = 64 * SR;                 // gathered values one sort takes
-    constexpr int LROW = LSLOTS + 1;             // list slots per lane and column (+ one scratch slot)
-    const float pinf = __builtin_inff();
-    if (suspicious || keep < 1) return false;
-    float lo[NC], inv[NC], nlo[NC];
-    bool fine = true;
-#pragma unroll
-    for (int c = 0; c < NC; ++c) {
-        lo[c] = wave_min(mn[c]);
-        const float hi = wave_max(mx[c]);
-        const float width = hi - lo[c];
-        inv[c] = uniform(static_cast<float>(B) * (1.0f - 1.0f / 1048576.0f) / width);
-        nlo[c] = uniform(-lo[c] * inv[c]);
-        fine = fine && finite_f(lo[c]) && finite_f(hi) && width > 0.0f && finite_f(inv[c]) && finite_f(nlo[c]);
-    }
-    if (!fine) return false;
-
-    // ---- sweep 1: histogram (two columns share a word: 16-bit counts, rows <= 2560)
-    __builtin_amdgcn_wave_barrier();
-#pragma unroll
-    for (int i = 0; i < 2 * BPL; i += 4)
-        *reinterpret_cast<u32x4*>(hist + lane * 2 * BPL + i) = u32x4{0u, 0u, 0u, 0u};
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-#pragma unroll
-    for (int c = 0; c < NC; ++c) {
-#pragma unroll
-        for (int g = 0; g < RPL / GS; ++g) {
-            if (g < groups) {
-#pragma unroll
-                for (int jj = 0; jj < GS; ++jj) {
-                    // (the clamp comes before the conversion: converting +inf, the padding, is undefined)
-                    const int b = static_cast<int>(__builtin_fminf(__builtin_fmaf(x[c][g * GS + jj], inv[c], nlo[c]),
-                                                                   static_cast<float>(B) - 0.5f));
-                    atomicAdd(hist + b * 2 + (c >> 1), (c & 1) ? 65536u : 1u);
-                }
-            }
-        }
-    }
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-
-    // ---- prefix sums: lane l owns buckets BPL l .. BPL l + BPL - 1; the exclusive sums go back in place.  While they
-    // are at hand: bucket of rank r = number of buckets whose inclusive sum is <= r (the median buckets).
-    const bool even = (n_rows & 1) == 0;
-    const int r1 = (n_rows - 1) >> 1, r2 = n_rows >> 1;
-    int bm1[NC], bm2[NC];
-    {
-        uint32_t run0 = 0u, run1 = 0u;
-#pragma unroll
-        for (int i = 0; i < BPL; ++i) {
-            run0 += hist[(lane * BPL + i) * 2 + 0];
-            run1 += hist[(lane * BPL + i) * 2 + 1];
-        }
-        uint32_t s0 = run0, s1 = run1;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const uint32_t u0 = __shfl_up(s0, d, 64), u1 = __shfl_up(s1, d, 64);
-            if (lane >= d) {
-                s0 += u0;
-                s1 += u1;
-            }
-        }
-        uint32_t acc0 = s0 - run0, acc1 = s1 - run1;   // values in the buckets of lower lanes
-        uint32_t below[NC] = {0u, 0u, 0u, 0u};         // low half: buckets at or below r1, high half: r2
-        __builtin_amdgcn_wave_barrier();
-#pragma unroll
-        for (int i = 0; i < BPL; ++i) {
-            const uint32_t h0 = hist[(lane * BPL + i) * 2 + 0], h1 = hist[(lane * BPL + i) * 2 + 1];
-            hist[(lane * BPL + i) * 2 + 0] = acc0;
-            hist[(lane * BPL + i) * 2 + 1] = acc1;
-            acc0 += h0;
-            acc1 += h1;
-#pragma unroll
-            for (int c = 0; c < NC; ++c) {
-                // (the last bucket's sum includes the padding rows: it exceeds every rank either way)
-                const uint32_t word = (c >> 1) ? acc1 : acc0;
-                const int v = static_cast<int>((c & 1) ? (word >> 16) : (word & 0xffffu));
-                below[c] += (v <= r1 ? 1u : 0u) + (v <= r2 ? 65536u : 0u);
-            }
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-#pragma unroll
-        for (int c = 0; c < NC; ++c) {
-            const uint32_t t = wave_sum_u32(below[c]);
-            bm1[c] = static_cast<int>(t & 0xffffu);
-            bm2[c] = static_cast<int>(t >> 16);
-            fine = fine && bm1[c] < B && bm2[c] < B && bm2[c] - bm1[c] <= 8;
-        }
-    }
-    if (!fine) return false;
-    const uint32_t* cum = hist;
-
-    // ---- j* = number of rings j with N(j) < keep (N is monotone); lane l tries j = l, l + 64, ...
-    int ring_lo[NC], span[NC], n_in[NC], need[NC], idx1[NC], idx2[NC], marked[NC], expected[NC], mid_lo[NC];
-    {
-        uint32_t fewer[2] = {0u, 0u};
-#pragma unroll 1   // (unrolled, all 8 BPL lookups are hoisted to the top and held in registers)
-        for (int i = 0; i < BPL; ++i) {
-            const int j = lane + 64 * i;
-#pragma unroll
-            for (int c = 0; c < NC; ++c) {
-                const int inside = cum_field<B>(cum, bm2[c] + j + 1, c, n_rows) - cum_field<B>(cum, bm1[c] - j, c, n_rows);
-                fewer[c >> 1] += inside < keep ? ((c & 1) ? 65536u : 1u) : 0u;
-            }
-        }
-        const uint32_t f0 = wave_sum_u32(fewer[0]), f1 = wave_sum_u32(fewer[1]);
-#pragma unroll
-        for (int c = 0; c < NC; ++c) {
-            const uint32_t f = (c >> 1) ? f1 : f0;
-            const int j_star = static_cast<int>((c & 1) ? (f >> 16) : (f & 0xffffu));
-            const int s = 1 + bm2[c] - bm1[c];
-            const int j_in = j_star - 1 - s;               // rings <= j_in are decided in
-            const int ring_hi = j_star + s;
-            ring_lo[c] = j_in + 1;                         // may be <= 0: then the median buckets are undecided too
-            span[c] = ring_hi - ring_lo[c];
-            // (everything below is the same in every lane: LDS reads at uniform addresses; say so to the compiler)
-            const int first_left = bm1[c] - ring_hi;       // leftmost gathered bucket (may be < 0)
-            const int n_upto_hi = uniform(cum_field<B>(cum, bm2[c] + ring_hi + 1, c, n_rows) - cum_field<B>(cum, first_left, c, n_rows));
-            n_in[c] = j_in >= 0 ? uniform(cum_field<B>(cum, bm2[c] + j_in + 1, c, n_rows) - cum_field<B>(cum, bm1[c] - j_in, c, n_rows)) : 0;
-            const int middle = uniform(cum_field<B>(cum, bm2[c] + 1, c, n_rows) - cum_field<B>(cum, bm1[c], c, n_rows));
-            marked[c] = ring_lo[c] >= 1 ? middle : 0;      // gathered for the median only, not undecided
-            expected[c] = n_upto_hi - n_in[c] + marked[c];
-            need[c] = keep - n_in[c];
-            // gathered values left of the median buckets: rings max(ring_lo, 1) .. ring_hi on the low side
-            const int left = uniform(cum_field<B>(cum, bm1[c] - (ring_lo[c] > 1 ? ring_lo[c] : 1) + 1, c, n_rows) -
-                                     cum_field<B>(cum, first_left, c, n_rows));
-            const int at_bm1 = uniform(cum_field<B>(cum, bm1[c], c, n_rows));
-            mid_lo[c] = left;                              // first gathered value of the median buckets
-            idx1[c] = left + (r1 - at_bm1);
-            idx2[c] = left + (r2 - at_bm1);
-            fine = fine && expected[c] <= CAP && need[c] >= 1 && need[c] <= n_upto_hi - n_in[c];
-        }
-    }
-    if (!fine) return false;
-
-    // ---- sweep 2: gather.  Every lane keeps a short stack per column; a miss overwrites the scratch slot on top.
-    int top[NC] = {0, 0, 0, 0};
-#pragma unroll
-    for (int c = 0; c < NC; ++c) {
-        uint32_t* mine = (c < 2 ? lists01 + c * LROW * 64 : lists23 + (c - 2) * LROW * 64) + lane;
-#pragma unroll
-        for (int g = 0; g < RPL / GS; ++g) {
-            if (g < groups) {
-#pragma unroll
-                for (int jj = 0; jj < GS; ++jj) {
-                    const float a = x[c][g * GS + jj];
-                    const int b = static_cast<int>(__builtin_fminf(__builtin_fmaf(a, inv[c], nlo[c]), 1.0e9f));   // padding: far out
-                    const int ring = max(max(bm1[c] - b, b - bm2[c]), 0);
-                    const bool hit = static_cast<uint32_t>(ring - ring_lo[c]) <= static_cast<uint32_t>(span[c]) || ring == 0;
-                    mine[min(top[c], LSLOTS) * 64] = __float_as_uint(a);
-                    top[c] += hit ? 1 : 0;
-                }
-            }
-        }
-    }
-    // ---- compaction of the stacks into one array per column
-    int total[NC];
-    {
-        bool overflow = false;
-        uint32_t packed = 0u;
-#pragma unroll
-        for (int c = 0; c < NC; ++c) {
-            overflow = overflow || top[c] > LSLOTS;
-            packed |= static_cast<uint32_t>(top[c] & 0xff) << (8 * c);
-        }
-        if (__ballot(overflow) != 0ull) return false;
-        uint32_t scan = packed;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const uint32_t u = __shfl_up(scan, d, 64);
-            if (lane >= d) scan += u;
-        }
-        const uint32_t all = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(scan), 63));
-        const uint32_t before = scan - packed;
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-#pragma unroll
-        for (int c = 0; c < NC; ++c) {
-            total[c] = uniform(static_cast<int>((all >> (8 * c)) & 0xffu));
-            fine = fine && total[c] == expected[c];       // the histogram and the gather must agree
-            const int at = static_cast<int>((before >> (8 * c)) & 0xffu);
-#pragma unroll
-            for (int sl = 0; sl < LSLOTS; ++sl) {
-                const uint32_t v = (c < 2 ? lists01 + c * LROW * 64 : lists23 + (c - 2) * LROW * 64)[sl * 64 + lane];
-                if (sl < top[c] && at + sl < CAP) dense[c * CAP + at + sl] = __uint_as_float(v);
-            }
-        }
-        if (!fine) return false;
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    }
-
-    // ---- one sort by value: the median; one merge of the deviations: the threshold
-    float sv[NC][SR];
-#pragma unroll
-    for (int c = 0; c < NC; ++c)
-#pragma unroll
-        for (int r = 0; r < SR; ++r) sv[c][r] = (r + SR * lane) < total[c] ? dense[c * CAP + r + SR * lane] : pinf;
-    wave_bitonic_sort<SR, NC>(sv, lane);
-    __builtin_amdgcn_wave_barrier();
-#pragma unroll
-    for (int c = 0; c < NC; ++c)
-#pragma unroll
-        for (int r = 0; r < SR; ++r) dense[c * CAP + r + SR * lane] = sv[c][r];
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    float med[NC], thr[NC];
-#pragma unroll
-    for (int c = 0; c < NC; ++c) {
-        const float a = dense[c * CAP + idx1[c]], b = dense[c * CAP + idx2[c]];
-        med[c] = uniform(even ? __fmul_rn(__fadd_rn(a, b), 0.5f) : a);    // np.median
-        // deviations of the sorted gathered values: falling, then rising; the median buckets that are not
-        // undecided sink to the bottom (-inf) and are skipped by rank, the padding floats on top (+inf)
-#pragma unroll
-        for (int r = 0; r < SR; ++r) {
-            const int i = r + SR * lane;
-            const float dv = __builtin_fabsf(__fsub_rn(sv[c][r], med[c]));
-            const bool skip = marked[c] > 0 && i >= mid_lo[c] && i < mid_lo[c] + marked[c];
-            sv[c][r] = i >= total[c] ? pinf : (skip ? -pinf : dv);
-        }
-    }
-    wave_bitonic_merge<SR, NC>(sv, lane);
-    __builtin_amdgcn_wave_barrier();
-#pragma unroll
-    for (int c = 0; c < NC; ++c)
-#pragma unroll
-        for (int r = 0; r < SR; ++r) dense[c * CAP + r + SR * lane] = sv[c][r];
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-#pragma unroll
-    for (int c = 0; c < NC; ++c) thr[c] = uniform(dense[c * CAP + marked[c] + need[c] - 1]);
-
-    // ---- sweep 3: the window sum
-    float result[NC];
-#pragma unroll
-    for (int c = 0; c < NC; ++c) {
-        float acc = 0.0f;
-        int inside = 0;
-#pragma unroll
-        for (int g = 0; g < RPL / GS; ++g) {
-            if (g < groups) {
-#pragma unroll
-                for (int jj = 0; jj < GS; ++jj) {
-                    const float d = __fsub_rn(x[c][g * GS + jj], med[c]);     // +inf padding stays +inf: never inside
-                    const bool in = __builtin_fabsf(d) <= thr[c];
-                    acc += in ? d : 0.0f;
-                    inside += in ? 1 : 0;
-                }
-            }
-        }
-        const float sum = wave_sum(acc);
-        const int n_inside = static_cast<int>(wave_sum_u32(static_cast<uint32_t>(inside)));
-        // more than `keep` values within T: ties at the edge (row order decides) -- fewer: a decided-in value lies
-        // beyond T; both are the general kernel's business
-        fine = fine && n_inside == keep && thr[c] == thr[c];
-        result[c] = __fadd_rn(__fdiv_rn(sum, static_cast<float>(keep)), med[c]);   // defences.py:51
-    }
-    if (!fine) return false;
-    if (lane < NC) {
-        const int64_t col = c_base + NC * wave + lane;
-        const float r = lane == 0 ? result[0] : (lane == 1 ? result[1] : (lane == 2 ? result[2] : result[3]));
-        if (col < n_cols) out[col] = r;
-    }
-    return true;
-}
-
 // NC columns per wave, WAVES waves per workgroup, WAVES * NC = 16 columns per tile.  NC = 4 (4 waves) holds up to
 // 2560 rows; NC = 1 (16 waves, one column each) trades the amortisation of the probe bookkeeping for register space
 // and holds up to 5632 rows (Bulyan's second stage at N = 10,000: theta = 5200).
-// MODE 0: the general selection for every tile.  MODE 1: the ring selection; tiles it cannot resolve are appended to
-// `redo`.  MODE 2: the general selection for the tiles listed in `redo` (launched right behind a MODE 1 kernel).
-struct RingShape {   // buckets, sort registers, list slots by tile height
-    int buckets, sort_regs, slots;
-};
-template <int RPL>
-constexpr RingShape ring_shape() { return RPL <= 16 ? RingShape{512, 1, 6} : RingShape{1024, 2, 8}; }
+// MODE 0: the general selection for every tile.  MODE 2: the general selection for the tiles listed in `redo` -- launched
+// right behind the ring selection of window_lean.hip, which resolves all but a few tiles in a thousand and lists the rest.
+// (MODE 1 was this file's own ring selection over the column-split layout, round 2's fast path up to 1024 rows, and
+// window_rows.hip its row-split form above that: both were superseded by window_lean.hip in round 3 -- 0.64 / 0.56 -> 0.40 ms
+// at 1000 rows, 1.21 -> 0.94 ms at 2080 rows per 2^18 columns -- and removed.)
 
 // (A branch-free form of the staging loads -- every load of a chunk unconditional, padding rows re-reading the last row --
 // was built at the end of round 2 on the strength of the ISA (s_waitcnt vmcnt(0) in front of every guarded load) and measured
@@ -1114,11 +800,10 @@ __global__ __launch_bounds__(64 * WAVES, (RPL * NC <= 64 || WAVES == 16 ? 4 : 2)
     constexpr int QUADS = COLS / 4;
     constexpr int THREADS_ = 64 * WAVES;
     constexpr int ROWS_PER_PASS = THREADS_ / QUADS;   // rows one staging pass of the workgroup covers
-    constexpr RingShape kRing = ring_shape<RPL>();
     constexpr int kTransit = 64 * JC * STRIDE;
     // per-wave scratch behind the transit buffer: the general path's strip/histogram/candidates, or the ring path's
     // histogram (its gather lists reuse the transit buffer, dead once the tile sits in registers)
-    constexpr int kScratch = MODE == 1 ? kRing.buckets * 2 : kWaveScratch;
+    constexpr int kScratch = kWaveScratch;
     __shared__ __attribute__((aligned(16))) float transit[kTransit + WAVES * kScratch + 16];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     float* strip = transit + kTransit + wave * kScratch;
@@ -1214,23 +899,7 @@ __global__ __launch_bounds__(64 * WAVES, (RPL * NC <= 64 || WAVES == 16 ? 4 : 2)
     __syncthreads();
     const bool suspicious = uniform(nonfinite[NC == 4 ? wave : wave / 4]) != 0;   // an LDS load is per-lane to the compiler: make it scalar
 
-    if constexpr (MODE == 1) {
-        static_assert(NC == 4 && WAVES == 4, "the ring selection is written for 4 waves x 4 columns");
-        constexpr int kLists = (kRing.slots + 1) * 64;          // words per column
-        constexpr int kDense = 4 * 64 * kRing.sort_regs;
-        constexpr int kSlice = kTransit / WAVES;
-        constexpr bool kDenseInSlice = 2 * kLists + kDense <= kSlice;
-        static_assert(2 * kLists <= kSlice && 2 * kLists + (kDenseInSlice ? 0 : kDense) <= kRing.buckets * 2, "LDS layout");
-        uint32_t* slice = reinterpret_cast<uint32_t*>(transit) + wave * kSlice;   // free: every wave is past the staging barrier
-        uint32_t* hist = reinterpret_cast<uint32_t*>(strip);
-        float* dense = reinterpret_cast<float*>(kDenseInSlice ? slice + 2 * kLists : hist + 2 * kLists);
-        const bool done = finish_fast<RPL, kRing.buckets, kRing.sort_regs, kRing.slots>(
-            x, mn, mx, suspicious, groups, n_rows, keep, lane, wave, hist, slice, hist, dense, c_base, n_cols, out);
-        // one unresolved wave sends the whole tile to the general kernel
-        if (__syncthreads_or(done ? 0 : 1) && tid == 0) redo[1 + atomicAdd(redo, 1)] = static_cast<int32_t>(tile);
-    } else {
-        finish_tile<RPL, NC>(x, mn, mx, suspicious, groups, slots, n_rows, keep, lane, wave, strip, c_base, n_cols, out);
-    }
+    finish_tile<RPL, NC>(x, mn, mx, suspicious, groups, slots, n_rows, keep, lane, wave, strip, c_base, n_cols, out);
 }
 
 template <int RPL, int NC, int WAVES>
@@ -1242,9 +911,8 @@ int launch_rpl(const float* G, int64_t n_rows, int64_t n_cols, int64_t ld, const
     return check_launch("median_window_kernel");
 }
 
-// ring selection first, then the general kernel over whatever it could not resolve (redo[0] tiles; the second launch is
-// sized for all of them and the surplus workgroups leave at once).  The first stage is the row-split kernel of
-// window_rows.hip (above 1024 rows) or this file's column-split ring kernel (129 .. 2560 rows).
+// The ring selection of window_lean.hip first, then this file's general kernel over whatever it could not resolve (redo[0]
+// tiles; the second launch is sized for all of them and the surplus workgroups leave at once).
 template <int RPL, int NC, int WAVES>
 int launch_ring(byz_ctx* ctx, const float* G, int64_t n_rows, int64_t n_cols, int64_t ld, const int32_t* row_index,
                 int64_t keep, float* out, hipStream_t stream) {
@@ -1252,28 +920,12 @@ int launch_ring(byz_ctx* ctx, const float* G, int64_t n_rows, int64_t n_cols, in
     BYZ_TRY(ctx->redo_tiles.ensure(static_cast<size_t>(n_tiles + 1) * sizeof(int32_t)));
     int32_t* redo = ctx->redo_tiles.as<int32_t>();
     BYZ_HIP(hipMemsetAsync(redo, 0, sizeof(int32_t), stream));
-    // BYZ_TM_ROWS: unset -> the row-split kernel above 1024 rows (measured: 2.29 vs 2.18 ms at 1000 rows x 1e6 columns,
-    // 8.5 vs 9.1 ms at 2080 rows x 2^20, 12.5 vs 16.3 ms at 5200 rows x 2^19); 1 -> always; 0 -> never
-    const char* e = std::getenv("BYZ_TM_ROWS");
-    int rc = BYZ_E_UNSUPPORTED;
-    // BYZ_TM_LEAN (default 1): window_lean.hip, round 3's form of the row-split kernel, for every height it covers
-    const char* lean_env = std::getenv("BYZ_TM_LEAN");
-    if (lean_env == nullptr || std::atoi(lean_env) != 0)
-        rc = launch_window_lean(ctx, G, n_rows, n_cols, ld, row_index, keep, out, redo, stream);
-    if (rc == BYZ_E_UNSUPPORTED && (e ? std::atoi(e) != 0 : n_rows > 1024))
-        rc = launch_window_rows(ctx, G, n_rows, n_cols, ld, row_index, keep, out, redo, stream);
-    if (rc == BYZ_E_UNSUPPORTED) {
-        if constexpr (NC == 4 && WAVES == 4 && RPL >= 4) {
-            median_window_kernel<RPL, 4, 4, 1><<<static_cast<unsigned>(n_tiles), 256, 0, stream>>>(
-                G, static_cast<int>(n_rows), n_cols, ld, row_index, static_cast<int>(keep), out, redo);
-            BYZ_TRY(check_launch("median_window_kernel<ring>"));
-        } else {
-            ctx->redo_valid = false;
-            return launch_rpl<RPL, NC, WAVES>(G, n_rows, n_cols, ld, row_index, keep, out, stream);
-        }
-    } else if (rc != BYZ_OK) {
-        return rc;
+    const int rc = launch_window_lean(ctx, G, n_rows, n_cols, ld, row_index, keep, out, redo, stream);
+    if (rc == BYZ_E_UNSUPPORTED) {   // (a leading dimension of 2^30 elements or more)
+        ctx->redo_valid = false;
+        return launch_rpl<RPL, NC, WAVES>(G, n_rows, n_cols, ld, row_index, keep, out, stream);
     }
+    if (rc != BYZ_OK) return rc;
     median_window_kernel<RPL, NC, WAVES, 2><<<static_cast<unsigned>(n_tiles), 64 * WAVES, 0, stream>>>(
         G, static_cast<int>(n_rows), n_cols, ld, row_index, static_cast<int>(keep), out, redo);
     return check_launch("median_window_kernel<redo>");
@@ -1294,8 +946,8 @@ int launch_trimmed_mean(byz_ctx* ctx, const float* G, int64_t n_rows, int64_t n_
     ctx->redo_valid = false;
     const int64_t rpl = ceil_div(n_rows, 64);
     if (rpl > 88) return launch_trimmed_mean_sorted(ctx, G, n_rows, n_cols, ld, row_index, keep, out, stream);
-    // the ring selection (window_rows.hip) with this file's general kernel behind it: 129 .. 5376 rows
-    // (BYZ_TM_RING=0 keeps the general kernel for everything)
+    // the ring selection (window_lean.hip) with this file's general kernel behind it: 129 .. 5376 rows
+    // (BYZ_TM_RING=0 keeps the general kernel for everything: the comparison, and tests of the general kernel itself)
     {
         const char* e = std::getenv("BYZ_TM_RING");
         if ((!e || std::atoi(e) != 0) && keep >= 1 && rpl >= 3 && rpl <= 84) {

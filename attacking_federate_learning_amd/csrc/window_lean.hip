@@ -1,6 +1,6 @@
 // Median-window trimmed mean (reference defences.py:44-52), row-split layout, round 3: the instruction-lean form.
 //
-// window_rows.hip (round 2) proved the layout -- the workgroup owns 16 columns, the waves split the rows, every load of
+// window_rows.hip (round 2; removed when this file replaced it) proved the layout -- the workgroup owns 16 columns, the waves split the rows, every load of
 // the tile in flight at once -- and its counters showed what bounds it: 65 vector instructions per value (1.05e9 VALU
 // wave-instructions per 1e9 values, profiles/r02k), i.e. instruction issue, not HBM.  Half of them were the four sweeps
 // over the register-resident tile, half the per-column bookkeeping done by every wave with all 64 lanes for one column at
@@ -260,7 +260,8 @@ __global__ __launch_bounds__(64 * W, 4) void window_lean_kernel(const float* __r
 
     // ---- sweep A: histograms.  bucket = round(x * inv + nlo) clamped to [0, B - 1]; column 4 q + e counts in the
     // low (e even) or high (e odd) half of word [column pair 2 q + e / 2][bucket]
-    float inv[4], kadd[4];   // the same two numbers map a value to its bucket in both sweeps
+    // (inv, nlo + 2^23) of a column: the same two numbers map a value to its bucket in both sweeps.  They are recomputed where
+    // they are needed rather than kept: eight registers held across the phases were what pushed the tall shapes into scratch
     auto column_range = [&](int c, float& lo, float& hi) __attribute__((always_inline)) {
         lo = from_okey(minmax[c]);
         hi = from_okey(minmax[kTileCols + c]);
@@ -274,13 +275,14 @@ __global__ __launch_bounds__(64 * W, 4) void window_lean_kernel(const float* __r
         iv = static_cast<float>(B - 1) * __builtin_amdgcn_rcpf(hi - lo);   // (any monotone map will do: the same numbers everywhere)
         ka = __builtin_fmaf(-lo, iv, kMagic);
     };
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        float lo, hi;
-        column_range(4 * q + e, lo, hi);
-        column_scale(lo, hi, inv[e], kadd[e]);
-    }
     {
+        float inv[4], kadd[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float lo, hi;
+            column_range(4 * q + e, lo, hi);
+            column_scale(lo, hi, inv[e], kadd[e]);
+        }
         f32x2 poison = {0.0f, 0.0f};   // x * 0 accumulates to NaN as soon as one live value is NaN or +-inf
         const f32x2 zero2 = {0.0f, 0.0f};
         const f32x2 inv01 = {inv[0], inv[1]}, inv23 = {inv[2], inv[3]};
@@ -457,16 +459,28 @@ __global__ __launch_bounds__(64 * W, 4) void window_lean_kernel(const float* __r
 
     // ---- sweep B: gather (median buckets and undecided rings go on the lane's stack) and sum (decided-in rings)
     {
-        int top[4] = {0, 0, 0, 0};
-        float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
         const f32x2 magic2 = {kMagic, kMagic}, two2 = {2.0f, 2.0f};
+        bool overflow = false;
 #pragma unroll
         for (int ep = 0; ep < 2; ++ep) {   // the lane's columns two at a time: the affine steps run as packed instructions
             const ColumnPlan p0 = plan[4 * q + 2 * ep], p1 = plan[4 * q + 2 * ep + 1];
-            const f32x2 inv2 = {inv[2 * ep], inv[2 * ep + 1]}, k2 = {kadd[2 * ep], kadd[2 * ep + 1]};
+            f32x2 inv2, k2;
+            {
+                float lo, hi, iv, ka;
+                column_range(4 * q + 2 * ep, lo, hi);
+                column_scale(lo, hi, iv, ka);
+                inv2.x = iv;
+                k2.x = ka;
+                column_range(4 * q + 2 * ep + 1, lo, hi);
+                column_scale(lo, hi, iv, ka);
+                inv2.y = iv;
+                k2.y = ka;
+            }
             const f32x2 nsum2 = {-p0.sum_b, -p1.sum_b}, piv2 = {p0.pivot, p1.pivot};
             uint32_t* const mine0 = un + (2 * ep) * (LS + 1) * T + tid;
             uint32_t* const mine1 = un + (2 * ep + 1) * (LS + 1) * T + tid;
+            int top0 = 0, top1 = 0;
+            float acc0 = 0.0f, acc1 = 0.0f;
 #pragma unroll
             for (int j = 0; j < RPW; ++j) {
                 const f32x2 v = {x[j][2 * ep], x[j][2 * ep + 1]};
@@ -476,37 +490,32 @@ __global__ __launch_bounds__(64 * W, 4) void window_lean_kernel(const float* __r
                 const float az0 = __builtin_fabsf(z.x), az1 = __builtin_fabsf(z.y);
                 const bool in0 = __builtin_fabsf(az0 - p0.mid) < p0.half, in1 = __builtin_fabsf(az1 - p1.mid) < p1.half;
                 const bool hit0 = az0 <= p0.outer && !in0, hit1 = az1 <= p1.outer && !in1;
-                acc[2 * ep] = __fadd_rn(acc[2 * ep], in0 ? d.x : 0.0f);
-                acc[2 * ep + 1] = __fadd_rn(acc[2 * ep + 1], in1 ? d.y : 0.0f);
-                mine0[min(top[2 * ep], LS) * T] = __float_as_uint(v.x);
-                mine1[min(top[2 * ep + 1], LS) * T] = __float_as_uint(v.y);
-                top[2 * ep] += hit0 ? 1 : 0;
-                top[2 * ep + 1] += hit1 ? 1 : 0;
+                acc0 = __fadd_rn(acc0, in0 ? d.x : 0.0f);
+                acc1 = __fadd_rn(acc1, in1 ? d.y : 0.0f);
+                mine0[min(top0, LS) * T] = __float_as_uint(v.x);
+                mine1[min(top1, LS) * T] = __float_as_uint(v.y);
+                top0 += hit0 ? 1 : 0;
+                top1 += hit1 ? 1 : 0;
             }
-            // one partial per wave and column, in a fixed order: inside the 16-lane row, then across the four rows
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                float a = row_quad_sum(acc[2 * ep + h]);
-                a = __fadd_rn(a, lane_xor(a, 16, lane));
-                a = __fadd_rn(a, lane_xor(a, 32, lane));
-                acc[2 * ep + h] = a;
+            // the pair's counts and sums leave the registers at once (the tile fills half the register file).  One partial
+            // per wave and column, in a fixed order: inside the 16-lane row, then across the four rows
+            overflow = overflow || top0 > LS || top1 > LS;
+            reinterpret_cast<uint8_t*>(tops)[4 * tid + 2 * ep] = static_cast<uint8_t>(top0 > LS ? LS : top0);
+            reinterpret_cast<uint8_t*>(tops)[4 * tid + 2 * ep + 1] = static_cast<uint8_t>(top1 > LS ? LS : top1);
+            acc0 = row_quad_sum(acc0);
+            acc0 = __fadd_rn(acc0, lane_xor(acc0, 16, lane));
+            acc0 = __fadd_rn(acc0, lane_xor(acc0, 32, lane));
+            acc1 = row_quad_sum(acc1);
+            acc1 = __fadd_rn(acc1, lane_xor(acc1, 16, lane));
+            acc1 = __fadd_rn(acc1, lane_xor(acc1, 32, lane));
+            if (rr == 0) {
+                part_sum[wave * kTileCols + 4 * q + 2 * ep] = acc0;
+                part_sum[wave * kTileCols + 4 * q + 2 * ep + 1] = acc1;
             }
         }
-        bool overflow = false;
-        uint32_t packed = 0u;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            overflow = overflow || top[e] > LS;
-            packed |= static_cast<uint32_t>(top[e] > LS ? LS : top[e]) << (8 * e);
-        }
-        tops[tid] = packed;
         if (overflow) {
             flags[1] = 1;
             atomicAdd(&g_lean_reasons[6], 1u);
-        }
-        if (rr == 0) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) part_sum[wave * kTileCols + 4 * q + e] = acc[e];
         }
     }
     __syncthreads();

@@ -421,7 +421,7 @@ def roofline_of(wl, per_kernel, traffic_table, steps=None):
     if traffic_table:
         # the committed PMC passes were taken at the BASELINE sizes of each workload; other sizes report null
         rec = traffic_table.get('%s/%s' % (wl.name, dom['kernel'])) if wl.at_profiled_size() else None
-        if rec and rec.get('arithmetic', 'split') == dom.get('arithmetic', 'split'):
+        if rec and rec.get('arithmetic', 'split') == dom.get('arithmetic', 'split') and traffic_record_is_current(rec):
             traffic = rec.get('hbm_bytes_per_launch')
     out = {'kernel': dom['kernel'], 'bound': dom['bound'], 'achieved': achieved / dom['scale'],
            'peak': dom['peak'] / dom['scale'], 'unit': dom['unit'], 'frac': achieved / dom['peak'],
@@ -477,6 +477,21 @@ def projected_scaling(wl, kernels, ms_per_step):
         out['gpus_%d' % w] = {'ms_per_step': ms, 'rounds_per_s': 1e3 / ms, 'allreduce_gram_ms': allreduce, 'allgather_output_ms': allgather,
                               'params_total': wl.d_total * shard_is_one_of}
     return out
+
+
+def traffic_record_is_current(rec):
+    """A PMC record stands for the kernel it was taken on: it names the kernel's source file and that file's hash at the
+    time (scripts/update_traffic.py).  A kernel edited since reports `traffic: null` rather than a stale number; records
+    from before round 3 carry no hash and are taken as they are (their kernels have not changed)."""
+    src, want = rec.get('source'), rec.get('source_sha16')
+    if not src or not want:
+        return True
+    try:
+        import hashlib
+        path = os.path.join(ROOT, 'attacking_federate_learning_amd', 'csrc', src)
+        return hashlib.sha256(open(path, 'rb').read()).hexdigest()[:16] == want
+    except OSError:
+        return False
 
 
 def load_traffic_table():

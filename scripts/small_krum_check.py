@@ -58,7 +58,7 @@ def dist64(g):
     return out
 
 
-MODES = ('0', '1', '1t')   # general path, csrc/krum_small.hip, the same with K3..K5 merged (BYZ_KRUM_SMALL_TAIL=1)
+MODES = ('0', '1')   # general path, csrc/krum_small.hip
 
 
 def one_case(eng, n, d, f, family, seed):
@@ -68,7 +68,6 @@ def one_case(eng, n, d, f, family, seed):
     res = {}
     for mode in MODES:
         os.environ['BYZ_KRUM_SMALL'] = mode[0]
-        os.environ['BYZ_KRUM_SMALL_TAIL'] = '1' if mode.endswith('t') else '0'
         t0 = time.time()
         dm = eng.pairwise_distances(buf).numpy()
         idx = eng.krum(buf, n, f, return_index=True)
@@ -104,9 +103,8 @@ def one_case(eng, n, d, f, family, seed):
 def timing(eng, n, d, f, rounds=200):
     g = make(n, d, 77, 'scaled')
     buf = eng.to_device(g)
-    for mode in ('0', '1', '1t'):
+    for mode in ('0', '1'):
         os.environ['BYZ_KRUM_SMALL'] = mode[0]
-        os.environ['BYZ_KRUM_SMALL_TAIL'] = '1' if mode.endswith('t') else '0'
         for _ in range(20):
             eng.krum(buf, n, f)
         eng.synchronize()

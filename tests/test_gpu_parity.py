@@ -387,6 +387,30 @@ def test_trimmed_mean_general_kernel(eng, n, d):
     assert close(eng.trimmed_mean(g, n, c), ideal.trimmed_mean(g, c))
 
 
+@pytest.mark.parametrize('n,d', [(200, 50), (1000, 130), (2080, 48), (2561, 20), (5200, 33)])
+def test_trimmed_mean_general_kernel_on_its_own(eng, monkeypatch, n, d):
+    """BYZ_TM_RING=0: the general selection (median_window.hip, MODE 0) for every tile -- by default it only sees the few
+    tiles the ring selection of window_lean.hip hands back, so its other instantiations get their own run here."""
+    monkeypatch.setenv('BYZ_TM_RING', '0')
+    g = scaled(6100 + n, n, d)
+    for c in (n // 4, 1, n - 2):
+        assert close(eng.trimmed_mean(g, n, c), ideal.trimmed_mean(g, c))
+    assert eng.trimmed_mean_redone() == 0      # (no ring selection ran: nothing was handed back)
+
+
+@pytest.mark.parametrize('n,d', [(100, 4096), (300, 2048), (640, 1024)])
+def test_gram_register_staging_equals_lds_dma(eng, monkeypatch, n, d):
+    """BYZ_GRAM_NO_DMA=1 stages the Gram's operand tiles through registers (the path rows that are not 16-byte aligned
+    take anyway) instead of LDS-DMA: same arithmetic, same k order -- the distances must be bit for bit the same."""
+    monkeypatch.setenv('BYZ_KRUM_SMALL', '0')
+    g = scaled(6200 + n, n, d)
+    monkeypatch.delenv('BYZ_GRAM_NO_DMA', raising=False)
+    want = eng.pairwise_distances(g).numpy()
+    monkeypatch.setenv('BYZ_GRAM_NO_DMA', '1')
+    got = eng.pairwise_distances(g).numpy()
+    assert np.array_equal(got, want)
+
+
 @pytest.mark.parametrize('n,m', [(300, 72), (1000, 240), (130, 129)])
 def test_trimmed_mean_with_many_identical_rows(eng, n, m):
     """More than 64 clients submit the same vector (the attack's normal case): a bucket then holds more equal values
