@@ -129,6 +129,23 @@ constexpr int kStampTiles = 256, kStamps = 12;
 __device__ int g_lean_timing;
 __device__ unsigned long long g_lean_stamps[kStampTiles * kStamps];
 
+// Register rows are loaded (and then swept) in this order: the three sampled ones first, so that the range phase can start
+// while the rest of the tile is still on its way (memory returns loads in order).
+template <int RPW>
+__host__ __device__ constexpr int lean_order(int i) {
+    const int s1 = RPW / 3, s2 = (2 * RPW) / 3;
+    if (i == 0) return 0;
+    if (i == 1) return s1;
+    if (i == 2) return s2;
+    int k = i - 3;
+    for (int j = 0; j < RPW; ++j) {
+        if (j == 0 || j == s1 || j == s2) continue;
+        if (k == 0) return j;
+        --k;
+    }
+    return 0;
+}
+
 struct ColumnPlan {   // written by the search (the first lane of the column's group), read by sweep B and by the column's owner
     // sweep B classifies a value by z = 2 b - (bm1 + bm2), b its bucket: |z| = s - 1 + 2 ring, s = 1 + bm2 - bm1
     float sum_b;         // bm1 + bm2
@@ -193,8 +210,10 @@ __global__ __launch_bounds__(64 * W, 4) void window_lean_kernel(const float* __r
                 src[j] = static_cast<uint32_t>(row_index ? row_index[row] : row);
             }
 #pragma unroll
-            for (int j = 0; j < RPW; ++j)
+            for (int i = 0; i < RPW; ++i) {
+                const int j = lean_order<RPW>(i);
                 x[j] = *reinterpret_cast<const f32x4u*>(base + static_cast<uint64_t>(src[j]) * pitch);
+            }
         } else {
 #pragma unroll
             for (int j = 0; j < RPW; ++j) {
@@ -312,7 +331,8 @@ __global__ __launch_bounds__(64 * W, 4) void window_lean_kernel(const float* __r
             asm volatile("ds_add_u32 %0, %1" ::"v"(a3), "v"(one_hi) : "memory");
         };
 #pragma unroll
-        for (int j = 0; j < RPW; ++j) {
+        for (int i = 0; i < RPW; ++i) {
+            const int j = lean_order<RPW>(i);               // the order the loads were issued in
             if ((j * W + wave) * 16 + 15 < n_rows) {        // wave-uniform: a block without padding
                 count(x[j]);
             } else if ((j * W + wave) * 16 + rr < n_rows) {
