@@ -195,47 +195,37 @@ __global__ __launch_bounds__(64 * W, 4) void window_lean_kernel(const float* __r
 #define BYZ_STAMP(i) do { if (stamping) g_lean_stamps[stamp_tile * kStamps + (i)] = __builtin_readcyclecounter(); } while (0)
     BYZ_STAMP(0);
 
-    // ---- every load of the tile, at once (no branch around a load: rows past the matrix re-read the last row)
-    f32x4 x[RPW];
-    {
-        const int64_t col = c_base + 4 * q;
-        const unsigned char* base = reinterpret_cast<const unsigned char*>(G) + col * 4;
-        const uint32_t pitch = static_cast<uint32_t>(ld) * 4u;
-        if (c_base + kTileCols <= n_cols) {   // uniform: every tile but a ragged last one
-            uint32_t src[RPW];
-#pragma unroll
-            for (int j = 0; j < RPW; ++j) {
-                int row = (j * W + wave) * 16 + rr;
-                row = row < n_rows ? row : n_rows - 1;
-                src[j] = static_cast<uint32_t>(row_index ? row_index[row] : row);
-            }
-#pragma unroll
-            for (int i = 0; i < RPW; ++i) {
-                const int j = lean_order<RPW>(i);
-                x[j] = *reinterpret_cast<const f32x4u*>(base + static_cast<uint64_t>(src[j]) * pitch);
-            }
-        } else {
-#pragma unroll
-            for (int j = 0; j < RPW; ++j) {
-                int row = (j * W + wave) * 16 + rr;
-                row = row < n_rows ? row : n_rows - 1;
-                const uint32_t src = static_cast<uint32_t>(row_index ? row_index[row] : row);
-                const float* ptr = reinterpret_cast<const float*>(base + static_cast<uint64_t>(src) * pitch);
-                f32x4 v = {0.0f, 0.0f, 0.0f, 0.0f};   // columns past the matrix are computed on zeros and never stored
-                if (col + 0 < n_cols) v.x = ptr[0];
-                if (col + 1 < n_cols) v.y = ptr[1];
-                if (col + 2 < n_cols) v.z = ptr[2];
-                if (col + 3 < n_cols) v.w = ptr[3];
-                x[j] = v;
-            }
-        }
-#pragma unroll
-        for (int j = 0; j < RPW; ++j) {   // padding rows: +inf (in no ring, in no sum; the histogram skips them)
-            if ((j * W + wave) * 16 + 15 >= n_rows) {   // wave-uniform: only the last block or two can hold padding
-                if ((j * W + wave) * 16 + rr >= n_rows) x[j] = f32x4{pinf, pinf, pinf, pinf};
-            }
-        }
+    // ---- loads.  No branch around a load (rows past the matrix re-read the last row and are masked where they are used).
+    // A wave cannot get past its load instructions while the CU's memory pipeline is full -- measured: the 16 loads of a
+    // 1000-row tile hold wave 0 for 7,000 of the workgroup's 37,000 ticks.  With several workgroups on the CU (4 and 8 waves
+    // per tile) that is covered by the others, and requesting the whole tile at once keeps the most requests in flight:
+    // requesting rows a few ahead of their use inside sweep A instead was measured SLOWER there (0.442 vs 0.400 ms at 1000
+    // rows, 0.918 vs 0.881 ms at 2080).  The 16-wave shapes have the CU to themselves: there only the three SAMPLED register
+    // rows are requested up front and the others under the range phase and the histogram (1.526 -> 1.409 ms at 5200 rows).
+    // (EXACT needs every row for the range: everything up front.)
+    // A ragged last tile (n_cols not a multiple of 16) is the general kernel's: its scalar, guarded loads have no place here.
+    if (c_base + kTileCols > n_cols) {   // uniform
+        if (tid == 0) redo[1 + atomicAdd(redo, 1)] = static_cast<int32_t>(tile);
+        return;
     }
+    f32x4 x[RPW];
+    uint32_t src[RPW];
+#pragma unroll
+    for (int j = 0; j < RPW; ++j) {
+        int row = (j * W + wave) * 16 + rr;
+        row = row < n_rows ? row : n_rows - 1;
+        src[j] = static_cast<uint32_t>(row_index ? row_index[row] : row);
+    }
+    const unsigned char* const col_base = reinterpret_cast<const unsigned char*>(G) + (c_base + 4 * q) * 4;
+    const uint32_t pitch = static_cast<uint32_t>(ld) * 4u;
+    auto fetch = [&](int j) __attribute__((always_inline)) {
+        x[j] = *reinterpret_cast<const f32x4u*>(col_base + static_cast<uint64_t>(src[j]) * pitch);
+    };
+    constexpr int PRE = (EXACT || W < 16) ? RPW : 3;   // positions (in lean_order) requested before the range phase
+    constexpr int AHEAD = 4;               // ... and how far sweep A requests ahead of what it counts
+#pragma unroll
+    for (int i = 0; i < PRE; ++i) fetch(lean_order<RPW>(i));
+    BYZ_STAMP(8);   // (the first loads issued)
     // LDS set-up while the loads fly
     for (int i = tid; i < 8 * PS / 4; i += T) reinterpret_cast<uint4*>(un)[i] = make_uint4(0u, 0u, 0u, 0u);
     if (tid < kTileCols) {
@@ -257,7 +247,7 @@ __global__ __launch_bounds__(64 * W, 4) void window_lean_kernel(const float* __r
             const bool live = (j * W + wave) * 16 + rr < n_rows;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                mn[e] = __builtin_fminf(mn[e], x[j][e]);                    // +inf padding never wins a minimum
+                mn[e] = __builtin_fminf(mn[e], live ? x[j][e] : pinf);     // (rows past the matrix hold a copy of the last row)
                 mx[e] = __builtin_fmaxf(mx[e], live ? x[j][e] : -pinf);
             }
         }
@@ -330,8 +320,18 @@ __global__ __launch_bounds__(64 * W, 4) void window_lean_kernel(const float* __r
             asm volatile("ds_add_u32 %0, %1" ::"v"(a2), "v"(one_lo) : "memory");
             asm volatile("ds_add_u32 %0, %1" ::"v"(a3), "v"(one_hi) : "memory");
         };
+        auto request = [&](int i) __attribute__((always_inline)) {   // position i of the load order (nothing moves above here)
+            if (i >= PRE && i < RPW) {
+                const int j = lean_order<RPW>(i);
+                asm volatile("" : "+v"(src[j]));
+                fetch(j);
+            }
+        };
+#pragma unroll
+        for (int i = PRE; i < PRE + AHEAD; ++i) request(i);
 #pragma unroll
         for (int i = 0; i < RPW; ++i) {
+            request(PRE + AHEAD + i);
             const int j = lean_order<RPW>(i);               // the order the loads were issued in
             if ((j * W + wave) * 16 + 15 < n_rows) {        // wave-uniform: a block without padding
                 count(x[j]);
@@ -341,6 +341,12 @@ __global__ __launch_bounds__(64 * W, 4) void window_lean_kernel(const float* __r
         }
         if (poison.x != poison.x || poison.y != poison.y) flags[0] = 1;
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the atomics above are invisible to the compiler's counters
+    }
+#pragma unroll
+    for (int j = 0; j < RPW; ++j) {   // padding rows: +inf from here on (in no ring, in no sum)
+        if ((j * W + wave) * 16 + 15 >= n_rows) {   // wave-uniform: only the last block or two can hold padding
+            if ((j * W + wave) * 16 + rr >= n_rows) x[j] = f32x4{pinf, pinf, pinf, pinf};
+        }
     }
     __syncthreads();
     BYZ_STAMP(3);   // sweep A done
@@ -710,6 +716,11 @@ int launch_lean_shape(const float* G, int64_t n_rows, int64_t n_cols, int64_t ld
         double sum[kStamps] = {0};
         for (int t = 0; t < tiles; ++t)
             for (int i = 1; i < 8; ++i) sum[i] += static_cast<double>(stamps[t * kStamps + i] - stamps[t * kStamps + i - 1]);
+        {
+            double issue_only = 0;
+            for (int t = 0; t < tiles; ++t) issue_only += static_cast<double>(stamps[t * kStamps + 8] - stamps[t * kStamps + 0]);
+            std::fprintf(stderr, "lean: the load instructions alone take %.0f ticks of the first phase\n", issue_only / tiles);
+        }
         std::fprintf(stderr, "lean W=%d RPW=%d phases (s_memtime ticks, mean of %d tiles): issue %.0f | load wait + range %.0f | sweep A %.0f | scan %.0f | search %.0f | sweep B %.0f | owners %.0f\n",
                      W, RPW, tiles, sum[1] / tiles, sum[2] / tiles, sum[3] / tiles, sum[4] / tiles, sum[5] / tiles, sum[6] / tiles, sum[7] / tiles);
         const int off = 0;
