@@ -401,8 +401,10 @@ def test_trimmed_mean_general_kernel_on_its_own(eng, monkeypatch, n, d):
 @pytest.mark.parametrize('n,d', [(100, 4096), (300, 2048), (640, 1024)])
 def test_gram_register_staging_equals_lds_dma(eng, monkeypatch, n, d):
     """BYZ_GRAM_NO_DMA=1 stages the Gram's operand tiles through registers (the path rows that are not 16-byte aligned
-    take anyway) instead of LDS-DMA: same arithmetic, same k order -- the distances must be bit for bit the same."""
+    take anyway) instead of LDS-DMA: same arithmetic, same k order -- the distances must be bit for bit the same.  (The
+    fp32-input MFMA on both sides: the bf16 x 3 split exists only on the LDS-DMA path.)"""
     monkeypatch.setenv('BYZ_KRUM_SMALL', '0')
+    monkeypatch.setenv('BYZ_GRAM_MODE', 'exact')
     g = scaled(6200 + n, n, d)
     monkeypatch.delenv('BYZ_GRAM_NO_DMA', raising=False)
     want = eng.pairwise_distances(g).numpy()
