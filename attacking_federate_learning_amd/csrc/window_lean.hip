@@ -161,7 +161,7 @@ struct ColumnPlan {   // written by the search (the first lane of the column's g
 // W waves, RPW 16-row blocks per wave (rows <= 16 W RPW), B buckets, SR sort registers per lane (64 SR candidates per column),
 // LS stack slots per lane and column.  EXACT: the bucket range is the column's true [min, max] (one more sweep); otherwise
 // it is taken from a sample and the end buckets collect what falls outside.
-template <int W, int RPW, int B, int SR, int LS, bool EXACT>
+template <int W, int RPW, int B, int SR, int LS, bool EXACT, bool PIPE>
 __global__ __launch_bounds__(64 * W, 4) void window_lean_kernel(const float* __restrict__ G, int n_rows, int64_t n_cols,
                                                                 int64_t ld, const int32_t* __restrict__ row_index, int keep,
                                                                 float* __restrict__ out, int32_t* __restrict__ redo) {
@@ -221,7 +221,7 @@ __global__ __launch_bounds__(64 * W, 4) void window_lean_kernel(const float* __r
     auto fetch = [&](int j) __attribute__((always_inline)) {
         x[j] = *reinterpret_cast<const f32x4u*>(col_base + static_cast<uint64_t>(src[j]) * pitch);
     };
-    constexpr int PRE = (EXACT || W < 16) ? RPW : 3;   // positions (in lean_order) requested before the range phase
+    constexpr int PRE = (EXACT || !PIPE) ? RPW : 3;   // positions (in lean_order) requested before the range phase
     constexpr int AHEAD = 4;               // ... and how far sweep A requests ahead of what it counts
 #pragma unroll
     for (int i = 0; i < PRE; ++i) fetch(lean_order<RPW>(i));
@@ -696,17 +696,21 @@ int launch_lean_shape(const float* G, int64_t n_rows, int64_t n_cols, int64_t ld
     // (tiles from the middle of the launch: the chip is in its steady state there)
     const int timing = timing_env != nullptr && std::atoi(timing_env) != 0 ? 1 + static_cast<int>(n_tiles > 2 * kStampTiles ? n_tiles / 2 : 0) : 0;
     if (timing) BYZ_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_lean_timing), &timing, sizeof(int)));
-    if (exact) {
-        BYZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&window_lean_kernel<W, RPW, B, SR, LS, true>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
-        window_lean_kernel<W, RPW, B, SR, LS, true><<<static_cast<unsigned>(n_tiles), 64 * W, lds, stream>>>(
-            G, static_cast<int>(n_rows), n_cols, ld, row_index, static_cast<int>(keep), out, redo);
-    } else {
-        BYZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&window_lean_kernel<W, RPW, B, SR, LS, false>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
-        window_lean_kernel<W, RPW, B, SR, LS, false><<<static_cast<unsigned>(n_tiles), 64 * W, lds, stream>>>(
-            G, static_cast<int>(n_rows), n_cols, ld, row_index, static_cast<int>(keep), out, redo);
-    }
+    // PIPE: request the tile's rows under the range phase and the histogram instead of all at once (the 16-wave shapes, which
+    // have the CU to themselves; BYZ_TM_LEAN_PIPE=0|1 forces it either way: the comparison)
+    const char* pipe_env = std::getenv("BYZ_TM_LEAN_PIPE");
+    const bool pipe = pipe_env != nullptr ? std::atoi(pipe_env) != 0 : W == 16;
+#define BYZ_LEAN(E, P)                                                                                              \
+    do {                                                                                                            \
+        BYZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&window_lean_kernel<W, RPW, B, SR, LS, E, P>),     \
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));            \
+        window_lean_kernel<W, RPW, B, SR, LS, E, P><<<static_cast<unsigned>(n_tiles), 64 * W, lds, stream>>>(        \
+            G, static_cast<int>(n_rows), n_cols, ld, row_index, static_cast<int>(keep), out, redo);                 \
+    } while (0)
+    if (exact) BYZ_LEAN(true, false);
+    else if (pipe) BYZ_LEAN(false, true);
+    else BYZ_LEAN(false, false);
+#undef BYZ_LEAN
     BYZ_TRY(check_launch("window_lean_kernel"));
     if (timing) {
         static unsigned long long stamps[kStampTiles * kStamps];
