@@ -372,7 +372,9 @@ struct Frags<2> {
 };
 
 // PLANES = 3: bf16x3 (gram.hip's arithmetic), 2: f16x2.  NBUF stages of LDS; the DMA runs NBUF stages ahead.
-// DBG (timing experiments only, wrong results): bit 0 no DMA after the first NBUF stages, bit 1 no MFMA.
+// DBG (timing experiments only, wrong results; scripts/gram_ab.py): bit 0 no DMA after the first NBUF stages,
+// bit 1 no MFMA, bit 2 no workgroup barrier in the steady loop, bit 3 no LDS reads after stage 0, bit 4 no slab update,
+// bit 5 every workgroup's DMA reads tile (0, 0) (the L2 -> LDS rate without misses).
 template <int PLANES, int NBUF, int DBG>
 __global__ __launch_bounds__(kThreads, 1) void gram_planes_kernel(const u32x4* __restrict__ planes, int64_t n_steps,
                                                                   const double* __restrict__ unscale, int64_t rows_pad,
@@ -438,7 +440,8 @@ __global__ __launch_bounds__(kThreads, 1) void gram_planes_kernel(const u32x4* _
         int q = wave + 8 * i;
         if (q >= kPieces) q = kPieces - 1;
         const int rbl = q / PLANES, piece = q % PLANES;
-        const int64_t rb = rbl < 8 ? static_cast<int64_t>(bi) * 8 + rbl : static_cast<int64_t>(tj) * 4 + (rbl - 8);
+        int64_t rb = rbl < 8 ? static_cast<int64_t>(bi) * 8 + rbl : static_cast<int64_t>(tj) * 4 + (rbl - 8);
+        if (DBG & 32) rb = rbl < 8 ? rbl : rbl - 8;
         piece_off[i] = (((rb * n_steps + step0) * PLANES + piece) * 64) * 16;
     }
     const unsigned char* lane_base = reinterpret_cast<const unsigned char*>(planes) + lane * 16;
@@ -467,6 +470,7 @@ __global__ __launch_bounds__(kThreads, 1) void gram_planes_kernel(const u32x4* _
             }
 
     auto read_frags = [&](int s, Frags<PLANES>& f) __attribute__((always_inline)) {
+        if ((DBG & 8) && s > 0) return;
         const unsigned char* A = lds + (s % NBUF) * kStage + (2 * wr) * kRbBytes + lane * 16;
         const unsigned char* B = lds + (s % NBUF) * kStage + (8 + 2 * wc) * kRbBytes + lane * 16;
 #pragma unroll
@@ -526,7 +530,8 @@ __global__ __launch_bounds__(kThreads, 1) void gram_planes_kernel(const u32x4* _
         // outstanding (memory reads return in order, so that is a vmcnt bound)
         if (kFullWaves == 8 || wave < kFullWaves) wait_vmcnt<(kLead - 2) * kPerWave>();
         else wait_vmcnt<(kLead - 2) * (kPerWave - 1)>();
-        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        if (DBG & 4) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         if (live_wave) flush(s);
     };
     auto drain = [&](int s, const Frags<PLANES>& cur, Frags<PLANES>& next) __attribute__((always_inline)) {
@@ -581,6 +586,15 @@ __global__ __launch_bounds__(kThreads, 1) void gram_planes_kernel(const u32x4* _
         // ... and must not be papered over: without the ticket the slab is not ours to update (the host turns the
         // status word into BYZ_E_HIP)
         if (tid == 0) atomicOr(device_status, kStatusLostTicket);
+    } else if (live_wave && (DBG & 16)) {
+        float all = 0.0f;   // keeps the accumulators alive without the slab traffic
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int n = 0; n < 2; ++n)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) all += acc[m][n][e] + acc2[m][n][e];
+        if (all == 1.2345e38f) partial[tid] = all;
     } else if (live_wave) {
         const bool slab_live = chunk > 0 || slab_live0 != 0;
         double* out = partial + (static_cast<int64_t>(ti) * (ti + 1) / 2 + tj) * (kSlab * kSlab);
@@ -686,8 +700,8 @@ int launch_gram_planes(byz_ctx* ctx, const float* G, int64_t n_rows, int64_t n_c
     }
     int* tickets = ctx->gram_tickets.as<int>();
     u32x4* planes = ctx->gram_planes.as<u32x4>();
-    // BYZ_GRAM_PLANES_VARIANT: 0 production; 4: f16x2 with four LDS stages; 10 / 20: timing experiments (no DMA / no
-    // MFMA, wrong results)
+    // BYZ_GRAM_PLANES_VARIANT: 0 production; 4: f16x2 with four LDS stages; the others are timing experiments with wrong
+    // results (the DBG bits of the kernel, times ten)
     const int variant = env_int("BYZ_GRAM_PLANES_VARIANT", 0);
     typedef void (*kernel_t)(const u32x4*, int64_t, const double*, int64_t, double*, int, const int2*, int, int*, int, int,
                              int, int32_t*);
@@ -696,7 +710,14 @@ int launch_gram_planes(byz_ctx* ctx, const float* G, int64_t n_rows, int64_t n_c
     if (f16) {
         nbuf = variant == 4 ? 4 : 6;
         kernel = variant == 10 ? &gram_planes_kernel<2, 6, 1> : variant == 20 ? &gram_planes_kernel<2, 6, 2>
-                 : variant == 4 ? &gram_planes_kernel<2, 4, 0> : &gram_planes_kernel<2, 6, 0>;
+                 : variant == 4 ? &gram_planes_kernel<2, 4, 0>
+                 : variant == 50 ? &gram_planes_kernel<2, 6, 5>      // no DMA, no barrier
+                 : variant == 90 ? &gram_planes_kernel<2, 6, 9>      // no DMA, no LDS reads
+                 : variant == 130 ? &gram_planes_kernel<2, 6, 13>    // the MFMAs, the loop and the slab update only
+                 : variant == 160 ? &gram_planes_kernel<2, 6, 16>    // everything but the slab update
+                 : variant == 340 ? &gram_planes_kernel<2, 6, 34>    // DMA only, every workgroup the same tile
+                 : variant == 320 ? &gram_planes_kernel<2, 6, 32>    // everything, every workgroup the same tile
+                                  : &gram_planes_kernel<2, 6, 0>;
     } else {
         nbuf = 4;
         kernel = variant == 10 ? &gram_planes_kernel<3, 4, 1> : variant == 20 ? &gram_planes_kernel<3, 4, 2>
