@@ -99,7 +99,8 @@ __global__ void row_sort_kernel(const float* __restrict__ dist, int n, int n_pad
             const unsigned long long key = keys[r];
             const int c = static_cast<int>(key & 0xffffffffu);
             sorted_idx[static_cast<int64_t>(u) * n + r] = static_cast<uint16_t>(c);
-            sorted_val[static_cast<int64_t>(u) * n + r] = from_ordered_bits(static_cast<uint32_t>(key >> 32));
+            const float v = from_ordered_bits(static_cast<uint32_t>(key >> 32));
+            sorted_val[static_cast<int64_t>(u) * n + r] = v == 0.0f ? 0.0f : v;   // never -0.0: that bit pattern marks a removed entry
             rank_t[static_cast<int64_t>(c) * n + u] = static_cast<uint16_t>(r);
             if (r < n - 1) {
                 const double v = static_cast<double>(from_ordered_bits(static_cast<uint32_t>(key >> 32)));
@@ -425,6 +426,254 @@ __device__ __forceinline__ float reference_score_plain(const float* __restrict__
     return carry;
 }
 
+// ---------------------------------------------------------------------------------------------------
+// The same score, bit for bit, WITHOUT the chain of dependent additions (round 3; prototype and its checks:
+// scripts/proto/seqsum_int.py).  A dependent v_add_f32 costs ~10 cycles on a SIMD that runs one wave, so the literal chain
+// over a 7600-entry prefix is ~76,000 cycles however its operands are fed (profiles/r03s_bulyan_pair_rescore.txt).  But
+// while the running sum s = I q (q its ulp, 2^23 <= I < 2^24) stays inside its binade, round-to-nearest-even is integer
+// arithmetic:
+//       fl(s + x) = (I + a + t) q,   a = floor(x / q),   t = [rem > q / 2]  or  [rem == q / 2 and I + a odd],
+// and the only thing one entry needs from its predecessors is the PARITY of I in front of it (ties) -- a prefix over
+// "xor b" (no tie: b = a + t mod 2) and "reset to 0" (a tie always leaves an even I).  So a wave takes 512 entries at once,
+// eight consecutive ones per lane: a and the remainder's class per entry, the lane's increment under either incoming
+// parity, the incoming parity of every lane from two ballots, a DPP prefix sum, and the first entry at which I reaches
+// 2^24: that ONE entry is added in fp32 (always right, whatever the binades do), and the pass restarts behind it with the
+// new q.  A prefix of m entries has ~log2(m / 64) such crossings once the first 64 entries -- where the sum doubles every
+// other step -- have been added literally: 23 passes for 7600 entries.
+//
+// No staging either: the table of ascending values is MARKED as the loop goes -- every row sets the entry of the removed
+// winner (its rank comes from the rank table the O(1) update reads anyway) and of its own diagonal to -0.0, which adds
+// nothing and is never a live distance (row_sort_kernel stores +0.0 for a zero) -- so a re-score reads the row's entries as
+// they lie, counts the live ones for the prefix cut, and needs neither the columns nor the `removed` bitmap.
+constexpr uint32_t kGoneBits = 0x80000000u;   // -0.0f
+
+__device__ __forceinline__ uint32_t wave_scan_u32(uint32_t v) {   // inclusive, lane order
+    int x = static_cast<int>(v);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xF, 0xF, true);   // row_shr:1 (zeros shifted in)
+    x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xF, 0xF, true);   // row_shr:2
+    x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xF, 0xF, true);   // row_shr:4
+    x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xF, 0xF, true);   // row_shr:8
+    x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xA, 0xF, false);  // row_bcast:15 into rows 1 and 3
+    x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xC, 0xF, false);  // row_bcast:31 into rows 2 and 3
+    return static_cast<uint32_t>(x);
+}
+
+// 512 entries onto s (wave-uniform in and out).  Lane l holds entries 8 l .. 8 l + 7 as significand M (0: the entry adds
+// nothing -- removed, past the prefix, or already in s) and biased exponent ex >= 1 (subnormals count as exponent 1).
+// Per pass and entry, under the unit q of s (biased exponent es): (M : 0) >> (es - ex) as ONE 64-bit shift gives
+// a = floor(x / q) in the high word and the remainder, left-aligned, in the low word -- above half a unit iff it exceeds
+// 0x80000000, a tie iff it equals it.  Lanes without a tie (nearly all) have their increment at once, and its parity is
+// their "xor"; only lanes that hold a tie walk their eight entries under both incoming parities.
+__device__ __forceinline__ float integer_passes(uint32_t (&M)[8], const int (&ex)[8], float s, int lane, unsigned long long& n_passes) {
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    for (;;) {
+        const uint32_t sbits = __float_as_uint(s);
+        const int e0 = static_cast<int>(sbits >> 23);
+        if (e0 >= 255) break;   // inf / NaN: it stays what it is as far as "< 1e20" goes
+        ++n_passes;
+        const int es = e0 != 0 ? e0 : 1;
+        const uint32_t I = e0 != 0 ? ((sbits & 0x7fffffu) | 0x800000u) : (sbits & 0x7fffffu);
+        uint32_t a[8], y[8];
+        uint32_t mine = 0;
+        bool any_tie = false;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int sh = es - ex[j];
+            const int shc = sh < 0 ? 0 : (sh > 25 ? 25 : sh);
+            const unsigned long long w = (static_cast<unsigned long long>(M[j]) << 32) >> shc;
+            y[j] = static_cast<uint32_t>(w);
+            a[j] = sh < 0 ? (1u << 24) : static_cast<uint32_t>(w >> 32);   // x above the sum's binade: the crossing entry for sure
+            mine += a[j] + (y[j] > 0x80000000u ? 1u : 0u);
+            any_tie = any_tie || y[j] == 0x80000000u;
+        }
+        uint32_t pin = 0, s1 = mine, p0 = mine & 1u, p1 = p0 ^ 1u;
+        const unsigned long long tie_lanes = __ballot(any_tie);
+        if (tie_lanes != 0ull) {   // uniform
+            if (any_tie) {
+                uint32_t s0 = 0;
+                s1 = 0, p0 = 0, p1 = 1;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const uint32_t alpha = a[j] & 1u, ab = y[j] > 0x80000000u ? 1u : 0u, ti = y[j] == 0x80000000u ? 1u : 0u;
+                    s0 += a[j] + (ab | (ti & (p0 ^ alpha)));
+                    s1 += a[j] + (ab | (ti & (p1 ^ alpha)));
+                    p0 = ti ? 0u : (p0 ^ alpha ^ ab);
+                    p1 = ti ? 0u : (p1 ^ alpha ^ ab);
+                }
+                mine = s0;
+            }
+            // the parity in front of this lane: behind the last lane that holds a tie (its outgoing parity is absolute), or
+            // from I itself, times the xor of the lanes in between
+            const unsigned long long valm = __ballot(p0 == 1u);
+            const unsigned long long cm = tie_lanes & lt;
+            if (cm == 0ull) {
+                pin = (I & 1u) ^ (static_cast<uint32_t>(__popcll(valm & lt)) & 1u);
+            } else {
+                const int j = 63 - __clzll(static_cast<long long>(cm));
+                const unsigned long long after = lt & ~((2ull << j) - 1ull);
+                pin = (static_cast<uint32_t>(valm >> j) & 1u) ^ (static_cast<uint32_t>(__popcll(valm & after)) & 1u);
+            }
+            mine = pin ? s1 : mine;
+        }
+        mine = mine < (1u << 25) ? mine : (1u << 25);
+        const uint32_t incl = wave_scan_u32(mine);
+        const uint32_t limit = (1u << 24) - I;                  // I + increments reaching 2^24: the binade ends
+        const unsigned long long crossm = __ballot(incl >= limit);
+        if (crossm == 0ull) {
+            const uint32_t In = I + static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(incl), 63));   // < 2^24
+            s = __uint_as_float((e0 == 0 && In < (1u << 23)) ? In : ((static_cast<uint32_t>(es) << 23) | (In & 0x7fffffu)));
+            break;
+        }
+        // the first lane whose entries reach 2^24 walks them; the crossing entry is added in fp32, and everything up to it
+        // is done with (M = 0)
+        const int lc = __builtin_ctzll(crossm);
+        uint32_t run = I + (incl - mine), par = pin, hit = 8, run_at = 0;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const uint32_t alpha = a[j] & 1u, ab = y[j] > 0x80000000u ? 1u : 0u, ti = y[j] == 0x80000000u ? 1u : 0u;
+            const uint32_t inc = a[j] + (ab | (ti & (par ^ alpha)));
+            if (hit == 8 && run + inc >= (1u << 24)) {
+                hit = j;
+                run_at = run;
+            }
+            run += inc;
+            par = ti ? 0u : (par ^ alpha ^ ab);
+        }
+        uint32_t xm = M[0];
+        int xe = ex[0];
+#pragma unroll
+        for (int j = 1; j < 8; ++j) {
+            xm = hit == static_cast<uint32_t>(j) ? M[j] : xm;
+            xe = hit == static_cast<uint32_t>(j) ? ex[j] : xe;
+        }
+        const uint32_t hit_u = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(hit), lc));
+        const uint32_t run_u = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(run_at), lc));   // < 2^24
+        const uint32_t xm_u = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(xm), lc));
+        const uint32_t xe_u = static_cast<uint32_t>(__builtin_amdgcn_readlane(xe, lc));
+        // (M, ex) back to the float it came from: M carries the hidden bit exactly when the value is normal
+        const float x_u = __uint_as_float(xm_u >= (1u << 23) ? ((xe_u << 23) | (xm_u & 0x7fffffu)) : xm_u);
+        const float before = __uint_as_float((e0 == 0 && run_u < (1u << 23)) ? run_u : ((static_cast<uint32_t>(es) << 23) | (run_u & 0x7fffffu)));
+        s = __fadd_rn(before, x_u);
+        if (lane <= lc) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                if (lane < lc || static_cast<uint32_t>(j) <= hit) M[j] = 0u;
+        }
+    }
+    return s;
+}
+
+// development aid (BYZ_BULYAN_CLOCKS=1): re-scores, their batches, integer passes and cycles
+__device__ unsigned long long g_rescore_clock[8];
+
+// One wave; wave-uniform result; `ok` = false when the row holds a negative value (the passes assume distances: the caller
+// then takes the literal chain).  `head`: 64 floats of LDS for the first 64 entries' literal chain.
+__device__ __forceinline__ float reference_score_marked(const float* sorted_val, int n, int u, int take, int lane,
+                                                        float* __restrict__ head, bool clocks, bool& ok) {
+    typedef uint32_t u32x4u __attribute__((ext_vector_type(4), aligned(4)));
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    const uint32_t* vals = reinterpret_cast<const uint32_t*>(sorted_val + static_cast<int64_t>(u) * n);
+    const unsigned long long c_begin = clocks ? __builtin_readcyclecounter() : 0ull;
+    unsigned long long n_passes = 0, n_batches = 0, c_passes = 0;
+    struct Batch {
+        uint32_t x[8];
+    };
+    auto fetch = [&](Batch& b, int r0) __attribute__((always_inline)) {
+        int p = r0 + 8 * lane;
+        p = p < n ? p : n;   // eight dwords from here stay inside the table's padding; what lies past the row is masked below
+        const u32x4u lo = *reinterpret_cast<const u32x4u*>(vals + p), hi = *reinterpret_cast<const u32x4u*>(vals + p + 4);
+        b.x[0] = lo.x, b.x[1] = lo.y, b.x[2] = lo.z, b.x[3] = lo.w;
+        b.x[4] = hi.x, b.x[5] = hi.y, b.x[6] = hi.z, b.x[7] = hi.w;
+    };
+    float s = 0.0f;
+    int got = 0;
+    bool negative = false;
+    // returns true behind the last batch of the prefix
+    auto add = [&](const Batch& b, int r0) __attribute__((always_inline)) -> bool {
+        uint32_t xb[8];
+        uint32_t cnt = 0, top = 0;
+        const int inside = n - r0 - 8 * lane;   // entries of this lane that lie inside the row (<= 0 .. >= 8)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const bool live = j < inside && b.x[j] != kGoneBits;
+            xb[j] = live ? b.x[j] : 0u;
+            cnt += live ? 1u : 0u;
+            top = xb[j] > top ? xb[j] : top;
+        }
+        negative = negative || top > kGoneBits;   // a sign bit on a live entry
+        const uint32_t incl = wave_scan_u32(cnt);
+        const int total = __builtin_amdgcn_readlane(static_cast<int>(incl), 63);
+        if (got + total > take) {   // uniform: the prefix ends inside this batch
+            int room = take - got - static_cast<int>(incl - cnt);   // live entries of this lane that still belong to it
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                if (xb[j] != 0u || (j < inside && b.x[j] == 0u)) {   // live (a live +0.0 counts)
+                    if (room <= 0) xb[j] = 0u;   // past the prefix: + 0.0 (exact)
+                    --room;
+                }
+            }
+        }
+        got += total;
+        int start = 0;
+        if (r0 == 0) {
+            // the first 64 entries literally (the sum changes binade every other step there): lanes 0 .. 7 hold them
+            if (lane < 8) {
+                *reinterpret_cast<f32x4*>(head + 8 * lane) = f32x4{__uint_as_float(xb[0]), __uint_as_float(xb[1]), __uint_as_float(xb[2]), __uint_as_float(xb[3])};
+                *reinterpret_cast<f32x4*>(head + 8 * lane + 4) = f32x4{__uint_as_float(xb[4]), __uint_as_float(xb[5]), __uint_as_float(xb[6]), __uint_as_float(xb[7])};
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            const f32x4* src = reinterpret_cast<const f32x4*>(head);
+            f32x4 e[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) e[i] = src[i];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) s = __fadd_rn(__fadd_rn(__fadd_rn(__fadd_rn(s, e[i].x), e[i].y), e[i].z), e[i].w);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // read before the wave's next re-score overwrites it
+            __builtin_amdgcn_wave_barrier();
+            start = 64;
+        }
+        if (__ballot(negative) == 0ull) {
+            uint32_t M[8];
+            int ex[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const uint32_t e = xb[j] >> 23;
+                ex[j] = e != 0u ? static_cast<int>(e) : 1;
+                M[j] = e != 0u ? ((xb[j] & 0x7fffffu) | 0x800000u) : xb[j];
+                if (8 * lane + j < start) M[j] = 0u;
+            }
+            const unsigned long long c0 = clocks ? __builtin_readcyclecounter() : 0ull;
+            s = integer_passes(M, ex, s, lane, n_passes);
+            if (clocks) c_passes += __builtin_readcyclecounter() - c0;
+        }
+        ++n_batches;
+        return got >= take || r0 + 512 >= n;
+    };
+    Batch b0, b1, b2;
+    fetch(b0, 0);
+    fetch(b1, 512);
+    fetch(b2, 1024);
+    for (int r0 = 0;; r0 += 3 * 512) {
+        if (add(b0, r0)) break;
+        fetch(b0, r0 + 3 * 512);
+        if (add(b1, r0 + 512)) break;
+        fetch(b1, r0 + 4 * 512);
+        if (add(b2, r0 + 1024)) break;
+        fetch(b2, r0 + 5 * 512);
+    }
+    ok = __ballot(negative) == 0ull;
+    if (clocks && lane == 0) {
+        atomicAdd(&g_rescore_clock[0], 1ull);
+        atomicAdd(&g_rescore_clock[1], n_batches);
+        atomicAdd(&g_rescore_clock[2], n_passes);
+        atomicAdd(&g_rescore_clock[3], __builtin_readcyclecounter() - c_begin);
+        atomicAdd(&g_rescore_clock[4], c_passes);
+    }
+    return s;
+}
+
 struct GridDecision {
     int mode;        // 0 winner known, 1 round 2, 2 no candidate, 3 exchange timed out
     int winner;
@@ -433,10 +682,10 @@ struct GridDecision {
 
 __global__ __launch_bounds__(kGridThreads) void bulyan_grid_kernel(
     const float* __restrict__ dist, int n, int theta, int drop, int users_count, int corrupted,
-    const uint16_t* __restrict__ sorted_idx, const uint16_t* __restrict__ rank_t, const float* __restrict__ sorted_val,
+    const uint16_t* __restrict__ sorted_idx, const uint16_t* __restrict__ rank_t, float* sorted_val,
     const double* __restrict__ row_total, const double* __restrict__ row_top, const int32_t* __restrict__ cls,
     unsigned long long* __restrict__ xchg, float band_scale, int32_t* __restrict__ selection,
-    int32_t* __restrict__ status, int32_t* __restrict__ rescored) {
+    int32_t* __restrict__ status, int32_t* __restrict__ rescored, int rescore_mode) {
     __shared__ __attribute__((aligned(16))) float rescore_stage[kGridThreads / 64][512];
     __shared__ Candidate slots[kGridThreads / 64];
     __shared__ double second_slots[kGridThreads / 64];
@@ -457,6 +706,9 @@ __global__ __launch_bounds__(kGridThreads) void bulyan_grid_kernel(
     const int my_class = alive ? cls[u] : 0;
     const int my_pos = visit_position(u);
     int n_rescored = 0;
+    // rescore_mode >= 1: the table of ascending values carries the removals (-0.0); first of all the row's own diagonal
+    const bool marked = rescore_mode >= 1;
+    if (marked && alive) sorted_val[static_cast<int64_t>(u) * n + rank_t[static_cast<int64_t>(u) * n + u]] = __uint_as_float(kGoneBits);
     __syncthreads();
 
     // exchange slots: [parity][kind A, B, R][workgroup]
@@ -575,7 +827,10 @@ __global__ __launch_bounds__(kGridThreads) void bulyan_grid_kernel(
             Candidate r{static_cast<double>(kKrumInit), 0x7fffffff, -1};
             for (int k = wave; k < n_lead; k += kGridThreads / 64) {
                 const int row = wg * kGridThreads + leaders[k];
-                const float s32 = reference_score_plain(sorted_val, sorted_idx, removed, n, row, take, lane, rescore_stage[wave]);
+                float s32 = 0.0f;
+                bool done = false;
+                if (marked) s32 = reference_score_marked(sorted_val, n, row, take, lane, rescore_stage[wave], rescore_mode >= 2, done);
+                if (!done) s32 = reference_score_plain(sorted_val, sorted_idx, removed, n, row, take, lane, rescore_stage[wave]);
                 if (s32 < kKrumInit) {
                     Candidate o{static_cast<double>(s32), visit_position(row), row};
                     if (better(o, r)) r = o;
@@ -627,6 +882,7 @@ __global__ __launch_bounds__(kGridThreads) void bulyan_grid_kernel(
             } else {
                 const double dw = static_cast<double>(dist[static_cast<int64_t>(w) * n + u]);   // symmetric: d[w][u] == d[u][w]
                 const int r = rank_t[static_cast<int64_t>(w) * n + u];                          // rank of column w inside row u
+                if (marked) sorted_val[static_cast<int64_t>(u) * n + r] = __uint_as_float(kGoneBits);
                 tot -= dw;
                 if (drop > 0 && r >= ptr) {
                     // w was one of this row's `drop` largest: the largest survivor below the boundary joins them
@@ -671,7 +927,7 @@ int launch_row_sort(byz_ctx* ctx, const float* dist, int64_t n, int64_t prefix_l
         BYZ_TRY(ctx->rank_t.ensure(static_cast<size_t>(n) * n * sizeof(uint16_t)));
         BYZ_TRY(ctx->row_total.ensure(static_cast<size_t>(n) * sizeof(double)));
         BYZ_TRY(ctx->row_top.ensure(static_cast<size_t>(n) * sizeof(double)));
-        BYZ_TRY(ctx->sorted_val.ensure(static_cast<size_t>(n) * n * sizeof(float)));
+        BYZ_TRY(ctx->sorted_val.ensure(static_cast<size_t>(n) * n * sizeof(float) + 64));   // (+ 64: a re-score reads 8 dwords per lane)
     }
     const size_t lds = static_cast<size_t>(n_pad) * 8 + static_cast<size_t>(threads) * 8;
     KernelTimer t(ctx, BYZ_K_ROW_SORT, stream);
@@ -714,6 +970,17 @@ int launch_bulyan_loop(byz_ctx* ctx, const float* dist, int64_t n, int64_t theta
     if (const char* e = std::getenv("BYZ_BULYAN_BAND")) {
         if (std::strcmp(e, "rigorous") != 0) band_scale = static_cast<float>(std::atof(e));
     }
+    // BYZ_BULYAN_RESCORE=plain: the literal chain of additions with liveness from the bitmap (round 2: the form the C oracle
+    // was checked against); default: the marked table and the integer passes -- the same bits
+    int rescore_mode = 1;
+    if (const char* e = std::getenv("BYZ_BULYAN_RESCORE")) rescore_mode = std::strcmp(e, "plain") == 0 ? 0 : 1;
+    const char* clocks_env = std::getenv("BYZ_BULYAN_CLOCKS");
+    const bool clocks = rescore_mode != 0 && clocks_env != nullptr && std::atoi(clocks_env) != 0;
+    if (clocks) {
+        rescore_mode = 2;
+        const unsigned long long zero[8] = {0};
+        BYZ_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_rescore_clock), zero, sizeof(zero)));
+    }
     BYZ_HIP(hipMemsetAsync(ctx->xchg.ptr, 0, static_cast<size_t>(2 * 3 * kGridMaxWgs) * sizeof(unsigned long long), stream));
     BYZ_HIP(hipMemsetAsync(status_dev, 0, 2 * sizeof(int32_t), stream));
     KernelTimer t(ctx, BYZ_K_BULYAN_LOOP, stream);
@@ -725,8 +992,17 @@ int launch_bulyan_loop(byz_ctx* ctx, const float* dist, int64_t n, int64_t theta
     bulyan_grid_kernel<<<n_wgs, kGridThreads, 0, stream>>>(
         dist, (int)n, (int)theta, (int)drop_count, (int)users_count, (int)corrupted, ctx->sorted_idx.as<uint16_t>(),
         ctx->rank_t.as<uint16_t>(), ctx->sorted_val.as<float>(), ctx->row_total.as<double>(), ctx->row_top.as<double>(), cls,
-        ctx->xchg.as<unsigned long long>(), band_scale, selection_dev, status_dev, status_dev + 1);
-    return check_launch("bulyan_grid_kernel");
+        ctx->xchg.as<unsigned long long>(), band_scale, selection_dev, status_dev, status_dev + 1, rescore_mode);
+    BYZ_TRY(check_launch("bulyan_grid_kernel"));
+    if (clocks) {
+        unsigned long long c[8];
+        BYZ_HIP(hipStreamSynchronize(stream));
+        BYZ_HIP(hipMemcpyFromSymbol(c, HIP_SYMBOL(g_rescore_clock), sizeof(c)));
+        const double r = c[0] ? static_cast<double>(c[0]) : 1.0;
+        std::fprintf(stderr, "bulyan re-scores: %llu; per re-score: %.1f batches, %.1f integer passes, %.0f cycles (%.0f inside the passes)\n",
+                     c[0], c[1] / r, c[2] / r, c[3] / r, c[4] / r);
+    }
+    return BYZ_OK;
 }
 
 }  // namespace byz

@@ -1,4 +1,4 @@
-"""Same-box A/B of the Bulyan loop's re-score (BYZ_BULYAN_RESCORE=plain | pair; torch-free GPU probe): time of the whole loop
+"""Same-box A/B of the Bulyan loop's re-score (BYZ_BULYAN_RESCORE=plain | marked; torch-free GPU probe): time of the whole loop
 (row sorts included) and whether the selections agree pick for pick -- `plain` is the form the C oracle was checked against."""
 import os
 import sys
@@ -13,7 +13,7 @@ from test_gpu_scale import point_distances                             # noqa: E
 
 
 def main():
-    modes = sys.argv[1].split(',') if len(sys.argv) > 1 else ['plain', 'pair']
+    modes = sys.argv[1].split(',') if len(sys.argv) > 1 else ['plain', 'marked']
     sizes = [int(x) for x in sys.argv[2].split(',')] if len(sys.argv) > 2 else [4000, 10000]
     eng = Engine(0)
     for n in sizes:

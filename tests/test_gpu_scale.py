@@ -114,6 +114,53 @@ def test_bulyan_selection_on_concentrated_scores(eng, n, dim):
           % (sum(a != b for a, b in zip(ideal_sel, want)), len(want)))
 
 
+def lattice_distances(seed, n, bits=9):
+    """Distances on a coarse binary lattice (integer multiples of 2^-bits, many of them equal): a row's sequential fp32 sum
+    meets remainders of exactly half an ulp -- round-to-even ties -- at every other step, and whole groups of equal scores."""
+    rng = np.random.default_rng(seed)
+    dist = (rng.integers(1 << 6, 1 << 12, (n, n)).astype(np.float32) * np.float32(2.0 ** -bits))
+    dist = np.minimum(dist, dist.T)
+    np.fill_diagonal(dist, np.inf)
+    return dist
+
+
+@pytest.mark.parametrize('n,family', [(333, 'lattice'), (1500, 'lattice'), (3000, 'lattice'), (1500, 'points'), (1500, 'ties'),
+                                      (2049, 'zeros'), (700, 'negative')])
+def test_bulyan_rescore_integer_passes_are_the_literal_chain(eng, monkeypatch, n, family):
+    """The default re-score evaluates the reference's sequential fp32 sum in integer passes over a table marked with the
+    removals (csrc/select.hip); BYZ_BULYAN_RESCORE=plain is the literal chain of additions over bitmap-tested entries.
+    Same selections, pick for pick -- on round-to-even ties at every other addition (lattice), exact-zero distances
+    between live rows, and a matrix with negative entries (which the passes hand back to the chain) -- and
+    both are the C oracle's (the reference's loop)."""
+    f = int(n * MAL_PROP)
+    if family == 'lattice':
+        dist = lattice_distances(4400 + n, n)
+    elif family == 'points':
+        dist = point_distances(4400 + n, n)
+    elif family == 'ties':
+        dist = point_distances(4400 + n, n, identical=f)
+    elif family == 'zeros':           # groups of coincident honest points: live +0.0 entries inside every prefix
+        dist = point_distances(4400 + n, n)
+        grp = np.arange(n) // 3
+        same = grp[:, None] == grp[None, :]
+        dist[same] = 0.0
+        np.fill_diagonal(dist, np.inf)
+    else:
+        dist = point_distances(4400 + n, n)
+        dist[5, 9] = dist[9, 5] = -0.25
+        dist[40, 41] = dist[41, 40] = -0.0
+    monkeypatch.setenv('BYZ_BULYAN_RESCORE', 'plain')
+    plain = eng.bulyan_select(dist, n, f).tolist()
+    rescored = eng.bulyan_rescored()
+    monkeypatch.delenv('BYZ_BULYAN_RESCORE')
+    got = eng.bulyan_select(dist, n, f).tolist()
+    assert eng.bulyan_rescored() == rescored
+    assert got == plain, 'first difference at pick %d' % next(i for i, (a, b) in enumerate(zip(got, plain)) if a != b)
+    if family != 'negative':          # (the oracle restates the reference for distances, which are never negative)
+        check_selection(dist, n, f, got)
+    print('%s N=%d: %d rows re-scored over %d picks' % (family, n, rescored, n - 2 * f))
+
+
 # ---- end to end at configs[3]'s N ------------------------------------------------------------------------
 def test_config4_bulyan_end_to_end_n4000(eng):
     """Bulyan N = 4000, f = 960 on a D = 4096 slice: Gram distances (bf16 x 3 split MFMA, chunk-free schedule),
