@@ -13,7 +13,7 @@ from test_gpu_scale import point_distances                             # noqa: E
 
 
 def main():
-    modes = sys.argv[1].split(',') if len(sys.argv) > 1 else ['plain', 'marked']
+    modes = sys.argv[1].split(',') if len(sys.argv) > 1 else ['plain', 'marked', 'coop']
     sizes = [int(x) for x in sys.argv[2].split(',')] if len(sys.argv) > 2 else [4000, 10000]
     eng = Engine(0)
     for n in sizes:
