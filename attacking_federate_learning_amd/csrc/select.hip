@@ -338,18 +338,12 @@ __device__ __forceinline__ bool gather_granule_pair(const unsigned long long* sl
 // (zeros for removed columns and past the prefix: adding +0.0 is exact) go to LDS in order, and every lane of the wave adds
 // them up left to right from broadcast reads -- the reference's loop, literally.
 //
-// Two cleverer forms were built and measured against this one, selections identical in every case (profiles/r02q .. r02t,
-// profiles/r03a, r03k): round 2's integer rule per 64 entries (while the running sum stays inside one binade it is a
-// multiple of q = ulp and fl(s + x) = s + q rn(x / q) barring exact ties, so a chunk adds q * sum(rn(x_i / q)) in any
-// order; everything else ran as a 63-step DPP chain), and round 3's version of it per 512 entries with a checkpoint behind
-// every row's first 512 entries (invalidated when a removed winner ranks inside that prefix).  At N = 10,000 they take
-// 260 / 254 / 234 ms against this form's 253; at N = 4000 40.6 / -- / 41.6 against 36.7.  Round 3's counters say why the
-// arithmetic does not matter: a 7600-entry re-score is ~76,000 cycles of ONE wave alone on its SIMD, of which ~2000 per
-// 512 entries go into loading the entries and testing their columns against the `removed` bitmap, ~1100 into a clean
-// integer batch, and ~5000 into each of the six batches per chain that hold a tie or a binade crossing -- dependent
-// instructions at ten or more cycles apiece whatever they compute.  What would help is several waves per contender (the
-// liveness step of later batches while the sum runs over earlier ones); that restructuring is not done.  Both forms were
-// removed again; this one is the only re-score.
+// Since round 3 this is the COMPARISON (BYZ_BULYAN_RESCORE=plain) and the fallback for rows the integer passes refuse (a
+// sign bit on a live entry); the default re-score is reference_score_marked below.  Two earlier attempts to beat this form
+// were measured, selections identical in every case (profiles/r02q .. r02t, r03a, r03k): round 2's integer rule per 64
+// entries with every chunk that held a tie or a binade crossing falling back to a 63-step DPP chain, and a version per 512
+// entries with a checkpoint behind every row's first 512 entries: 260 / 234 ms at N = 10,000 against this form's 253.  What
+// they lacked is what the passes below have: ties and crossings handled INSIDE the parallel pass, and no staging at all.
 __device__ __forceinline__ float reference_score_plain(const float* __restrict__ sorted_val, const uint16_t* __restrict__ sorted_idx,
                                                        const uint32_t* removed, int n, int u, int take, int lane,
                                                        float* __restrict__ stage) {
