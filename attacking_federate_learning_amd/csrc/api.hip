@@ -230,7 +230,7 @@ int byz_ctx_reserve(byz_ctx* ctx, int64_t n_rows, int64_t n_cols) {
     BYZ_TRY(ctx->sorted_idx.ensure(static_cast<size_t>(n_rows) * n_rows * sizeof(uint16_t)));
     BYZ_TRY(ctx->rank_t.ensure(static_cast<size_t>(n_rows) * n_rows * sizeof(uint16_t)));
     BYZ_TRY(ctx->row_total.ensure(static_cast<size_t>(n_rows) * sizeof(double)));
-    BYZ_TRY(ctx->row_top.ensure(static_cast<size_t>(n_rows) * sizeof(double)));
+    BYZ_TRY(ctx->row_top.ensure(static_cast<size_t>(2 * n_rows) * sizeof(double)));
     BYZ_TRY(ctx->stage_out.ensure(static_cast<size_t>(n_cols) * 3 * sizeof(float)));
     BYZ_TRY(ctx->pinned.ensure(static_cast<size_t>(n_rows) * sizeof(int32_t) + 64));
     if (krum_small_applies(n_rows, n_cols)) BYZ_TRY(reserve_small_workspaces(ctx));

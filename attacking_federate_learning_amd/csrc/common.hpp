@@ -127,7 +127,7 @@ struct byz_ctx {
     byz::Buffer sorted_val;      // n x n fp32: every row's distances in ascending order (the reference-arithmetic re-score)
     byz::Buffer rank_t;          // n x n uint16: rank_t[w][u] = rank of column w in row u
     byz::Buffer row_total;       // n fp64: sum of a row's finite distances
-    byz::Buffer row_top;         // n fp64: sum of a row's largest `drop` distances
+    byz::Buffer row_top;         // n fp64: sum of a row's largest `drop` finite distances; then n counts of non-finite ones
     byz::Buffer scores;          // n fp32 Krum scores
     bool redo_valid = false;     // the last trimmed mean went through the ring selection (redo_tiles[0] is its count)
     byz::Buffer redo_tiles;      // trimmed mean: tiles the ring selection handed to the general kernel (count first)

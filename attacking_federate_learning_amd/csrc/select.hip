@@ -61,8 +61,11 @@ __global__ void row_sort_kernel(const float* __restrict__ dist, int n, int n_pad
         if (c >= n) {
             key = ~0ull;
         } else {
-            const float d = (c == u) ? __builtin_inff() : row[c];  // self entry sorts behind every real one
-            key = (static_cast<unsigned long long>(ordered_bits(d)) << 32) | static_cast<unsigned>(c);
+            // the self entry sorts behind every real one, +inf and NaN included (a client with a non-finite gradient)
+            // NaN of either sign: behind +inf (the Gram identity makes inf - inf of an infinite gradient, whose sign is anybody's)
+            const float d = row[c];
+            const uint32_t ob = (c == u) ? 0xffffffffu : (d != d ? 0xfffffffeu : ordered_bits(d));
+            key = (static_cast<unsigned long long>(ob) << 32) | static_cast<unsigned>(c);
         }
         keys[c] = key;
     }
@@ -83,8 +86,8 @@ __global__ void row_sort_kernel(const float* __restrict__ dist, int n, int n_pad
             __syncthreads();
         }
     }
-    // A self distance of +inf can tie with a genuine +inf/NaN entry only for poisoned input; otherwise the
-    // real neighbours occupy ranks 0 .. n-2.
+    // The real neighbours occupy ranks 0 .. n-2 (a NaN with an all-ones payload could tie with the self entry's key; the
+    // sums below skip the self entry by its column, not by its rank).
 
     if (tid == 0) {
         float s = 0.0f;
@@ -93,19 +96,25 @@ __global__ void row_sort_kernel(const float* __restrict__ dist, int n, int n_pad
     }
 
     if (TABLES) {
-        double tot = 0.0, top = 0.0;
+        // tot / top are sums over the FINITE distances; the non-finite ones (+inf, NaN: a client whose gradient is not
+        // finite) sort last and are counted -- a row's score is finite exactly while they all lie among its `drop` largest
+        // entries, which is what the reference's sorted(...)[:k] sum gives for +inf (defences.py:33-34)
+        double tot = 0.0, top = 0.0, bad = 0.0;
         const int first_top = n - 1 - drop;
         for (int r = tid; r < n; r += nt) {
             const unsigned long long key = keys[r];
             const int c = static_cast<int>(key & 0xffffffffu);
             sorted_idx[static_cast<int64_t>(u) * n + r] = static_cast<uint16_t>(c);
-            const float v = from_ordered_bits(static_cast<uint32_t>(key >> 32));
+            const float v = c == u ? __builtin_inff() : from_ordered_bits(static_cast<uint32_t>(key >> 32));
             sorted_val[static_cast<int64_t>(u) * n + r] = v == 0.0f ? 0.0f : v;   // never -0.0: that bit pattern marks a removed entry
             rank_t[static_cast<int64_t>(c) * n + u] = static_cast<uint16_t>(r);
-            if (r < n - 1) {
-                const double v = static_cast<double>(from_ordered_bits(static_cast<uint32_t>(key >> 32)));
-                tot += v;
-                if (r >= first_top) top += v;
+            if (c != u) {
+                if (__builtin_fabsf(v) <= 3.4028234663852886e38f) {
+                    tot += static_cast<double>(v);
+                    if (r >= first_top) top += static_cast<double>(v);
+                } else {
+                    bad += 1.0;
+                }
             }
         }
         // fixed-shape tree: identical sorted rows reduce to identical sums
@@ -124,6 +133,14 @@ __global__ void row_sort_kernel(const float* __restrict__ dist, int n, int n_pad
             __syncthreads();
         }
         if (tid == 0) row_top[u] = scratch[0];
+        __syncthreads();
+        scratch[tid] = bad;
+        __syncthreads();
+        for (int s = nt >> 1; s > 0; s >>= 1) {
+            if (tid < s) scratch[tid] += scratch[tid + s];
+            __syncthreads();
+        }
+        if (tid == 0) row_top[n + u] = scratch[0];   // the count of non-finite entries rides behind the n sums
     }
 }
 
@@ -713,6 +730,7 @@ __global__ __launch_bounds__(kGridThreads) void bulyan_grid_kernel(
     bool alive = u < n;
     double tot = alive ? row_total[u] : 0.0;
     double top = (alive && drop > 0) ? row_top[u] : 0.0;
+    int bad = alive ? static_cast<int>(row_top[n + u]) : 0;   // live non-finite distances of this row
     int ptr = n - 1 - drop;
     const int my_class = alive ? cls[u] : 0;
     const int my_pos = visit_position(u);
@@ -740,7 +758,8 @@ __global__ __launch_bounds__(kGridThreads) void bulyan_grid_kernel(
                                    : (live_entries + keep > 0 ? live_entries + keep : 0);
         // ---- 1. the workgroup's best row, and its best score outside that row's twin class
         const double score = tot - top;
-        const bool candidate = alive && score < static_cast<double>(kKrumInit);   // false for NaN
+        // (a non-finite distance inside the summed prefix makes the reference's score inf / NaN: never below 1e20)
+        const bool candidate = alive && bad <= drop && score < static_cast<double>(kKrumInit);   // false for NaN
         Candidate c{static_cast<double>(kKrumInit), 0x7fffffff, -1};
         if (candidate) c = Candidate{score, my_pos, u};
         const Candidate best = block_best(c, slots);
@@ -891,7 +910,10 @@ __global__ __launch_bounds__(kGridThreads) void bulyan_grid_kernel(
             if (u == w) {
                 alive = false;
             } else {
-                const double dw = static_cast<double>(dist[static_cast<int64_t>(w) * n + u]);   // symmetric: d[w][u] == d[u][w]
+                const float dwf = dist[static_cast<int64_t>(w) * n + u];   // symmetric: d[w][u] == d[u][w]
+                const bool dw_finite = __builtin_fabsf(dwf) <= 3.4028234663852886e38f;
+                const double dw = dw_finite ? static_cast<double>(dwf) : 0.0;
+                if (!dw_finite) --bad;
                 const int r = rank_t[static_cast<int64_t>(w) * n + u];                          // rank of column w inside row u
                 if (marked) sorted_val[static_cast<int64_t>(u) * n + r] = __uint_as_float(kGoneBits);
                 tot -= dw;
@@ -905,7 +927,10 @@ __global__ __launch_bounds__(kGridThreads) void bulyan_grid_kernel(
                         if (!((removed[col >> 5] >> (col & 31)) & 1u)) break;
                         --p;
                     }
-                    if (p >= 0) top += static_cast<double>(dist[static_cast<int64_t>(u) * n + order[p]]);
+                    if (p >= 0) {
+                        const float joins = dist[static_cast<int64_t>(u) * n + order[p]];
+                        if (__builtin_fabsf(joins) <= 3.4028234663852886e38f) top += static_cast<double>(joins);
+                    }
                     ptr = p;
                 }
             }
@@ -937,7 +962,7 @@ int launch_row_sort(byz_ctx* ctx, const float* dist, int64_t n, int64_t prefix_l
         BYZ_TRY(ctx->sorted_idx.ensure(static_cast<size_t>(n) * n * sizeof(uint16_t)));
         BYZ_TRY(ctx->rank_t.ensure(static_cast<size_t>(n) * n * sizeof(uint16_t)));
         BYZ_TRY(ctx->row_total.ensure(static_cast<size_t>(n) * sizeof(double)));
-        BYZ_TRY(ctx->row_top.ensure(static_cast<size_t>(n) * sizeof(double)));
+        BYZ_TRY(ctx->row_top.ensure(static_cast<size_t>(2 * n) * sizeof(double)));   // sums, then the counts of non-finite entries
         BYZ_TRY(ctx->sorted_val.ensure(static_cast<size_t>(n) * n * sizeof(float) + 64));   // (+ 64: a re-score reads 8 dwords per lane)
     }
     const size_t lds = static_cast<size_t>(n_pad) * 8 + static_cast<size_t>(threads) * 8;

@@ -337,6 +337,36 @@ def test_small_krum_path_covers_selection_and_bulyan(eng, monkeypatch, golden):
         assert eng.krum(c['G'], n, f, return_index=True) == int(c['index'])
 
 
+@pytest.mark.parametrize('n,d,f', [(40, 500, 9), (100, 3000, 24), (300, 2000, 70), (700, 1200, 168)])
+def test_clients_with_infinite_gradients_are_never_chosen(eng, n, d, f):
+    """Byzantine clients may send anything, +inf included.  In the reference every distance to such a client is +inf
+    (np.linalg.norm of a difference with an infinite entry, defences.py:20), sorts last in every row and stays outside the
+    summed prefix, and the client's own score is inf: Krum and Bulyan carry on with the finite clients.  Here the Gram identity
+    turns those distances into NaN, which sort last just the same: same Krum index, same Bulyan selection and vector as the
+    oracle on the same gradients (N <= 128: csrc/krum_small.hip; above: gram.hip + select.hip, whose running sums count the
+    non-finite entries instead of adding them)."""
+    g = scaled(5100 + n, n, d)
+    for bad in (1, n // 3, n - 2):
+        g[bad, 7] = np.inf
+        g[bad, d - 1] = -np.inf
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        want_idx = faithful.krum(g, n, f, return_index=True)
+    assert eng.krum(g, n, f, return_index=True) == want_idx
+    # Bulyan on a given matrix: the reference's loop on the engine's own distances, with NaN read as the +inf the reference
+    # has there (the Gram identity's last bits differ from np.linalg.norm's, so the comparison is on ONE matrix)
+    dist = eng.pairwise_distances(g).numpy()
+    assert not np.isfinite(dist[1, 0]) and not np.isfinite(dist[0, n - 2])
+    want_sel = faithful.bulyan_selection(np.where(np.isnan(dist), np.float32(np.inf), dist), n, f)
+    assert eng.bulyan_select(dist, n, f).tolist() == list(want_sel)
+    assert not ({1, n // 3, n - 2} & set(want_sel))
+    # ... and end to end: theta distinct finite clients, and the reference's trimmed mean over them
+    out, sel = eng.bulyan(g, n, f, return_selection=True)
+    sel = sel.tolist()
+    assert len(set(sel)) == n - 2 * f and not ({1, n // 3, n - 2} & set(sel))
+    assert close(out, faithful.trimmed_mean(g[sel], len(sel), 2 * f))
+
+
 @pytest.mark.parametrize('n,f', [(2, 0), (5, 1), (64, 15), (100, 24), (128, 31), (333, 80), (1000, 240)])
 def test_krum_selection_is_bit_exact_given_distances(eng, n, f):
     rng = np.random.default_rng(2000 + n)

@@ -125,13 +125,14 @@ def lattice_distances(seed, n, bits=9):
 
 
 @pytest.mark.parametrize('n,family', [(333, 'lattice'), (1500, 'lattice'), (3000, 'lattice'), (1500, 'points'), (1500, 'ties'),
-                                      (2049, 'zeros'), (700, 'negative')])
+                                      (2049, 'zeros'), (700, 'negative'), (700, 'inf'), (1500, 'nan')])
 def test_bulyan_rescore_integer_passes_are_the_literal_chain(eng, monkeypatch, n, family):
     """The default re-score evaluates the reference's sequential fp32 sum in integer passes over a table marked with the
     removals (csrc/select.hip); BYZ_BULYAN_RESCORE=plain is the literal chain of additions over bitmap-tested entries.
     Same selections, pick for pick -- on round-to-even ties at every other addition (lattice), exact-zero distances
-    between live rows, and a matrix with negative entries (which the passes hand back to the chain) -- and
-    both are the C oracle's (the reference's loop)."""
+    between live rows, a matrix with negative entries (which the passes hand back to the chain), and clients at an infinite /
+    NaN distance from everybody (non-finite gradients: they sort last and are never picked) -- and both are the C oracle's
+    (the reference's loop)."""
     f = int(n * MAL_PROP)
     if family == 'lattice':
         dist = lattice_distances(4400 + n, n)
@@ -145,6 +146,12 @@ def test_bulyan_rescore_integer_passes_are_the_literal_chain(eng, monkeypatch, n
         same = grp[:, None] == grp[None, :]
         dist[same] = 0.0
         np.fill_diagonal(dist, np.inf)
+    elif family in ('inf', 'nan'):    # clients whose gradients are not finite: every distance to them is +inf / NaN
+        dist = point_distances(4400 + n, n)
+        for bad in (17, 300, n - 2):
+            dist[bad, :] = np.inf if family == 'inf' else np.nan
+            dist[:, bad] = np.inf if family == 'inf' else np.nan
+        np.fill_diagonal(dist, np.inf)
     else:
         dist = point_distances(4400 + n, n)
         dist[5, 9] = dist[9, 5] = -0.25
@@ -156,7 +163,9 @@ def test_bulyan_rescore_integer_passes_are_the_literal_chain(eng, monkeypatch, n
     got = eng.bulyan_select(dist, n, f).tolist()
     assert eng.bulyan_rescored() == rescored
     assert got == plain, 'first difference at pick %d' % next(i for i, (a, b) in enumerate(zip(got, plain)) if a != b)
-    if family != 'negative':          # (the oracle restates the reference for distances, which are never negative)
+    if family in ('inf', 'nan'):      # such a client is never picked while finite ones remain (the reference's scores are inf)
+        assert len(set(got)) == n - 2 * f and not ({17, 300, n - 2} & set(got))
+    if family not in ('negative', 'nan'):   # (the oracle restates the reference, whose sorted() is undefined with NaN keys)
         check_selection(dist, n, f, got)
     print('%s N=%d: %d rows re-scored over %d picks' % (family, n, rescored, n - 2 * f))
 
