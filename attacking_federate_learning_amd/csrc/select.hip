@@ -43,6 +43,9 @@ __device__ __forceinline__ float from_ordered_bits(uint32_t o) {
 }
 __device__ __forceinline__ int visit_position(int u) { return u == 0 ? 1 : (u == 1 ? 0 : u); }
 
+// (defined with the Bulyan re-score below; row_sort_kernel's Krum score uses it too)
+__device__ __forceinline__ float integer_passes(uint32_t (&M)[8], const int (&ex)[8], float s, int lane, unsigned long long& n_passes);
+
 // ---------------------------------------------------------------------------------------------------
 template <bool TABLES>
 __global__ void row_sort_kernel(const float* __restrict__ dist, int n, int n_pad, int prefix_len, int drop,
@@ -89,10 +92,47 @@ __global__ void row_sort_kernel(const float* __restrict__ dist, int n, int n_pad
     // The real neighbours occupy ranks 0 .. n-2 (a NaN with an all-ones payload could tie with the self entry's key; the
     // sums below skip the self entry by its column, not by its rank).
 
-    if (tid == 0) {
+    // The Krum score: the sequential fp32 sum of the first prefix_len sorted values, exactly as Python's sum() forms it
+    // (defences.py:33-34).  One thread walking the prefix out of LDS took ~70 cycles per entry -- at N = 10,000 more than the
+    // sort itself; wave 0 now adds the first 512 entries as a chain from broadcast reads and the rest in integer passes
+    // (integer_passes below: the same bits).  A prefix that holds a sign bit, or a sum that leaves the finite range, is summed
+    // again the old way.
+    if (tid < 64 && prefix_len > 0) {
+        const int lane = tid;
         float s = 0.0f;
-        for (int r = 0; r < prefix_len; ++r) s = __fadd_rn(s, from_ordered_bits(static_cast<uint32_t>(keys[r] >> 32)));
-        scores[u] = s;
+        const int head_n = prefix_len < 512 ? prefix_len : 512;
+        for (int r0 = 0; r0 < head_n; r0 += 16) {
+            float v[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int r = r0 + i;
+                v[i] = r < head_n ? from_ordered_bits(static_cast<uint32_t>(keys[r] >> 32)) : 0.0f;   // (+ 0.0 is exact)
+            }
+#pragma unroll
+            for (int i = 0; i < 16; ++i) s = __fadd_rn(s, v[i]);
+        }
+        bool odd = false;   // a negative value, or -0.0: the passes take non-negative distances
+        for (int r = lane; r < head_n; r += 64) odd = odd || (from_ordered_bits(static_cast<uint32_t>(keys[r] >> 32)) < 0.0f);
+        unsigned long long n_passes = 0;
+        for (int r0 = 512; r0 < prefix_len && __ballot(odd) == 0ull; r0 += 512) {
+            uint32_t M[8];
+            int ex[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int r = r0 + 8 * lane + j;
+                const uint32_t xb = r < prefix_len ? __float_as_uint(from_ordered_bits(static_cast<uint32_t>(keys[r < n_pad ? r : n_pad - 1] >> 32))) : 0u;
+                odd = odd || (xb >> 31) != 0u;
+                const uint32_t e = (xb >> 23) & 0xffu;
+                ex[j] = e != 0u ? static_cast<int>(e) : 1;
+                M[j] = e != 0u ? ((xb & 0x7fffffu) | 0x800000u) : (xb & 0x7fffffu);
+            }
+            if (__ballot(odd) == 0ull) s = integer_passes(M, ex, s, lane, n_passes);
+        }
+        if (__ballot(odd) != 0ull || !(__builtin_fabsf(s) <= 3.4028234663852886e38f)) {
+            s = 0.0f;
+            for (int r = 0; r < prefix_len; ++r) s = __fadd_rn(s, from_ordered_bits(static_cast<uint32_t>(keys[r] >> 32)));
+        }
+        if (tid == 0) scores[u] = s;
     }
 
     if (TABLES) {
