@@ -164,7 +164,8 @@ struct ColumnPlan {   // written by the search (the first lane of the column's g
 template <int W, int RPW, int B, int SR, int LS, bool EXACT, bool PIPE>
 __global__ __launch_bounds__(64 * W, 4) void window_lean_kernel(const float* __restrict__ G, int n_rows, int64_t n_cols,
                                                                 int64_t ld, const int32_t* __restrict__ row_index, int keep,
-                                                                float* __restrict__ out, int32_t* __restrict__ redo) {
+                                                                float* __restrict__ out, int32_t* __restrict__ redo,
+                                                                int by_xcd) {
     constexpr int T = 64 * W;
     constexpr int NCW = kTileCols / W;          // columns an owner wave resolves: 4, 2 or 1
     constexpr int CAP = 64 * SR;
@@ -187,7 +188,17 @@ __global__ __launch_bounds__(64 * W, 4) void window_lean_kernel(const float* __r
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = sgpr(tid >> 6);
     const int rr = lane >> 2, q = lane & 3;
-    const int64_t tile = blockIdx.x;
+    // Workgroup -> tile.  A tile's rows are 64-byte segments, half a 128-byte line each, and consecutive workgroups go to
+    // different XCDs (each with its own L2): with tile = blockIdx.x the two halves of every line are fetched by two L2s at
+    // different times.  Instead XCD x (blockIdx.x & 7, an affinity the dispatcher follows but does not promise: only speed
+    // depends on it) takes the x-th eighth of the tiles in order, so that neighbouring tiles are neighbours in time on ONE L2.
+    // Same-box A/B (scripts/tm_ab.py BYZ_TM_LEAN_XCD 0,1): 1000 rows 0.375 -> 0.354 ms per 2^18 columns, 2080 rows 0.471 ->
+    // 0.410 per 2^17, 5200 rows 0.766 -> 0.625 per 2^16; groups of 2 / 4 / 16 / 64 tiles per XCD instead of eighths: worse or equal.
+    int64_t tile = blockIdx.x;
+    if (by_xcd != 0) {
+        const int64_t per = gridDim.x >> 3;
+        if (tile < (per << 3)) tile = (tile & 7) * per + (tile >> 3);
+    }
     const int64_t c_base = tile * kTileCols;
     const float pinf = __builtin_inff();
     const int64_t stamp_tile = tile - (g_lean_timing - 1);   // g_lean_timing = 1 + first stamped tile (0: off)
@@ -698,6 +709,8 @@ int launch_lean_shape(const float* G, int64_t n_rows, int64_t n_cols, int64_t ld
     if (timing) BYZ_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_lean_timing), &timing, sizeof(int)));
     // PIPE: request the tile's rows under the range phase and the histogram instead of all at once (the 16-wave shapes, which
     // have the CU to themselves; BYZ_TM_LEAN_PIPE=0|1 forces it either way: the comparison)
+    const char* xcd_env = std::getenv("BYZ_TM_LEAN_XCD");   // 0: tile = blockIdx.x (the comparison)
+    const int by_xcd = xcd_env != nullptr ? std::atoi(xcd_env) : 1;
     const char* pipe_env = std::getenv("BYZ_TM_LEAN_PIPE");
     const bool pipe = pipe_env != nullptr ? std::atoi(pipe_env) != 0 : W == 16;
 #define BYZ_LEAN(E, P)                                                                                              \
@@ -705,7 +718,7 @@ int launch_lean_shape(const float* G, int64_t n_rows, int64_t n_cols, int64_t ld
         BYZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&window_lean_kernel<W, RPW, B, SR, LS, E, P>),     \
                                     hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));            \
         window_lean_kernel<W, RPW, B, SR, LS, E, P><<<static_cast<unsigned>(n_tiles), 64 * W, lds, stream>>>(        \
-            G, static_cast<int>(n_rows), n_cols, ld, row_index, static_cast<int>(keep), out, redo);                 \
+            G, static_cast<int>(n_rows), n_cols, ld, row_index, static_cast<int>(keep), out, redo, by_xcd);         \
     } while (0)
     if (exact) BYZ_LEAN(true, false);
     else if (pipe) BYZ_LEAN(false, true);
