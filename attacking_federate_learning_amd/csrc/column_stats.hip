@@ -96,13 +96,26 @@ __global__ __launch_bounds__(kThreads) void column_finalize_kernel(
     }
 }
 
+// vec -> every row of G (malicious.py:26-27: all malicious clients get ONE array).  VEC = 4: 16-byte stores, 4 KiB of a row per
+// workgroup and step (rows and the vector 16-byte aligned); VEC = 1: any alignment.
+template <int VEC>
 __global__ __launch_bounds__(kThreads) void broadcast_rows_kernel(float* __restrict__ G, int64_t n_rows,
                                                                   int64_t n_cols, int64_t ld,
                                                                   const float* __restrict__ vec) {
-    const int64_t c = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x;
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    const int64_t c = (static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x) * VEC;
     if (c >= n_cols) return;
-    const float v = vec[c];
-    for (int64_t r = blockIdx.y; r < n_rows; r += gridDim.y) G[r * ld + c] = v;
+    if constexpr (VEC == 4) {
+        if (c + 3 < n_cols) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(vec + c);
+            for (int64_t r = blockIdx.y; r < n_rows; r += gridDim.y) *reinterpret_cast<f32x4*>(G + r * ld + c) = v;
+            return;
+        }
+    }
+    for (int e = 0; e < VEC && c + e < n_cols; ++e) {
+        const float v = vec[c + e];
+        for (int64_t r = blockIdx.y; r < n_rows; r += gridDim.y) G[r * ld + c + e] = v;
+    }
 }
 
 __global__ __launch_bounds__(kThreads) void drift_axpy_kernel(float* __restrict__ mean,
@@ -190,11 +203,13 @@ int launch_column_drift(byz_ctx* ctx, const float* G, int64_t n_rows, int64_t n_
 int launch_broadcast_rows(byz_ctx* ctx, float* G, int64_t n_rows, int64_t n_cols, int64_t ld, const float* vec,
                           hipStream_t stream) {
     KernelTimer t(ctx, BYZ_K_MISC, stream);
-    const unsigned blocks = static_cast<unsigned>(ceil_div(n_cols, kThreads));
+    const bool wide = ld % 4 == 0 && (reinterpret_cast<uintptr_t>(G) & 15u) == 0 && (reinterpret_cast<uintptr_t>(vec) & 15u) == 0;
+    const unsigned blocks = static_cast<unsigned>(ceil_div(n_cols, kThreads * (wide ? 4 : 1)));
     unsigned ysplit = static_cast<unsigned>(ceil_div(static_cast<int64_t>(ctx->num_cus) * 8, blocks));
     if (ysplit > n_rows) ysplit = static_cast<unsigned>(n_rows);
     if (ysplit < 1) ysplit = 1;
-    broadcast_rows_kernel<<<dim3(blocks, ysplit), kThreads, 0, stream>>>(G, n_rows, n_cols, ld, vec);
+    if (wide) broadcast_rows_kernel<4><<<dim3(blocks, ysplit), kThreads, 0, stream>>>(G, n_rows, n_cols, ld, vec);
+    else broadcast_rows_kernel<1><<<dim3(blocks, ysplit), kThreads, 0, stream>>>(G, n_rows, n_cols, ld, vec);
     return check_launch("broadcast_rows_kernel");
 }
 
