@@ -563,11 +563,15 @@ __global__ __launch_bounds__(256) void gram_rep_kernel(const double* __restrict_
 // every rank): distance_kernel counts the listed pairs of every row (the count does not depend on the order of the atomics),
 // pair_offsets_kernel turns the counts into offsets (one workgroup, rows in order), pair_fill_kernel re-evaluates the rows
 // that have any and writes their pairs in column order.
+// `proven` (optional): dedup.hip's map of this very matrix -- proven[i] == proven[j] <=> rows i and j were compared byte for
+// byte and are identical; such a pair needs no second proof on the difference (under the attack that is one pair per
+// malicious client: 2399 x 2 rows of D columns read again, 6 ms of the c5s round).
 __device__ __forceinline__ bool pair_is_listed(const double* __restrict__ gram, int64_t n, const int32_t* __restrict__ rep,
-                                               int64_t i, int64_t j, double cii) {
+                                               const int32_t* __restrict__ proven, int64_t i, int64_t j, double cii) {
     const double cjj = gram[j * n + j];
     const double d2 = cii + cjj - 2.0 * gram[i * n + j];
     if (!(d2 < kNearEps * (cii + cjj))) return false;
+    if (proven != nullptr && proven[i] == proven[j]) return false;
     const int ri = rep[i], rj = rep[j];
     // representatives pair with each other; a folded row only with its representative (the proof of identity)
     return (ri == i && rj == j) || ri == j;
@@ -575,7 +579,7 @@ __device__ __forceinline__ bool pair_is_listed(const double* __restrict__ gram, 
 
 __global__ __launch_bounds__(256) void distance_kernel(const double* __restrict__ gram, int64_t n,
                                                        float* __restrict__ dist, const int32_t* __restrict__ rep,
-                                                       int32_t* __restrict__ row_pairs) {
+                                                       const int32_t* __restrict__ proven, int32_t* __restrict__ row_pairs) {
     const int64_t j = static_cast<int64_t>(blockIdx.x) * 64 + (threadIdx.x & 63);
     const int64_t i = static_cast<int64_t>(blockIdx.y) * 4 + (threadIdx.x >> 6);
     if (i >= n || j >= n) return;
@@ -587,7 +591,7 @@ __global__ __launch_bounds__(256) void distance_kernel(const double* __restrict_
         const double d2 = cii + cjj - 2.0 * gram[i * n + j];
         // rounding can leave a tiny negative value for near-identical rows; NaN (poisoned input) must stay NaN
         d = static_cast<float>(sqrt(d2 < 0.0 ? 0.0 : d2));
-        if (i > j && pair_is_listed(gram, n, rep, i, j, cii)) atomicAdd(&row_pairs[i], 1);
+        if (i > j && pair_is_listed(gram, n, rep, proven, i, j, cii)) atomicAdd(&row_pairs[i], 1);
     }
     dist[i * n + j] = d;
 }
@@ -629,6 +633,7 @@ __global__ __launch_bounds__(1024) void pair_offsets_kernel(int32_t* __restrict_
 // one wave per row; rows without listed pairs (all of them, unless clients nearly coincide) leave after one load
 __global__ __launch_bounds__(256) void pair_fill_kernel(const double* __restrict__ gram, int64_t n,
                                                         const int32_t* __restrict__ rep,
+                                                        const int32_t* __restrict__ proven,
                                                         const int32_t* __restrict__ row_pairs,
                                                         const int32_t* __restrict__ pair_count, int2* __restrict__ pairs,
                                                         int pair_capacity) {
@@ -641,7 +646,7 @@ __global__ __launch_bounds__(256) void pair_fill_kernel(const double* __restrict
     const double cii = gram[i * n + i];
     for (int64_t j0 = 0; j0 < i && at < stop; j0 += 64) {
         const int64_t j = j0 + lane;
-        const bool listed = j < i && pair_is_listed(gram, n, rep, i, j, cii);
+        const bool listed = j < i && pair_is_listed(gram, n, rep, proven, i, j, cii);
         const unsigned long long m = __ballot(listed);
         if (listed) {
             const int slot = at + __builtin_popcountll(m & ((1ull << lane) - 1ull));
@@ -1087,13 +1092,16 @@ int launch_distances_from_gram(byz_ctx* ctx, const double* gram, int64_t n, floa
         gram_rep_kernel<<<static_cast<unsigned>(ceil_div(n, 4)), 256, 0, stream>>>(gram, n, ctx->gram_rep.as<int32_t>());
         BYZ_TRY(check_launch("gram_rep_kernel"));
         dim3 grid(static_cast<unsigned>(ceil_div(n, 64)), static_cast<unsigned>(ceil_div(n, 4)));
-        distance_kernel<<<grid, 256, 0, stream>>>(gram, n, dist, ctx->gram_rep.as<int32_t>(), row_pairs);
+        // identical rows already proven by dedup.hip for THIS matrix (launch_gram sets row_map_rows; every other producer of a
+        // Gram resets it)
+        const int32_t* proven = ctx->row_map_rows == n && ctx->row_map.ptr != nullptr ? ctx->row_map.as<int32_t>() : nullptr;
+        distance_kernel<<<grid, 256, 0, stream>>>(gram, n, dist, ctx->gram_rep.as<int32_t>(), proven, row_pairs);
         BYZ_TRY(check_launch("distance_kernel"));
         // the pair list in its canonical order (ascending i, then j): see pair_is_listed
         pair_offsets_kernel<<<1, 1024, 0, stream>>>(row_pairs, n, near_pair_count_word(ctx));
         BYZ_TRY(check_launch("pair_offsets_kernel"));
         pair_fill_kernel<<<static_cast<unsigned>(ceil_div(n, 4)), 256, 0, stream>>>(
-            gram, n, ctx->gram_rep.as<int32_t>(), row_pairs, near_pair_count_word(ctx), ctx->near_pairs.as<int2>(),
+            gram, n, ctx->gram_rep.as<int32_t>(), proven, row_pairs, near_pair_count_word(ctx), ctx->near_pairs.as<int2>(),
             (int)ctx->near_pair_capacity);
         BYZ_TRY(check_launch("pair_fill_kernel"));
     }
