@@ -42,6 +42,9 @@ class HipKernels:
     def gram_share(self, panel, row_index, share_count, share_index):
         return self.engine.gram_share(panel, row_index, share_count, share_index)
 
+    def pairwise_distances(self, g_local):
+        return self.engine.pairwise_distances(g_local)         # Distances handle: Gram, distances, near pairs in one call
+
     def distances_from_gram(self, gram, local_columns=None, all_reduce=None):
         return self.engine.distances_from_gram(gram, gram.shape[0], local_columns=local_columns, all_reduce=all_reduce)
 
@@ -136,6 +139,10 @@ class ShardedAggregator:
     def global_distances(self, g_local):
         """columns layout: Gram of the local slice, one all-reduce, distances (near-duplicate pairs re-evaluated on
         the difference: per-rank partial sums over the local columns, one more small all-reduce)."""
+        if not self._collective() and hasattr(self.kernels, 'pairwise_distances'):
+            # one rank holds every column: the engine's own composition, in which rows that its duplicate search has compared
+            # byte for byte need no second proof through the near-pair exchange
+            return self.kernels.pairwise_distances(g_local)
         gram = self.kernels.gram(g_local)
         self._all_reduce('allreduce_gram', gram)
         reduce_pairs = (lambda t: self._all_reduce('allreduce_near_pairs', t)) if self._collective() else None

@@ -6,7 +6,9 @@ Every record carries the hash of the kernel's source file at the time of the mea
 only while that hash still matches (a kernel that changed since its PMC pass reports null, not a stale number).
 fetch_scale: gfx950's FETCH_SIZE tallies a wide coalesced read (16 bytes per lane over segments of 128 bytes or more) at
 half its size (MI355X_MICROARCH.md, HBM; calibrated in round 1 on column_stats, whose doubled count equals its
-algorithmic bytes); 64-byte row segments are tallied at full size (calibrated on the trimmed-mean kernels).
+algorithmic bytes); isolated 64-byte requests are tallied at full size (calibrated on the trimmed-mean kernels of round 3 BEFORE their
+tile order followed the XCDs: raw = algorithmic; with neighbouring tiles on one L2 the same bytes arrive as 128-byte requests and
+the raw count is exactly half: profiles/r03t vs r03v).
 """
 import hashlib
 import json
@@ -20,8 +22,10 @@ CSRC = os.path.join(ROOT, 'attacking_federate_learning_amd', 'csrc')
 RULES = {
     'c4/gram_tile': ('c4/gram_planes_kernel', 'gram_planes.hip', 2.0, 10, 'LDS-DMA pieces of 1 KiB', {'arithmetic': 'f16x2'}),
     'c4/plane_split': ('c4/plane_split_f16_stream_kernel', 'gram_planes.hip', 2.0, 10, 'f32x4 per thread over 128-byte row segments', {}),
-    'c4/trimmed_mean': ('c4/window_lean_kernel', 'window_lean.hip', 1.0, 1, '64-byte row segments', {}),
-    'c3/trimmed_mean': ('c3/window_lean_kernel', 'window_lean.hip', 1.0, 1, '64-byte row segments', {}),
+    # (until the XCD-contiguous tile order the two 64-byte halves of a line were requested by two L2s and tallied at full size:
+    #  raw = algorithmic; now neighbouring tiles meet in one L2 and the counter sees 128-byte requests, tallied at 64)
+    'c4/trimmed_mean': ('c4/window_lean_kernel', 'window_lean.hip', 2.0, 1, '64-byte row segments of neighbouring tiles merged into 128-byte requests', {}),
+    'c3/trimmed_mean': ('c3/window_lean_kernel', 'window_lean.hip', 2.0, 1, '64-byte row segments of neighbouring tiles merged into 128-byte requests', {}),
     'c2/gram_tile': ('c2/small_gram_kernel', 'krum_small.hip', 2.0, 1, '8 x 16-byte loads per row slice', {'arithmetic': 'f16x2'}),
 }
 
