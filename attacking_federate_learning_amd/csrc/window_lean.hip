@@ -707,12 +707,14 @@ int launch_lean_shape(const float* G, int64_t n_rows, int64_t n_cols, int64_t ld
     // (tiles from the middle of the launch: the chip is in its steady state there)
     const int timing = timing_env != nullptr && std::atoi(timing_env) != 0 ? 1 + static_cast<int>(n_tiles > 2 * kStampTiles ? n_tiles / 2 : 0) : 0;
     if (timing) BYZ_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_lean_timing), &timing, sizeof(int)));
-    // PIPE: request the tile's rows under the range phase and the histogram instead of all at once (the 16-wave shapes, which
-    // have the CU to themselves; BYZ_TM_LEAN_PIPE=0|1 forces it either way: the comparison)
     const char* xcd_env = std::getenv("BYZ_TM_LEAN_XCD");   // 0: tile = blockIdx.x (the comparison)
     const int by_xcd = xcd_env != nullptr ? std::atoi(xcd_env) : 1;
+    // PIPE: request the tile's rows under the range phase and the histogram instead of all at once.  Same box, tiles ordered by
+    // XCD (scripts/tm_ab.py BYZ_TM_LEAN_PIPE 0,1): 2080 rows 0.398 -> 0.376 ms per 2^17 columns, 5200 rows 0.675 -> 0.626 per
+    // 2^16, 1000 rows 0.351 -> 0.345 per 2^18 (inside the noise: the 4-wave shapes keep loading at once).  Before the tile
+    // order it paid for the 16-wave shapes only.  BYZ_TM_LEAN_PIPE=0|1 forces it either way: the comparison.
     const char* pipe_env = std::getenv("BYZ_TM_LEAN_PIPE");
-    const bool pipe = pipe_env != nullptr ? std::atoi(pipe_env) != 0 : W == 16;
+    const bool pipe = pipe_env != nullptr ? std::atoi(pipe_env) != 0 : W >= 8;
 #define BYZ_LEAN(E, P)                                                                                              \
     do {                                                                                                            \
         BYZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&window_lean_kernel<W, RPW, B, SR, LS, E, P>),     \
