@@ -591,6 +591,11 @@ __global__ __launch_bounds__(256) void distance_kernel(const double* __restrict_
         const double d2 = cii + cjj - 2.0 * gram[i * n + j];
         // rounding can leave a tiny negative value for near-identical rows; NaN (poisoned input) must stay NaN
         d = static_cast<float>(sqrt(d2 < 0.0 ? 0.0 : d2));
+        // rows dedup.hip compared byte for byte are not on the pair list (pair_is_listed), so nothing would correct a d2 that
+        // is not EXACTLY zero -- and the Gram gives exact zeros only while both rows went through the same arithmetic with the
+        // same scale (the sampled operand split may redo one twin's row block at another shift: ADVICE r3).  Their distance
+        // is zero by proof, not by cancellation.
+        if (proven != nullptr && proven[i] == proven[j]) d = 0.0f;
         if (i > j && pair_is_listed(gram, n, rep, proven, i, j, cii)) atomicAdd(&row_pairs[i], 1);
     }
     dist[i * n + j] = d;

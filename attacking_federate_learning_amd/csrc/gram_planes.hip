@@ -155,10 +155,13 @@ __global__ __launch_bounds__(256) void plane_split_f16_kernel(const float* __res
     __shared__ float row_scale[32];
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
-    // redo != nullptr: the (chunk, row block) pairs the streaming kernel listed (redo[0] of them), one per workgroup
-    if (redo != nullptr && static_cast<int>(blockIdx.x) >= redo[0]) return;
-    const int64_t rb = redo != nullptr ? redo[2 + 2 * blockIdx.x] : blockIdx.y;
-    const int64_t chunk = redo != nullptr ? redo[1 + 2 * blockIdx.x] : blockIdx.x;
+    // redo != nullptr: the (chunk, row block) pairs the streaming kernel listed (redo[0] of them), dealt to the workgroups of
+    // the launch in a grid-stride loop: however many were listed, they are all redone and the host never has to read the
+    // count back (the read-back serialised host and device once per super-chunk at N = 10,000)
+    const int listed = redo != nullptr ? redo[0] : 1;
+    for (int item = redo != nullptr ? static_cast<int>(blockIdx.x) : 0; item < listed; item += static_cast<int>(gridDim.x)) {
+    const int64_t rb = redo != nullptr ? redo[2 + 2 * item] : blockIdx.y;
+    const int64_t chunk = redo != nullptr ? redo[1 + 2 * item] : blockIdx.x;
     const int r = tid >> 3, c = tid & 7;
     int64_t row = rb * 32 + r;
     if (row > n_rows - 1) row = n_rows - 1;
@@ -222,6 +225,9 @@ __global__ __launch_bounds__(256) void plane_split_f16_kernel(const float* __res
         }
         __syncthreads();
     }
+    if (redo == nullptr) break;
+    __syncthreads();
+    }
 }
 
 // f16x2 in ONE pass over G (round 3).  The two-pass kernel above reads every element twice -- once for the row's largest
@@ -234,8 +240,12 @@ __global__ __launch_bounds__(256) void plane_split_f16_kernel(const float* __res
 // placed at [2^9, 2^10) -- six binades of head room above, two below -- the chunk is then split as it streams by, and the
 // true largest magnitude, which falls out of the same pass, says whether the assumption held.  Where it did not (an outlier
 // 64 times the sampled maximum, a chunk whose sampled columns are all zero, inf / NaN) the (row block, chunk) goes on a
-// list and the two-pass kernel redoes exactly those.  For every other block the planes are bit for bit what the exact
-// scale would give, scaled by a power of two that `unscale` undoes.
+// list and the two-pass kernel redoes exactly those.  For every other block the planes are what the exact scale would give,
+// scaled by a power of two that `unscale` undoes -- bit for bit for every element whose two planes stay NORMAL fp16 numbers
+// under both scales; an element below ~2^-17 of the row's largest magnitude lands on a different subnormal grid (its planes
+// differ by ~2^-32 of that magnitude: harmless numerically, but the Gram under the sampled scale is NOT bitwise the two-pass
+// Gram, and twin rows in row blocks of which only one was redone do not give bitwise equal Gram entries -- which is why
+// rows proven identical get their zero distance from the proof, gram.hip distance_kernel, not from cancellation).
 constexpr int kSampleGroups = 16;
 __global__ __launch_bounds__(256) void plane_split_f16_stream_kernel(const float* __restrict__ G, int64_t n_rows, int64_t n_cols,
                                                                      int64_t ld, const int32_t* __restrict__ row_index, int64_t k0,
@@ -749,20 +759,11 @@ int launch_gram_planes(byz_ctx* ctx, const float* G, int64_t n_rows, int64_t n_c
                     plane_split_f16_stream_kernel<<<grid, 256, 0, stream>>>(G, n_rows, n_cols, ld, row_index, k0, n_steps, planes,
                                                                             unscale, rows_pad, redo);
                     BYZ_TRY(check_launch("plane_split_f16_stream_kernel"));
-                    // (sized for a few thousand listed blocks; the surplus workgroups leave at once.  More than that --
-                    // pathological data -- and the whole super-chunk is simply redone by the two-pass kernel.)
+                    // (sized for a few thousand listed blocks; the surplus workgroups leave at once, and a longer list --
+                    // pathological data -- is walked in a grid-stride loop: no host read-back of the count.)
                     const int64_t fix = pairs < 4096 ? pairs : 4096;
                     plane_split_f16_kernel<<<static_cast<unsigned>(fix), 256, 0, stream>>>(G, n_rows, n_cols, ld, row_index, k0,
                                                                                            n_steps, planes, unscale, rows_pad, redo);
-                    if (pairs > fix) {
-                        BYZ_TRY(check_launch("plane_split_f16_kernel<redo>"));
-                        int32_t listed = 0;
-                        BYZ_HIP(hipMemcpyAsync(&listed, redo, sizeof(int32_t), hipMemcpyDeviceToHost, stream));
-                        BYZ_HIP(hipStreamSynchronize(stream));
-                        if (listed > fix)
-                            plane_split_f16_kernel<<<grid, 256, 0, stream>>>(G, n_rows, n_cols, ld, row_index, k0, n_steps, planes,
-                                                                             unscale, rows_pad, nullptr);
-                    }
                 }
             } else {
                 const dim3 grid(static_cast<unsigned>(ceil_div(n_steps, kSplitCols / 16)), static_cast<unsigned>(rows_pad / 32));

@@ -97,10 +97,12 @@ __global__ void row_sort_kernel(const float* __restrict__ dist, int n, int n_pad
     // sort itself; wave 0 now adds the first 512 entries as a chain from broadcast reads and the rest in integer passes
     // (integer_passes below: the same bits).  A prefix that holds a sign bit, or a sum that leaves the finite range, is summed
     // again the old way.
-    if (tid < 64 && prefix_len > 0) {
+    // (an empty prefix -- users_count == corrupted_count, reachable through return_index=True which skips the assert --
+    // stores sum([]) == 0.0 like the reference: the guard must not skip the store)
+    if (tid < 64) {
         const int lane = tid;
         float s = 0.0f;
-        const int head_n = prefix_len < 512 ? prefix_len : 512;
+        const int head_n = prefix_len < 512 ? (prefix_len > 0 ? prefix_len : 0) : 512;
         for (int r0 = 0; r0 < head_n; r0 += 16) {
             float v[16];
 #pragma unroll

@@ -365,12 +365,13 @@ class Engine:
         idx = int(idx.value)
         return idx if (keys is None or idx < 0) else keys[idx]
 
-    def krum(self, g, users_count, corrupted_count, distances=None, return_index=False, check=True):
+    def krum(self, g, users_count, corrupted_count, distances=None, return_index=False, debug=False, *, check=True):
         """defences.krum (defences.py:23-42).  Device-resident `g` without `return_index`: the winning row is copied on
         the device and nothing needs to cross to the host, but a kernel can only FLAG a failure there (a Gram chunk that
         never got its ticket, helpers that lost their worker: the sticky status word) -- so by default the call ends with
         `self.check(stream)` (one synchronisation) and raises instead of returning a row picked from invalid distances.
-        `check=False` keeps the call asynchronous; the caller then owes an `engine.check()` before it uses the result."""
+        `check=False` (keyword only: the positional slot behind `return_index` is the reference's `debug`, accepted and
+        ignored) keeps the call asynchronous; the caller then owes an `engine.check()` before it uses the result."""
         if not return_index:
             # defences.py:24-25 (the message says +3, the check is +1)
             assert users_count >= 2 * corrupted_count + 1, (

@@ -38,12 +38,12 @@ PEAK_MFMA_BF16 = 2.5e15   # flop/s, dense bf16 MFMA (same table)
 MAL_PROP = 0.24           # reference main.py:106
 
 
-def parse_args():
+def parse_args(argv=None):
     p = argparse.ArgumentParser()
     p.add_argument('--gpus', type=int, default=1)
     p.add_argument('--steps', type=int, default=3)
     p.add_argument('--warmup', type=int, default=1)
-    p.add_argument('--workload', default='c4', choices=['c4', 'c3', 'c2', 'c5s', 'attack'])
+    p.add_argument('--workload', default='c4', choices=['c4', 'c3', 'c2', 'c5s', 'c5u', 'attack', 'launch-selftest'])
     p.add_argument('--clients', type=int, default=None, help='override N')
     p.add_argument('--params', type=int, default=None, help='override total D')
     p.add_argument('--no-cpu-baseline', action='store_true')
@@ -51,7 +51,102 @@ def parse_args():
     p.add_argument('--cpu-seconds', type=float, default=20.0, help='budget of the cpu_baseline leg')
     p.add_argument('--layout', default='columns', choices=['columns', 'clients', 'both'],
                    help='multi-GPU layout of the gradient matrix (sharded.py); "both" times the other one as well')
-    return p.parse_args()
+    p.add_argument('--no-sharded-w1', action='store_true',
+                   help='skip the leg that times the W > 1 code path (collectives forced) on this one GPU')
+    p.add_argument('--no-north-star', action='store_true', help='skip the c5s / c5u legs of the default run')
+    return p.parse_args(argv)
+
+
+# ---- launching: `python bench.py --gpus N` must BE an N-rank run or fail -----------------------------------------
+def launch_plan(gpus, env, device_count, needs_gpu=True):
+    """What `python bench.py --gpus N` does, decided from the environment alone (a pure function: tests/test_bench_launcher.py).
+
+    ('inline', None)   this process is one rank: either started by torch.distributed.run / the driver (WORLD_SIZE set and
+                       equal to N), or N == 1
+    ('spawn', None)    N > 1 and nobody launched ranks: re-exec under torch.distributed.run with N ranks on this node
+    ('fail', message)  WORLD_SIZE disagrees with --gpus, or the box exposes fewer than N GPUs: a line that says n_gpus = N
+                       must never come from fewer than N ranks (`--gpus 8` without torchrun ran ONE process
+                       and printed n_gpus 8)"""
+    if gpus < 1:
+        return 'fail', '--gpus must be >= 1'
+    world_env = env.get('WORLD_SIZE')
+    if world_env is not None:
+        if int(world_env) != gpus:
+            return 'fail', '--gpus %d but WORLD_SIZE=%s: the launcher started another number of ranks' % (gpus, world_env)
+        if needs_gpu and device_count < gpus:
+            return 'fail', '--gpus %d but this node exposes %d GPU(s)' % (gpus, device_count)
+        return 'inline', None
+    if gpus == 1:
+        return 'inline', None
+    if needs_gpu and device_count < gpus:
+        return 'fail', '--gpus %d but this node exposes %d GPU(s): refusing to print an n_gpus=%d line from fewer ranks' % (
+            gpus, device_count, gpus)
+    return 'spawn', None
+
+
+def free_port():
+    import socket
+    with socket.socket() as sock:
+        sock.bind(('127.0.0.1', 0))
+        return sock.getsockname()[1]
+
+
+def spawn_ranks(gpus, argv):
+    """Re-exec this script as `gpus` ranks of one node (one process per GPU, rendezvous on 127.0.0.1) and pass the child's
+    output and exit code through."""
+    import subprocess
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(gpus),
+           '--master-addr', '127.0.0.1', '--master-port', str(free_port()), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    return subprocess.call(cmd, env=env)
+
+
+def ranks_seen(torch, dist, device):
+    """How many ranks really take part: every rank contributes a one through the collective library itself."""
+    if not dist.is_initialized():
+        return 1
+    one = torch.ones(1, dtype=torch.int64, device=device)
+    dist.all_reduce(one, op=dist.ReduceOp.SUM)
+    return int(one.item())
+
+
+def launch_selftest(args):
+    """The launcher's own workload (CPU, gloo): K trivial steps timed as the contract says, so that the spawn path, the
+    rank count and the max-over-ranks clock are exercised where there is no GPU (tests/test_bench_launcher.py)."""
+    import torch
+    import torch.distributed as dist
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('gloo')
+    seen = ranks_seen(torch, dist, torch.device('cpu'))
+    acc = torch.zeros(1 << 16, dtype=torch.float64)
+    for _ in range(args.warmup):
+        acc += 1.0
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        acc += float(rank + 1)
+        if world > 1:
+            dist.all_reduce(acc)     # the stub's exchange step
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    if rank == 0:
+        print(json.dumps({'metric': 'launcher self-test steps/sec', 'value': args.steps / elapsed, 'unit': 'steps/s',
+                          'n_gpus': dist.get_world_size() if dist.is_initialized() else 1, 'ranks_seen': seen,
+                          'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': elapsed / args.steps * 1e3,
+                          'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f64',
+                          'data': 'synthetic', 'config': {'workload': 'launch-selftest (CPU, gloo): no GPU work'}}), flush=True)
+    if dist.is_initialized():
+        dist.destroy_process_group()
 
 
 # ---- synthetic inputs -----------------------------------------------------------------------------
@@ -98,7 +193,7 @@ class Workload:
 class BulyanSharded(Workload):
     """configs[3] (and the Bulyan half of configs[4]): column-sharded Bulyan through ShardedAggregator."""
 
-    def __init__(self, torch, agg, eng, n, d_total, device, seed, with_attack=False, layout='columns'):
+    def __init__(self, torch, agg, eng, n, d_total, device, seed, with_attack=False, layout='columns', distinct=False, g=None):
         self.torch, self.agg, self.eng = torch, agg, eng
         self.n, self.d_total = n, d_total
         self.f = int(n * MAL_PROP)
@@ -107,20 +202,29 @@ class BulyanSharded(Workload):
             # north_star's layout: rank r holds the rows of its clients, all D columns (reference main.py:26-32)
             self.rows_per_rank = [n // agg.world + (1 if r < n % agg.world else 0) for r in range(agg.world)]
             self.d_local = d_total
-            self.g = make_matrix(torch, self.rows_per_rank[agg.rank], d_total, seed + 17 * agg.rank, device)
+            shape = (self.rows_per_rank[agg.rank], d_total)
         else:
             lo, hi = column_bounds(d_total, agg.world)[agg.rank]
             self.d_local = hi - lo
-            self.g = make_matrix(torch, n, self.d_local, seed + 17 * agg.rank, device)
+            shape = (n, self.d_local)
+        if g is not None:     # a matrix the caller already holds (at one rank both layouts are the whole matrix)
+            assert tuple(g.shape) == shape
+            self.g = g
+        else:
+            self.g = make_matrix(torch, shape[0], shape[1], seed + 17 * agg.rank, device)
         self.with_attack = with_attack
-        self.name = 'c5s' if with_attack else 'c4'
+        # distinct: the attack's column statistics are computed but the malicious rows are NOT overwritten with the one
+        # drifted vector -- all N rows stay distinct (an attacker who adds per-row noise; nothing for the identical-row
+        # shortcut to fold): configs[4] without the shortcut
+        self.distinct = bool(distinct and with_attack)
+        self.name = ('c5u' if self.distinct else 'c5s') if with_attack else 'c4'
         self.defence = 'attack+Krum+Bulyan' if with_attack else 'Bulyan'
         self.last = None
 
     def step(self):
         if self.layout == 'clients':
             if self.with_attack:
-                self.agg.drift_attack_clients(self.g, self.rows_per_rank, self.f, 1.5, write_back=True)
+                self.agg.drift_attack_clients(self.g, self.rows_per_rank, self.f, 1.5, write_back=not self.distinct)
                 dist_m = self.agg.client_distances(self.g, self.rows_per_rank)
                 idx = self.agg.kernels.krum_select(dist_m, self.n, self.f)
                 sel = np.asarray(self.agg.kernels.bulyan_select(dist_m, self.n, self.f), dtype=np.int64)
@@ -132,7 +236,7 @@ class BulyanSharded(Workload):
             return
         if self.with_attack:
             # rows 0..m-1 are the malicious clients (reference main.py:28); per column, no exchange
-            self.agg.drift_attack(self.g, self.f, 1.5, write_back=True)
+            self.agg.drift_attack(self.g, self.f, 1.5, write_back=not self.distinct)
             dist_m = self.agg.global_distances(self.g)
             idx = self.agg.kernels.krum_select(dist_m, self.n, self.f)
             sel = self.agg.kernels.bulyan_select(dist_m, self.n, self.f, on_device=True)   # stays on the device
@@ -169,7 +273,7 @@ class BulyanSharded(Workload):
         # dense fp32-input MFMA peak: the algorithmic flops are fp32 flops, whatever instructions carry them.
         # under the attack rows 0..f-1 are one vector and the engine runs the Gram over the unique rows only: the
         # kernel's work is (N - f + 1)^2 * D_local, not N^2 * D_local
-        rows = self.n - self.f + 1 if self.with_attack and self.n >= 512 else self.n
+        rows = self.n - self.f + 1 if self.with_attack and not self.distinct and self.n >= 512 else self.n
         share = self.agg.world if self.layout == 'clients' else 1     # clients: every rank does 1/W of the tiles, all D
         # Which arithmetic the engine picks (csrc/gram.hip launch_gram_rows): few tiles -> fp32-input MFMA; many tiles ->
         # bf16 x 3 (six bf16 MFMA flops per fp32 flop); many tiles AND a long K -> operands split once into two fp16 planes
@@ -199,11 +303,16 @@ class BulyanSharded(Workload):
         return self.name == 'c4' and self.n == 4000 and self.d_local == 10000000
 
     def config(self):
-        return {'workload': '%s: %s N=%d D=%d f=%d theta=%d (BASELINE configs[%d]), %s sharded %d-way'
+        rows = ('' if not self.with_attack else
+                ', all %d rows distinct (attack statistics computed, rows not overwritten)' % self.n if self.distinct else
+                ', the %d malicious rows one vector (malicious.py:26-27): Gram over %d unique rows' % (self.f, self.n - self.f + 1))
+        return {'workload': '%s: %s N=%d D=%d f=%d theta=%d (BASELINE configs[%d]%s), %s sharded %d-way%s'
                             % (self.name, self.defence, self.n, self.d_total, self.f, self.n - 2 * self.f,
-                               4 if self.with_attack else 3, self.layout, self.agg.world),
+                               4 if self.with_attack else 3,
+                               ": one GPU's slice of eight, D = 25M / 8" if self.with_attack and self.d_total == 3_125_000 * self.agg.world else '',
+                               self.layout, self.agg.world, rows),
                 'clients': self.n, 'params': self.d_total, 'corrupted': self.f, 'layout': self.layout,
-                'params_per_gpu': self.d_local, 'input_family': 'scaled'}
+                'params_per_gpu': self.d_local, 'input_family': 'scaled', 'distinct_rows': self.n if (self.distinct or not self.with_attack) else self.n - self.f + 1}
 
 
 class TrimmedMeanC3(Workload):
@@ -619,17 +728,46 @@ def cpu_baseline(wl, budget_s):
 
 
 # ---- main -----------------------------------------------------------------------------------------
-def main():
-    args = parse_args()
+def collectives_table(agg, steps):
+    """The timed steps' collectives: bytes THIS rank received and the time its compute stream spent in (or, for the overlapped
+    gathers, waiting for) each of them, per step."""
+    return {k: {'calls_per_step': v['calls'] / steps, 'MB_per_step': v['bytes'] / steps / 1e6, 'ms_per_step': v['ms'] / steps}
+            for k, v in agg.comm_report().items()}
+
+
+def bulyan_record(torch, dist, wl, eng, agg, steps, warmup, world, traffic):
+    """One timed leg of a BulyanSharded workload as a self-contained record (value, roofline, kernels, collectives)."""
+    agg.comm_report()     # drop whatever the set-up booked
+    elapsed, per_kernel = timed_steps(torch, dist, wl, eng, steps, warmup, world)
+    rec = {'config': wl.config(), 'value': steps / elapsed, 'unit': 'rounds/s', 'ms_per_step': elapsed / steps * 1e3,
+           'steps': steps, 'warmup': warmup, 'roofline': roofline_of(wl, per_kernel, traffic, steps),
+           'kernels': kernel_table(per_kernel, steps), 'collectives': collectives_table(agg, steps),
+           'verified_after_timing': wl.verify()}
+    return rec
+
+
+def main(argv=None):
+    args = parse_args(argv)
+    own_argv = sys.argv[1:] if argv is None else list(argv)
+    if args.workload == 'launch-selftest':     # CPU / gloo: the launcher under test, no GPU work
+        plan, why = launch_plan(args.gpus, os.environ, 0, needs_gpu=False)
+        if plan == 'fail':
+            raise SystemExit('bench: ' + why)
+        if plan == 'spawn':
+            raise SystemExit(spawn_ranks(args.gpus, own_argv))
+        return launch_selftest(args)
     import torch
     import torch.distributed as dist
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs an MI355X: the aggregation path has no CPU implementation')
+    plan, why = launch_plan(args.gpus, os.environ, torch.cuda.device_count())
+    if plan == 'fail':
+        raise SystemExit('bench: ' + why)
+    if plan == 'spawn':
+        raise SystemExit(spawn_ranks(args.gpus, own_argv))
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    if world != args.gpus and world > 1:
-        raise SystemExit('--gpus %d but WORLD_SIZE=%d' % (args.gpus, world))
-    if not torch.cuda.is_available():
-        raise SystemExit('bench.py needs an MI355X: the aggregation path has no CPU implementation')
     torch.cuda.set_device(local_rank)
     device = torch.device('cuda', local_rank)
     os.environ.setdefault('BYZ_DEVICE', str(local_rank))
@@ -639,6 +777,11 @@ def main():
         os.environ.setdefault('RANK', '0')
         os.environ.setdefault('WORLD_SIZE', '1')
         dist.init_process_group('nccl', device_id=device)
+    # n_gpus is what the collective library says, never what the command line says
+    n_gpus = dist.get_world_size() if dist.is_initialized() else 1
+    seen = ranks_seen(torch, dist, device)
+    if n_gpus != args.gpus or seen != args.gpus:
+        raise SystemExit('bench: --gpus %d but %d rank(s) joined the process group (%d counted)' % (args.gpus, n_gpus, seen))
 
     from attacking_federate_learning_amd.engine import Engine
     from attacking_federate_learning_amd.sharded import HipKernels, ShardedAggregator
@@ -646,12 +789,13 @@ def main():
     agg = ShardedAggregator(HipKernels(eng))
     traffic = load_traffic_table()
 
-    if args.workload in ('c4', 'c5s'):
+    if args.workload in ('c4', 'c5s', 'c5u'):
         n = args.clients or (4000 if args.workload == 'c4' else 10000)
-        # c5s: the slice of configs[4] one GPU of eight would hold (25M/8 columns) -- 125 GB
+        # c5s / c5u: the slice of configs[4] one GPU of eight would hold (25M/8 columns) -- 125 GB
         d_total = args.params or (10_000_000 if args.workload == 'c4' else 3_125_000 * world)
         primary = 'columns' if args.layout == 'both' else args.layout
-        wl = BulyanSharded(torch, agg, eng, n, d_total, device, 1237, with_attack=args.workload == 'c5s', layout=primary)
+        wl = BulyanSharded(torch, agg, eng, n, d_total, device, 1237, with_attack=args.workload != 'c4', layout=primary,
+                           distinct=args.workload == 'c5u')
     elif args.workload == 'c3':
         wl = TrimmedMeanC3(torch, eng, args.clients or 1000, args.params or 1_000_000, device, 1236)
     elif args.workload == 'c2':
@@ -662,42 +806,43 @@ def main():
     agg.comm_report()     # drop whatever the set-up booked
     elapsed, per_kernel = timed_steps(torch, dist, wl, eng, args.steps, args.warmup, world)
     ms_per_step = elapsed / args.steps * 1e3
-    # the timed steps' collectives: bytes THIS rank received and the time its compute stream spent in (or, for the
-    # overlapped gathers, waiting for) each of them, per step
-    collectives = {k: {'calls_per_step': v['calls'] / args.steps, 'MB_per_step': v['bytes'] / args.steps / 1e6,
-                       'ms_per_step': v['ms'] / args.steps} for k, v in agg.comm_report().items()}
     line = {
         'metric': 'aggregation rounds/sec at N clients x D params (%s)' % wl.defence,
-        'value': args.steps / elapsed, 'unit': 'rounds/s', 'n_gpus': args.gpus, 'steps': args.steps,
+        'value': args.steps / elapsed, 'unit': 'rounds/s', 'n_gpus': n_gpus, 'ranks_seen': seen, 'steps': args.steps,
         'warmup': args.warmup, 'ms_per_step': ms_per_step, 'higher_is_better': True,
-        'scaling': 'strong', 'vs_baseline': None, 'dtype': wl.dtype(), 'data': 'synthetic',
-        'config': wl.config(),
+        'scaling': 'weak' if args.workload in ('c5s', 'c5u') else 'strong', 'vs_baseline': None, 'dtype': wl.dtype(),
+        'data': 'synthetic', 'config': wl.config(),
         'roofline': roofline_of(wl, per_kernel, traffic, args.steps),
         'kernels': kernel_table(per_kernel, args.steps),
-        'collectives': collectives,
+        'collectives': collectives_table(agg, args.steps),
     }
     if hasattr(wl, 'verify'):
         line['verified_after_timing'] = wl.verify()
     if world == 1 and isinstance(wl, BulyanSharded) and wl.layout == 'columns':
         line['projected'] = projected_scaling(wl, line['kernels'], ms_per_step)
-    if args.workload in ('c4', 'c5s') and (args.layout == 'both' or (world > 1 and args.layout == 'columns'
-                                                                    and os.environ.get('BYZ_BENCH_ONE_LAYOUT') != '1')):
+    if args.workload in ('c4', 'c5s', 'c5u') and (args.layout == 'both' or (world > 1 and args.layout == 'columns'
+                                                                           and os.environ.get('BYZ_BENCH_ONE_LAYOUT') != '1')):
         # the other layout, same K steps: north_star names client sharding with an all-gather of row tiles; which one is
         # faster is a measurement, so every multi-GPU run records both
         other_name = 'clients' if wl.layout == 'columns' else 'columns'
         del wl.g
         torch.cuda.empty_cache()
-        other = BulyanSharded(torch, agg, eng, n, d_total, device, 1237, with_attack=args.workload == 'c5s', layout=other_name)
-        agg.comm_report()
-        e2, pk2 = timed_steps(torch, dist, other, eng, args.steps, args.warmup, world)
-        line['other_layout'] = {
-            'layout': other_name, 'value': args.steps / e2, 'unit': 'rounds/s', 'ms_per_step': e2 / args.steps * 1e3,
-            'config': other.config(), 'roofline': roofline_of(other, pk2, None, args.steps), 'kernels': kernel_table(pk2, args.steps),
-            'collectives': {k: {'calls_per_step': v['calls'] / args.steps, 'MB_per_step': v['bytes'] / args.steps / 1e6,
-                                'ms_per_step': v['ms'] / args.steps} for k, v in agg.comm_report().items()}}
+        other = BulyanSharded(torch, agg, eng, n, d_total, device, 1237, with_attack=args.workload != 'c4', layout=other_name,
+                              distinct=args.workload == 'c5u')
+        rec = bulyan_record(torch, dist, other, eng, agg, args.steps, args.warmup, world, None)
+        rec['layout'] = other_name
+        line['other_layout'] = rec
         wl = other
 
     if rank == 0 and world == 1:
+        if args.workload == 'c4' and not args.no_sharded_w1 and not dist.is_initialized():
+            line['sharded_path_w1'] = sharded_path_at_one_rank(torch, dist, wl, eng, device, traffic)
+            if wl.layout == 'columns' and 'columns' in line['sharded_path_w1']:
+                # the projection is built from the kernels that run at W > 1 (Gram -> all-reduce -> distances + near pairs)
+                rec = line['sharded_path_w1']['columns']
+                booked = sum(v['ms_per_step'] for v in rec['collectives'].values())
+                line['projected'] = projected_scaling(wl, rec['kernels'], rec['ms_per_step'] - booked)
+                line['projected']['built_from'] = 'sharded_path_w1.columns (collectives forced at one rank; their time at W = 1 subtracted)'
         if not args.no_cpu_baseline:
             line['cpu_baseline'] = cpu_baseline(wl, args.cpu_seconds)
         if not args.no_extras and args.workload == 'c4':
@@ -727,6 +872,20 @@ def main():
                                'kernels': kernel_table(pk2, k2)}
                 del w2
                 torch.cuda.empty_cache()
+            if not args.no_north_star:
+                # BASELINE configs[4]'s slice of one GPU of eight (N = 10,000, D = 25M / 8), with and without the
+                # identical-row shortcut: c5s = the attack as the reference runs it (its m rows are ONE vector, the Gram runs
+                # over the N - m + 1 unique rows); c5u = 10,000 DISTINCT rows (an attacker who adds per-row noise: nothing to
+                # fold), the full N^2 D Gram.  Both with the 8-GPU projection.
+                for name in ('c5s', 'c5u'):
+                    w5 = BulyanSharded(torch, agg, eng, 10000, 3_125_000, device, 1237, with_attack=True, layout='columns',
+                                       distinct=name == 'c5u')
+                    rec = bulyan_record(torch, dist, w5, eng, agg, 5, 1, 1, traffic)
+                    rec['projected'] = projected_scaling(w5, rec['kernels'], rec['ms_per_step'])
+                    extras[name] = rec
+                    w5.g = None
+                    del w5
+                    torch.cuda.empty_cache()
             line['other_workloads'] = extras
     if rank == 0:
         # RCCL writes its NCCL_DEBUG=VERSION banner through C stdio, which a pipe buffers until exit: push it out
@@ -739,6 +898,37 @@ def main():
         print(json.dumps(line), flush=True)
     if dist.is_initialized():
         dist.destroy_process_group()
+
+
+def sharded_path_at_one_rank(torch, dist, wl, eng, device, traffic, steps=2, warmup=1):
+    """The code path that runs at W > 1, timed on the one GPU there is: BYZ_FORCE_COLLECTIVES=1 makes ShardedAggregator issue
+    every collective through RCCL at world size 1, so the columns layout goes Gram -> all-reduce -> distances_from_gram +
+    near-pair exchange (not the engine's one-call composition the headline uses at W = 1), and the clients layout its
+    per-panel gather + tile share + N x N accumulation.  Same matrix as the headline (wl.g), few steps."""
+    from attacking_federate_learning_amd.sharded import HipKernels, ShardedAggregator
+    os.environ['BYZ_FORCE_COLLECTIVES'] = '1'
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    os.environ['MASTER_PORT'] = str(free_port())
+    os.environ['RANK'], os.environ['WORLD_SIZE'] = '0', '1'
+    out = {'note': 'BYZ_FORCE_COLLECTIVES=1 at world size 1: the W > 1 code path of sharded.py with every collective issued '
+                   'through RCCL (send-to-self); %d timed steps per layout' % steps}
+    dist.init_process_group('nccl', device_id=device)
+    try:
+        forced = ShardedAggregator(HipKernels(eng))
+        assert forced.always_collective
+        for layout in ('columns', 'clients'):
+            w = BulyanSharded(torch, forced, eng, wl.n, wl.d_total, device, 1237, with_attack=wl.with_attack, layout=layout,
+                              distinct=wl.distinct, g=wl.g)
+            rec = bulyan_record(torch, dist, w, eng, forced, steps, warmup, 1, None)
+            rec['layout'] = layout
+            out[layout] = rec
+            w.g = None
+            torch.cuda.empty_cache()
+    finally:
+        dist.destroy_process_group()
+        for key in ('BYZ_FORCE_COLLECTIVES', 'RANK', 'WORLD_SIZE', 'MASTER_PORT'):
+            os.environ.pop(key, None)
+    return out
 
 
 if __name__ == '__main__':

@@ -1,0 +1,99 @@
+"""Round-4 regression tests of the HIP path (needs an MI355X): the cases ADVICE r3 found by reading the code."""
+import numpy as np
+import pytest
+
+from oracle import faithful, scale
+
+pytestmark = pytest.mark.gpu
+
+
+def point_distances(seed, n, dim=16):
+    rng = np.random.default_rng(seed)
+    pts = rng.standard_normal((n, dim)).astype(np.float64)
+    sq = (pts * pts).sum(1)
+    dist = np.sqrt(np.maximum(sq[:, None] + sq[None, :] - 2.0 * (pts @ pts.T), 0.0)).astype(np.float32)
+    dist = np.minimum(dist, dist.T)
+    np.fill_diagonal(dist, np.inf)
+    return dist
+
+
+@pytest.mark.parametrize('n', [40, 129, 300, 1000])
+@pytest.mark.parametrize('slack', ['zero', 'beyond'])
+def test_krum_with_an_empty_prefix_is_the_reference(eng, n, slack):
+    """users_count - corrupted_count == 0 (or <= -(n - 1)): sorted(...)[:k] is empty, sum([]) == 0 < 1e20 for every row and the
+    first row visited -- row 1 -- wins (defences.py:27-37).  Reachable through return_index=True, which skips the assert.  The
+    general path's row sort used to skip the store of the empty sum and krum_argmin read stale scores."""
+    dist = point_distances(n, n)
+    users, corrupted = (n, n) if slack == 'zero' else (n, 2 * n + 5)
+    want = faithful.krum_pick(dist, faithful.visit_order(n), users, corrupted)
+    assert want == 1
+    # poison the context's score buffer with a run whose scores are large and whose winner is not row 1
+    eng.krum_select(dist[::-1, ::-1].copy(), n, 1)
+    assert eng.krum_select(dist, users, corrupted) == want
+    g = np.random.default_rng(n).standard_normal((n, 64)).astype(np.float32)
+    from attacking_federate_learning_amd import defences
+    assert defences.krum(g, users, corrupted, return_index=True) == faithful.krum(g, users, corrupted, return_index=True) == 1
+
+
+def test_engine_krum_takes_the_reference_positional_debug(eng):
+    """krum(users_grads, users_count, corrupted_count, distances, return_index, debug): `debug` sits where the engine's `check`
+    keyword used to be: a positional True must not switch the safety check off, nor raise."""
+    torch = pytest.importorskip('torch')
+    g = torch.randn((12, 300), device='cuda')
+    idx = eng.krum(g, 12, 3, None, True, True)
+    row = eng.krum(g, 12, 3, None, False, True)
+    assert torch.equal(row, g[idx])
+    with pytest.raises(TypeError):
+        eng.krum(g, 12, 3, None, False, True, False)
+
+
+@pytest.mark.parametrize('n,twins', [(2944, 100), (3000, 40)])
+def test_twins_in_row_blocks_split_at_different_scales(eng, monkeypatch, n, twins):
+    """The attack's identical rows, too few of them to drop a row of Gram tiles (so the Gram runs over all N rows), spread over
+    many 32-row blocks of the operand split, with a wide dynamic range inside every row (elements far below 2^-17 of the
+    row's largest: their fp16 planes are subnormal and depend on the shift) and planted outliers that send SOME blocks of the
+    sampled split to the exact two-pass redo: twins then sit in blocks split at different shifts and their Gram entries are
+    no longer bitwise equal.  Their distance must still be exactly zero and their distance rows identical -- by
+    the byte-for-byte proof of dedup.hip, not by cancellation -- and the selections the reference's on those distances."""
+    torch = pytest.importorskip('torch')
+    d = 3 * 8192 + 64
+    gen = torch.Generator(device='cuda').manual_seed(n)
+    g = torch.randn((n, d), generator=gen, device='cuda', dtype=torch.float32)
+    g *= torch.pow(2.0, torch.randint(-30, 1, (n, d), generator=gen, device='cuda').float())   # 30 binades inside a row
+    rows = torch.randperm(n, generator=gen, device='cuda')[:twins]
+    twin = g[rows[0]].clone()
+    g[rows] = twin
+    # outliers 2^12 above anything sampled, in unsampled columns, in a few row blocks that also hold a twin
+    for r in rows[: twins // 3].tolist():
+        other = (r // 32) * 32 + ((r + 1) % 32)
+        if other < n and other not in rows.tolist():
+            g[other, 5 + 8192] = 4096.0
+            g[other, 777] = -8192.0
+    monkeypatch.delenv('BYZ_GRAM_MODE', raising=False)
+    dist = eng.pairwise_distances(g).numpy()
+    idx = sorted(rows.tolist())
+    sub = dist[np.ix_(idx, idx)]
+    assert np.all(sub[~np.eye(len(idx), dtype=bool)] == 0.0)
+    keep = np.ones(n, dtype=bool)
+    keep[idx] = False
+    for r in idx[1:]:
+        assert np.array_equal(dist[idx[0], keep], dist[r, keep])
+    assert np.array_equal(dist, dist.T)
+    # against the exact two-pass split: the same matrix to rounding
+    monkeypatch.setenv('BYZ_GRAM_SPLIT_TWO_PASS', '1')
+    exact = eng.pairwise_distances(g).numpy()
+    monkeypatch.delenv('BYZ_GRAM_SPLIT_TWO_PASS')
+    off = ~np.eye(n, dtype=bool)
+    assert np.allclose(dist[off], exact[off], rtol=1e-6, atol=0.0)
+    assert np.array_equal(dist[off] == 0.0, exact[off] == 0.0)
+    # sampled fp64 check of non-twin distances
+    some = [0, 1, idx[0], n // 2, n - 1]
+    host = g[some].cpu().numpy().astype(np.float64)
+    for a in range(len(some)):
+        for b in range(a):
+            want = np.sqrt(((host[a].astype(np.float32) - host[b].astype(np.float32)).astype(np.float64) ** 2).sum())
+            assert abs(dist[some[a], some[b]] - want) <= 1e-6 * want
+    f = int(0.24 * n)
+    assert eng.krum_select(dist, n, f) == scale.krum_pick(dist, n, f)
+    got = list(eng.bulyan_select(dist, n, f))
+    assert got == scale.bulyan_selection(dist, n, f)
