@@ -362,31 +362,35 @@ __device__ __forceinline__ void wait_vmcnt() {
 __device__ __forceinline__ void wait_vmcnt_dyn(int n) {   // n is wave-uniform; only the first and last stages of a chunk
     switch (n) {
 #define BYZ_W(k) case k: wait_vmcnt<k>(); break;
-        BYZ_W(0) BYZ_W(3) BYZ_W(4) BYZ_W(5) BYZ_W(6) BYZ_W(8) BYZ_W(9) BYZ_W(10) BYZ_W(12) BYZ_W(15) BYZ_W(16) BYZ_W(20)
+        BYZ_W(0) BYZ_W(3) BYZ_W(4) BYZ_W(5) BYZ_W(6) BYZ_W(8) BYZ_W(9) BYZ_W(10) BYZ_W(12) BYZ_W(15) BYZ_W(16) BYZ_W(18) BYZ_W(20) BYZ_W(24)
 #undef BYZ_W
         default: wait_vmcnt<0>(); break;
     }
 }
 
-template <int PLANES>
+template <int PLANES, int MB>
 struct Frags;
-template <>
-struct Frags<3> {
+template <int MB>
+struct Frags<3, MB> {
     typedef bf16x8 frag_t;
-    bf16x8 a[3][2], b[3][2];   // [plane h, m, l][block]
+    bf16x8 a[3][MB], b[3][2];   // [plane h, m, l][block]
 };
-template <>
-struct Frags<2> {
+template <int MB>
+struct Frags<2, MB> {
     typedef f16x8 frag_t;
-    f16x8 a[2][2], b[2][2];    // [plane h, m][block]
+    f16x8 a[2][MB], b[2][2];    // [plane h, m][block]
 };
 
 // PLANES = 3: bf16x3 (gram.hip's arithmetic), 2: f16x2.  NBUF stages of LDS; the DMA runs NBUF stages ahead.
 // DBG (timing experiments only, wrong results; scripts/gram_ab.py): bit 0 no DMA after the first NBUF stages,
 // bit 1 no MFMA, bit 2 no workgroup barrier in the steady loop, bit 3 no LDS reads after stage 0, bit 4 no slab update,
 // bit 5 every workgroup's DMA reads tile (0, 0) (the L2 -> LDS rate without misses).
-template <int PLANES, int NBUF, int DBG>
-__global__ __launch_bounds__(kThreads, 1) void gram_planes_kernel(const u32x4* __restrict__ planes, int64_t n_steps,
+// MB = 32-row blocks of a wave's sub-tile along the A side: 2 -> eight waves of 64 x 64 (two per SIMD, round 2's geometry),
+// 4 -> FOUR waves of 128 x 64, one per SIMD with the 512-register budget (accumulators in AGPRs): a quarter fewer LDS fragment
+// reads per MFMA (12 ds_read_b128 per 24 MFMAs instead of 8 per 12), the same DMA bytes.  Every output element goes through
+// the same MFMA chain in the same order either way: the Gram is bitwise the same (BYZ_GRAM_WAVE_TILE).
+template <int PLANES, int NBUF, int DBG, int MB = 2>
+__global__ __launch_bounds__(64 * 16 / MB, 1) void gram_planes_kernel(const u32x4* __restrict__ planes, int64_t n_steps,
                                                                   const double* __restrict__ unscale, int64_t rows_pad,
                                                                   double* __restrict__ partial, int n_tiles,
                                                                   const int2* __restrict__ tile_order, int n_chunks,
@@ -394,11 +398,13 @@ __global__ __launch_bounds__(kThreads, 1) void gram_planes_kernel(const u32x4* _
                                                                   int slab_live0, int32_t* __restrict__ device_status) {
     constexpr int kRbBytes = PLANES * kFragBytes;           // one 32-row block, one stage: [plane][1 KiB]
     constexpr int kStage = kRowBlocks * kRbBytes;           // 36,864 (bf16x3) / 24,576 (f16x2)
+    constexpr int NW = 16 / MB;                             // waves of the workgroup
     constexpr int kPieces = kRowBlocks * PLANES;            // 1 KiB pieces per stage
-    constexpr int kPerWave = (kPieces + 7) / 8;             // DMA instructions per wave and stage (the last may be idle)
-    constexpr int kFullWaves = kPieces % 8 == 0 ? 8 : kPieces % 8;   // waves that issue all kPerWave
+    constexpr int kPerWave = (kPieces + NW - 1) / NW;       // DMA instructions per wave and stage (the last may be idle)
+    constexpr int kFullWaves = kPieces % NW == 0 ? NW : kPieces % NW;   // waves that issue all kPerWave
     constexpr int kLead = NBUF;
-    typedef typename Frags<PLANES>::frag_t frag_t;
+    typedef Frags<PLANES, MB> frags_t;
+    typedef typename frags_t::frag_t frag_t;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];   // [NBUF][12 row blocks][planes][1 KiB]
 
     // workgroup -> (tile, chunk): XCD x owns a contiguous share of the tile list and works through it chunk by chunk
@@ -435,7 +441,8 @@ __global__ __launch_bounds__(kThreads, 1) void gram_planes_kernel(const u32x4* _
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave >> 1, wc = wave & 1;
-    const int ti = 2 * bi + (wr >> 1);                 // this wave's slab row
+    const int ti = 2 * bi + (wr * MB) / 4;             // this wave's slab row
+    const int row_in_slab = ((wr * MB) % 4) * 32;      // and where its sub-tile starts inside it
     const bool live_wave = tj <= ti && ti < t128;      // the upper half of a tile that straddles the diagonal is not needed
 
     const int step0 = chunk * kChunkSteps;
@@ -447,7 +454,7 @@ __global__ __launch_bounds__(kThreads, 1) void gram_planes_kernel(const u32x4* _
     int64_t piece_off[kPerWave];
 #pragma unroll
     for (int i = 0; i < kPerWave; ++i) {
-        int q = wave + 8 * i;
+        int q = wave + NW * i;
         if (q >= kPieces) q = kPieces - 1;
         const int rbl = q / PLANES, piece = q % PLANES;
         int64_t rb = rbl < 8 ? static_cast<int64_t>(bi) * 8 + rbl : static_cast<int64_t>(tj) * 4 + (rbl - 8);
@@ -461,16 +468,16 @@ __global__ __launch_bounds__(kThreads, 1) void gram_planes_kernel(const u32x4* _
         unsigned char* dst = lds + (s % NBUF) * kStage + wave * kFragBytes;
 #pragma unroll
         for (int i = 0; i < kPerWave; ++i) {
-            if (kFullWaves != 8 && i == kPerWave - 1 && wave >= kFullWaves) break;   // wave-uniform
+            if (kFullWaves != NW && i == kPerWave - 1 && wave >= kFullWaves) break;   // wave-uniform
             __builtin_amdgcn_global_load_lds(
                 (const __attribute__((address_space(1))) void*)(lane_base + piece_off[i] + static_cast<int64_t>(s) * (PLANES * kFragBytes)),
-                (__attribute__((address_space(3))) void*)(dst + i * 8 * kFragBytes), 16, 0, 0);
+                (__attribute__((address_space(3))) void*)(dst + i * NW * kFragBytes), 16, 0, 0);
         }
     };
 
-    f32x16 acc[2][2], acc2[2][2];
+    f32x16 acc[MB][2], acc2[MB][2];
 #pragma unroll
-    for (int m = 0; m < 2; ++m)
+    for (int m = 0; m < MB; ++m)
 #pragma unroll
         for (int n = 0; n < 2; ++n)
 #pragma unroll
@@ -479,19 +486,19 @@ __global__ __launch_bounds__(kThreads, 1) void gram_planes_kernel(const u32x4* _
                 acc2[m][n][e] = 0.0f;
             }
 
-    auto read_frags = [&](int s, Frags<PLANES>& f) __attribute__((always_inline)) {
+    auto read_frags = [&](int s, frags_t& f) __attribute__((always_inline)) {
         if ((DBG & 8) && s > 0) return;
-        const unsigned char* A = lds + (s % NBUF) * kStage + (2 * wr) * kRbBytes + lane * 16;
+        const unsigned char* A = lds + (s % NBUF) * kStage + (MB * wr) * kRbBytes + lane * 16;
         const unsigned char* B = lds + (s % NBUF) * kStage + (8 + 2 * wc) * kRbBytes + lane * 16;
 #pragma unroll
-        for (int p = 0; p < PLANES; ++p)
+        for (int p = 0; p < PLANES; ++p) {
 #pragma unroll
-            for (int m = 0; m < 2; ++m) {
-                f.a[p][m] = *reinterpret_cast<const frag_t*>(A + m * kRbBytes + p * kFragBytes);
-                f.b[p][m] = *reinterpret_cast<const frag_t*>(B + m * kRbBytes + p * kFragBytes);
-            }
+            for (int m = 0; m < MB; ++m) f.a[p][m] = *reinterpret_cast<const frag_t*>(A + m * kRbBytes + p * kFragBytes);
+#pragma unroll
+            for (int n = 0; n < 2; ++n) f.b[p][n] = *reinterpret_cast<const frag_t*>(B + n * kRbBytes + p * kFragBytes);
+        }
     };
-    auto multiply = [&](const Frags<PLANES>& f) __attribute__((always_inline)) {
+    auto multiply = [&](const frags_t& f) __attribute__((always_inline)) {
         if constexpr (PLANES == 3) {
             // h h' + h m' + m h' + m m' + h l' + l h', smallest terms first, term-major over the four accumulators:
             // the order of gram.hip's split mode
@@ -500,7 +507,7 @@ __global__ __launch_bounds__(kThreads, 1) void gram_planes_kernel(const u32x4* _
 #pragma unroll
             for (int t = 0; t < 6; ++t)
 #pragma unroll
-                for (int m = 0; m < 2; ++m)
+                for (int m = 0; m < MB; ++m)
 #pragma unroll
                     for (int n = 0; n < 2; ++n)
                         acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[pa[t]][m], f.b[pb[t]][n], acc[m][n], 0, 0, 0);
@@ -510,7 +517,7 @@ __global__ __launch_bounds__(kThreads, 1) void gram_planes_kernel(const u32x4* _
 #pragma unroll
             for (int t = 0; t < 3; ++t)
 #pragma unroll
-                for (int m = 0; m < 2; ++m)
+                for (int m = 0; m < MB; ++m)
 #pragma unroll
                     for (int n = 0; n < 2; ++n)
                         acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.a[pa[t]][m], f.b[pb[t]][n], acc[m][n], 0, 0, 0);
@@ -519,7 +526,7 @@ __global__ __launch_bounds__(kThreads, 1) void gram_planes_kernel(const u32x4* _
     auto flush = [&](int s) __attribute__((always_inline)) {
         if ((s + 1) % kFlushSteps == 0) {
 #pragma unroll
-            for (int m = 0; m < 2; ++m)
+            for (int m = 0; m < MB; ++m)
 #pragma unroll
                 for (int n = 0; n < 2; ++n)
 #pragma unroll
@@ -530,7 +537,7 @@ __global__ __launch_bounds__(kThreads, 1) void gram_planes_kernel(const u32x4* _
         }
     };
     // one stage: multiply `cur` (stage s, in registers), read stage s + 1 into `next`, keep the DMA kLead stages ahead
-    auto steady = [&](int s, const Frags<PLANES>& cur, Frags<PLANES>& next) __attribute__((always_inline)) {
+    auto steady = [&](int s, const frags_t& cur, frags_t& next) __attribute__((always_inline)) {
         dma(s + kLead);                       // into the buffer of stage s, whose last readers passed the previous barrier
         if (live_wave && !(DBG & 2)) {
             read_frags(s + 1, next);
@@ -538,13 +545,13 @@ __global__ __launch_bounds__(kThreads, 1) void gram_planes_kernel(const u32x4* _
         }
         // before anyone reads stage s + 2 it must have landed: of my requests only stages s + 3 .. s + kLead may be
         // outstanding (memory reads return in order, so that is a vmcnt bound)
-        if (kFullWaves == 8 || wave < kFullWaves) wait_vmcnt<(kLead - 2) * kPerWave>();
+        if (kFullWaves == NW || wave < kFullWaves) wait_vmcnt<(kLead - 2) * kPerWave>();
         else wait_vmcnt<(kLead - 2) * (kPerWave - 1)>();
         if (DBG & 4) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         else asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         if (live_wave) flush(s);
     };
-    auto drain = [&](int s, const Frags<PLANES>& cur, Frags<PLANES>& next) __attribute__((always_inline)) {
+    auto drain = [&](int s, const frags_t& cur, frags_t& next) __attribute__((always_inline)) {
         if (s + kLead < n_stages) dma(s + kLead);
         if (live_wave && !(DBG & 2)) {
             if (s + 1 < n_stages) read_frags(s + 1, next);
@@ -557,7 +564,7 @@ __global__ __launch_bounds__(kThreads, 1) void gram_planes_kernel(const u32x4* _
         if (live_wave) flush(s);
     };
 
-    Frags<PLANES> x, y;
+    frags_t x, y;
     for (int a = 0; a < kLead && a < n_stages; ++a) dma(a);
     {
         const int issued = n_stages < kLead ? n_stages : kLead;
@@ -599,7 +606,7 @@ __global__ __launch_bounds__(kThreads, 1) void gram_planes_kernel(const u32x4* _
     } else if (live_wave && (DBG & 16)) {
         float all = 0.0f;   // keeps the accumulators alive without the slab traffic
 #pragma unroll
-        for (int m = 0; m < 2; ++m)
+        for (int m = 0; m < MB; ++m)
 #pragma unroll
             for (int n = 0; n < 2; ++n)
 #pragma unroll
@@ -610,7 +617,7 @@ __global__ __launch_bounds__(kThreads, 1) void gram_planes_kernel(const u32x4* _
         double* out = partial + (static_cast<int64_t>(ti) * (ti + 1) / 2 + tj) * (kSlab * kSlab);
         const double* un = PLANES == 2 ? unscale + static_cast<int64_t>(chunk) * rows_pad : nullptr;
 #pragma unroll
-        for (int m = 0; m < 2; ++m)
+        for (int m = 0; m < MB; ++m)
 #pragma unroll
             for (int n = 0; n < 2; ++n) {
                 const int j = wc * 64 + n * 32 + (lane & 31);
@@ -618,7 +625,7 @@ __global__ __launch_bounds__(kThreads, 1) void gram_planes_kernel(const u32x4* _
                 if constexpr (PLANES == 2) uj = un[static_cast<int64_t>(tj) * kSlab + j];
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
-                    const int i = (wr & 1) * 64 + m * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+                    const int i = row_in_slab + m * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
                     double v = static_cast<double>(acc2[m][n][e]);
                     v += static_cast<double>(acc[m][n][e]);
                     if constexpr (PLANES == 2) v *= un[static_cast<int64_t>(ti) * kSlab + i] * uj;   // powers of two: exact
@@ -712,7 +719,9 @@ int launch_gram_planes(byz_ctx* ctx, const float* G, int64_t n_rows, int64_t n_c
     u32x4* planes = ctx->gram_planes.as<u32x4>();
     // BYZ_GRAM_PLANES_VARIANT: 0 production; 4: f16x2 with four LDS stages; the others are timing experiments with wrong
     // results (the DBG bits of the kernel, times ten)
-    const int variant = env_int("BYZ_GRAM_PLANES_VARIANT", 0);
+    int variant = env_int("BYZ_GRAM_PLANES_VARIANT", 0);
+    if (variant == 0 && f16 && env_int("BYZ_GRAM_WAVE_TILE", 64) == 128) variant = 1280;
+    const int threads = (f16 && variant >= 1280 && variant <= 1282) ? 256 : kThreads;
     typedef void (*kernel_t)(const u32x4*, int64_t, const double*, int64_t, double*, int, const int2*, int, int*, int, int,
                              int, int32_t*);
     kernel_t kernel;
@@ -727,7 +736,10 @@ int launch_gram_planes(byz_ctx* ctx, const float* G, int64_t n_rows, int64_t n_c
                  : variant == 160 ? &gram_planes_kernel<2, 6, 16>    // everything but the slab update
                  : variant == 340 ? &gram_planes_kernel<2, 6, 34>    // DMA only, every workgroup the same tile
                  : variant == 320 ? &gram_planes_kernel<2, 6, 32>    // everything, every workgroup the same tile
-                                  : &gram_planes_kernel<2, 6, 0>;
+                 : variant == 1280 ? &gram_planes_kernel<2, 6, 0, 4>   // 128 x 64 wave tiles, one wave per SIMD
+                 : variant == 1281 ? &gram_planes_kernel<2, 6, 13, 4>  //   ... its MFMAs, loop and slab update only
+                 : variant == 1282 ? &gram_planes_kernel<2, 6, 1, 4>   //   ... without the DMA
+                                   : &gram_planes_kernel<2, 6, 0>;
     } else {
         nbuf = 4;
         kernel = variant == 10 ? &gram_planes_kernel<3, 4, 1> : variant == 20 ? &gram_planes_kernel<3, 4, 2>
@@ -779,7 +791,7 @@ int launch_gram_planes(byz_ctx* ctx, const float* G, int64_t n_rows, int64_t n_c
                 set_error("gram: grid too large");
                 return BYZ_E_UNSUPPORTED;
             }
-            kernel<<<static_cast<unsigned>(grid), kThreads, lds_bytes, stream>>>(
+            kernel<<<static_cast<unsigned>(grid), threads, lds_bytes, stream>>>(
                 planes, n_steps, unscale, rows_pad, slabs, static_cast<int>(n_tiles), ctx->plane_order.as<int2>(),
                 static_cast<int>(n_chunks), tickets, round_size, static_cast<int>(t128), sc > 0 ? 1 : 0,
                 device_status_word(ctx));

@@ -394,14 +394,19 @@ class ShardedAggregator:
         pitch = -(-(hi - lo) // 4) * 4
         out = torch.empty((len(wanted_rows), pitch), dtype=rows_local.dtype, device=device)[:, :hi - lo]
         all_of_mine = len(mine) == rows_local.shape[0] and np.array_equal(mine, np.arange(rows_local.shape[0]))
-        picked = rows_local if all_of_mine else rows_local.index_select(0, mine_t)
+
+        def block_for(p):
+            """My wanted rows x rank p's columns, contiguous: ONE gather per peer straight out of the caller's matrix (the
+            first version gathered the rows with all D columns and then cut every peer's block out of that copy: twice the
+            memory -- 83 + 83 GB next to a 160 GB matrix at configs[3] on one rank)."""
+            cols = rows_local[:, bounds[p][0]:bounds[p][1]]
+            return cols.contiguous() if all_of_mine else cols.index_select(0, mine_t)
         blocks_in = [out[int(starts[p]):int(starts[p + 1])] for p in range(self.world)]
         through_rccl = self.always_collective          # the rank's own block as a send-to-self (tests the P2P path on one GPU)
         if not through_rccl:
-            blocks_in[self.rank].copy_(picked[:, lo:hi])
+            blocks_in[self.rank].copy_(rows_local[:, lo:hi] if all_of_mine else block_for(self.rank))
         if self.world > 1 or through_rccl:
-            blocks_out = [picked[:, bounds[p][0]:bounds[p][1]].contiguous() if (p != self.rank or through_rccl) else picked[:0]
-                          for p in range(self.world)]
+            blocks_out = [block_for(p) if (p != self.rank or through_rccl) else rows_local[:0] for p in range(self.world)]
             self._exchange(name, blocks_out, blocks_in)
         plain = np.array_equal(row_index, np.arange(len(wanted_rows)))
         return out, (None if plain else row_index)

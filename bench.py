@@ -917,8 +917,12 @@ def sharded_path_at_one_rank(torch, dist, wl, eng, device, traffic, steps=2, war
         forced = ShardedAggregator(HipKernels(eng))
         assert forced.always_collective
         for layout in ('columns', 'clients'):
-            w = BulyanSharded(torch, forced, eng, wl.n, wl.d_total, device, 1237, with_attack=wl.with_attack, layout=layout,
-                              distinct=wl.distinct, g=wl.g)
+            # clients at one rank re-shards the theta selected rows through a send-to-self: a second and third copy of
+            # theta x D floats next to the 160 GB matrix.  That leg therefore runs on the first quarter of the columns (a
+            # strided view of the same matrix: 40 GB), and says so in its config.
+            cols = wl.d_total if layout == 'columns' else wl.d_total // 4
+            w = BulyanSharded(torch, forced, eng, wl.n, cols, device, 1237, with_attack=wl.with_attack, layout=layout,
+                              distinct=wl.distinct, g=wl.g if cols == wl.d_total else wl.g[:, :cols])
             rec = bulyan_record(torch, dist, w, eng, forced, steps, warmup, 1, None)
             rec['layout'] = layout
             out[layout] = rec

@@ -97,3 +97,27 @@ def test_twins_in_row_blocks_split_at_different_scales(eng, monkeypatch, n, twin
     assert eng.krum_select(dist, n, f) == scale.krum_pick(dist, n, f)
     got = list(eng.bulyan_select(dist, n, f))
     assert got == scale.bulyan_selection(dist, n, f)
+
+
+@pytest.mark.parametrize('n,d,dup', [(2900, 3 * 8192 + 100, 0), (3300, 2 * 8192 + 33 * 32 + 4, 700), (4000, 5 * 8192 + 36, 0)])
+def test_gram_with_128x64_wave_tiles_is_bitwise_the_production_gram(eng, monkeypatch, n, d, dup):
+    """gram_planes_kernel<2, 6, 0, MB = 4>: four waves of 128 x 64 (one per SIMD, accumulators in AGPRs) instead of eight of
+    64 x 64.  Every Gram entry goes through the same MFMA chain in the same order: the fp64 Gram must be IDENTICAL, with a
+    ragged K tail, an odd number of slab rows, several super-chunks and the identical-row indirection."""
+    torch = pytest.importorskip('torch')
+    gen = torch.Generator(device='cuda').manual_seed(4100 + n)
+    g = torch.randn((n, d), generator=gen, device='cuda', dtype=torch.float32)
+    g *= (1.0 + 0.5 * torch.rand((n, 1), generator=gen, device='cuda'))
+    if dup:
+        g[torch.randperm(n, device='cuda')[:dup]] = g[7].clone()
+    monkeypatch.delenv('BYZ_GRAM_MODE', raising=False)
+    monkeypatch.setenv('BYZ_GRAM_PLANES', '1')
+    monkeypatch.setenv('BYZ_GRAM_WAVE_TILE', '64')
+    base = eng.gram(g).clone()
+    monkeypatch.setenv('BYZ_GRAM_WAVE_TILE', '128')
+    wide = eng.gram(g).clone()
+    monkeypatch.setenv('BYZ_GRAM_PLANE_MB', '300')
+    wide_many = eng.gram(g).clone()
+    eng.check()
+    assert torch.equal(base, wide), float((base - wide).abs().max())
+    assert torch.equal(base, wide_many)
