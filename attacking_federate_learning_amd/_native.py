@@ -33,6 +33,7 @@ _PROTOTYPES = {
     'byz_pairwise_distances_dev': [c_vp, c_vp, c_i64, c_i64, c_i64, c_vp, c_vp],
     'byz_gram_dev': [c_vp, c_vp, c_i64, c_i64, c_i64, c_vp, c_vp],
     'byz_gram_share_dev': [c_vp, c_vp, c_i64, c_i64, c_i64, c_vp, c_int, c_int, c_vp, c_vp],
+    'byz_gram_share_add_dev': [c_vp, c_vp, c_i64, c_i64, c_i64, c_vp, c_int, c_int, c_vp, c_vp],
     'byz_distances_from_gram_dev': [c_vp, c_vp, c_i64, c_vp, c_vp],
     'byz_near_pairs_count': [c_vp, _P(c_i64), c_vp],
     'byz_near_pairs_sqdist_dev': [c_vp, c_vp, c_i64, c_i64, c_i64, c_vp, c_vp, c_vp],
@@ -51,6 +52,7 @@ _PROTOTYPES = {
     'byz_backdoor_initial_params_dev': [c_vp, c_vp, c_vp, c_i64, c_f32, c_vp, c_vp],
     'byz_backdoor_clip_dev': [c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_f32, c_f32, c_vp, c_vp],
     'byz_assemble_row_dev': [c_vp, c_vp, c_i64, c_i64, c_i64, c_i64, c_i64, c_vp, c_vp, c_vp],
+    'byz_assemble_rows_dev': [c_vp, c_vp, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_vp, c_vp, c_vp],
     'byz_assemble_columns_dev': [c_vp, c_vp, c_i64, c_i64, c_i64, c_i64, c_vp, c_vp, c_vp],
     'byz_assemble_row_host': [c_vp, c_vp, c_i64, c_i64, c_i64, c_i64, c_vp, c_vp],
     'byz_defend_host': [c_vp, c_int, c_vp, c_i64, c_i64, c_i64, c_i64, c_int, c_vp, c_vp],

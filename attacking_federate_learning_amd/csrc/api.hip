@@ -305,6 +305,13 @@ int byz_gram_share_dev(byz_ctx* ctx, const float* G, int64_t n_rows, int64_t n_c
     return launch_gram_share(ctx, G, n_rows, n_cols, ld, row_index, share_count, share_index, gram, as_stream(stream));
 }
 
+int byz_gram_share_add_dev(byz_ctx* ctx, const float* G, int64_t n_rows, int64_t n_cols, int64_t ld,
+                           const int32_t* row_index, int share_count, int share_index, double* gram, void* stream) {
+    BYZ_TRY(enter(ctx));
+    BYZ_REQUIRE(G && n_rows > 0 && n_cols > 0 && ld >= n_cols, "gram_share_add: bad matrix");
+    return launch_gram_share(ctx, G, n_rows, n_cols, ld, row_index, share_count, share_index, gram, as_stream(stream), true);
+}
+
 int byz_distances_from_gram_dev(byz_ctx* ctx, const double* gram, int64_t n_rows, float* dist, void* stream) {
     BYZ_TRY(enter(ctx));
     ctx->row_map_rows = 0;   // an external Gram: nothing is known about its rows
@@ -528,6 +535,19 @@ int byz_assemble_row_dev(byz_ctx* ctx, float* G, int64_t n_rows, int64_t n_cols,
     BYZ_REQUIRE(row >= 0 && row < n_rows, "assemble_row: row %lld outside 0..%lld", (long long)row, (long long)n_rows - 1);
     BYZ_REQUIRE(n_segments > 0 && segments_dev && lengths, "assemble_row: no segments");
     return launch_assemble_row(ctx, G + row * ld, n_cols, n_segments, segments_dev, lengths, as_stream(stream));
+}
+
+int byz_assemble_rows_dev(byz_ctx* ctx, float* G, int64_t n_rows, int64_t n_cols, int64_t ld, int64_t first_row,
+                          int64_t n_clients, int64_t n_segments, const float* const* segments_dev, const int64_t* lengths,
+                          void* stream) {
+    BYZ_TRY(enter(ctx));
+    BYZ_TRY(check_matrix(G, n_rows, n_cols, ld, "assemble_rows"));
+    BYZ_REQUIRE(first_row >= 0 && n_clients > 0 && first_row + n_clients <= n_rows,
+                "assemble_rows: rows %lld .. %lld outside 0..%lld", (long long)first_row, (long long)(first_row + n_clients - 1),
+                (long long)n_rows - 1);
+    BYZ_REQUIRE(n_segments > 0 && segments_dev && lengths, "assemble_rows: no segments");
+    return launch_assemble_rows(ctx, G + first_row * ld, n_cols, ld, n_clients, n_segments, segments_dev, lengths,
+                                as_stream(stream));
 }
 
 int byz_assemble_columns_dev(byz_ctx* ctx, float* G, int64_t n_rows, int64_t n_cols, int64_t ld, int64_t n_segments,

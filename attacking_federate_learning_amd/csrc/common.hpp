@@ -139,6 +139,7 @@ struct byz_ctx {
     byz::Buffer small_sync;      // krum_small.hip: flag / pair count / arrivals of the distance kernel's helpers
     int32_t small_epoch = 0;     // krum_small.hip: value the flag takes in the current launch
     bool small_configured = false;   // krum_small.hip: dynamic-LDS attributes set for this context's device
+    byz::Buffer assemble_table;  // byz_assemble_rows_dev: segment starts + every client's tensor pointers
     byz::Buffer stage_in;        // device copy of a host matrix
     byz::Buffer stage_out;       // device result before download
     byz::PinnedBuffer pinned;    // host bounce buffer for small results
@@ -221,6 +222,8 @@ int launch_assemble_row(byz_ctx* ctx, float* row, int64_t n_cols, int64_t n_segm
                         const int64_t* lengths, hipStream_t stream);
 int launch_assemble_columns(byz_ctx* ctx, float* G, int64_t n_rows, int64_t n_cols, int64_t ld, int64_t n_segments,
                             const float* const* segments, const int64_t* lengths, hipStream_t stream);
+int launch_assemble_rows(byz_ctx* ctx, float* G, int64_t n_cols, int64_t ld, int64_t n_clients, int64_t n_segments,
+                         const float* const* segments, const int64_t* lengths, hipStream_t stream);
 
 int launch_gram(byz_ctx* ctx, const float* G, int64_t n_rows, int64_t n_cols, int64_t ld, double* gram,
                 hipStream_t stream);
@@ -229,7 +232,7 @@ bool gram_planes_enabled();
 int launch_gram_planes(byz_ctx* ctx, const float* G, int64_t n_rows, int64_t n_cols, int64_t ld, const int32_t* row_index,
                        double* slabs, int share_count, int share_index, uint8_t* owned_host, bool f16, hipStream_t stream);
 int launch_gram_share(byz_ctx* ctx, const float* G, int64_t n_rows, int64_t n_cols, int64_t ld, const int32_t* row_index,
-                      int share_count, int share_index, double* gram, hipStream_t stream);
+                      int share_count, int share_index, double* gram, hipStream_t stream, bool accumulate = false);
 // dedup.hip: identical rows found before the Gram
 int find_unique_rows(byz_ctx* ctx, const float* G, int64_t n_rows, int64_t n_cols, int64_t ld, hipStream_t stream,
                      int64_t* n_unique_host);

@@ -475,7 +475,7 @@ __global__ __launch_bounds__(THREADS, 2) void gram_tile_kernel(const float* __re
 template <typename PartialT, int Q>
 __global__ __launch_bounds__(256) void gram_reduce_kernel(const PartialT* __restrict__ partial, int n_tiles,
                                                           int splits, int64_t n, double* __restrict__ gram,
-                                                          const uint8_t* __restrict__ tile_owned) {
+                                                          const uint8_t* __restrict__ tile_owned, int accumulate) {
     __shared__ double part[Q == 1 ? 1 : 256];
     const int jl = threadIdx.x & 63, q = threadIdx.x >> 6;
     const int64_t j = static_cast<int64_t>(blockIdx.x) * 64 + jl;
@@ -484,13 +484,17 @@ __global__ __launch_bounds__(256) void gram_reduce_kernel(const PartialT* __rest
     // addresses (the upper triangle reads the same slab entries 512 bytes apart) -- and the result is written twice.
     const bool live = i < n && j < n && (Q == 1 || j <= i);
     double s = 0.0;
+    bool mine = true;
     if (live) {
         const int64_t hi = i > j ? i : j, lo = i > j ? j : i;
         const int ti = static_cast<int>(hi / TM), tj = static_cast<int>(lo / TM);
         const int tile = ti * (ti + 1) / 2 + tj;
         const int64_t off = static_cast<int64_t>(tile) * (TM * TM) + (hi % TM) * TM + (lo % TM);
         const int64_t slab = static_cast<int64_t>(n_tiles) * (TM * TM);
-        if (tile_owned != nullptr && !tile_owned[tile]) {
+        // accumulate: the caller's matrix already holds the sum of earlier panels (byz_gram_share_add_dev): this panel's value
+        // is added in place -- the same fp64 addition, in the same panel order, a separate N x N `add_` pass did
+        mine = tile_owned == nullptr || tile_owned[tile] != 0;
+        if (!mine) {
             // a tile of another rank's share: this rank contributes zero to the all-reduced Gram
         } else if (Q == 1) {
             for (int sp = 0; sp < splits; ++sp) s += static_cast<double>(partial[sp * slab + off]);
@@ -508,12 +512,13 @@ __global__ __launch_bounds__(256) void gram_reduce_kernel(const PartialT* __rest
         }
     }
     if (Q == 1) {
-        if (live) gram[i * n + j] = s;
+        if (live && !(accumulate && !mine)) gram[i * n + j] = accumulate ? gram[i * n + j] + s : s;
     } else {
         part[threadIdx.x] = s;
         __syncthreads();
-        if (q == 0 && live) {
-            const double total = (part[jl] + part[64 + jl]) + (part[128 + jl] + part[192 + jl]);
+        if (q == 0 && live && !(accumulate && !mine)) {
+            double total = (part[jl] + part[64 + jl]) + (part[128 + jl] + part[192 + jl]);
+            if (accumulate) total += gram[i * n + j];
             gram[i * n + j] = total;
             gram[j * n + i] = total;
         }
@@ -815,7 +820,7 @@ int env_int(const char* name, int fallback) {
 // the sum of their outputs is the Gram (the client-sharded multi-GPU path, sharded.py).
 static int launch_gram_rows(byz_ctx* ctx, const float* G, int64_t n_rows, int64_t n_cols, int64_t ld,
                             const int32_t* row_index, double* gram, hipStream_t stream, int share_count = 1,
-                            int share_index = 0) {
+                            int share_index = 0, bool accumulate = false) {
     BYZ_REQUIRE(G && gram && n_rows > 0 && n_cols > 0 && ld >= n_cols, "gram: bad shape %lld x %lld ld %lld",
                 (long long)n_rows, (long long)n_cols, (long long)ld);
     BYZ_REQUIRE(share_count >= 1 && share_index >= 0 && share_index < share_count, "gram: bad share %d of %d",
@@ -829,7 +834,7 @@ static int launch_gram_rows(byz_ctx* ctx, const float* G, int64_t n_rows, int64_
     // tiles of this share: list positions share_index, share_index + share_count, ...
     const int64_t n_tiles = (n_tiles_all - share_index + share_count - 1) / share_count;
     if (n_tiles <= 0) {   // more ranks than tiles: nothing to compute here
-        BYZ_HIP(hipMemsetAsync(gram, 0, static_cast<size_t>(n_rows) * n_rows * sizeof(double), stream));
+        if (!accumulate) BYZ_HIP(hipMemsetAsync(gram, 0, static_cast<size_t>(n_rows) * n_rows * sizeof(double), stream));
         return BYZ_OK;
     }
     const int64_t stages = ceil_div(n_cols, BK);
@@ -980,7 +985,7 @@ static int launch_gram_rows(byz_ctx* ctx, const float* G, int64_t n_rows, int64_
         // four threads per entry only when entries alone cannot fill the chip (the 128 x 128 of one tile)
         const bool many = !chunked && splits >= 16 && n_rows * n_rows <= (1 << 18);
         dim3 grid(static_cast<unsigned>(ceil_div(n_rows, 64)), static_cast<unsigned>(many ? n_rows : ceil_div(n_rows, 4)));
-#define BYZ_REDUCE(T, Q) gram_reduce_kernel<T, Q><<<grid, 256, 0, stream>>>(ctx->gram_partials.as<T>(), (int)n_tiles_all, (int)(chunked ? 1 : splits), n_rows, gram, tile_owned)
+#define BYZ_REDUCE(T, Q) gram_reduce_kernel<T, Q><<<grid, 256, 0, stream>>>(ctx->gram_partials.as<T>(), (int)n_tiles_all, (int)(chunked ? 1 : splits), n_rows, gram, tile_owned, accumulate ? 1 : 0)
         if (wide) {
             if (many) BYZ_REDUCE(double, 4); else BYZ_REDUCE(double, 1);
         } else {
@@ -1015,9 +1020,9 @@ int launch_gram(byz_ctx* ctx, const float* G, int64_t n_rows, int64_t n_cols, in
 }
 
 int launch_gram_share(byz_ctx* ctx, const float* G, int64_t n_rows, int64_t n_cols, int64_t ld, const int32_t* row_index,
-                      int share_count, int share_index, double* gram, hipStream_t stream) {
+                      int share_count, int share_index, double* gram, hipStream_t stream, bool accumulate) {
     ctx->row_map_rows = 0;
-    return launch_gram_rows(ctx, G, n_rows, n_cols, ld, row_index, gram, stream, share_count, share_index);
+    return launch_gram_rows(ctx, G, n_rows, n_cols, ld, row_index, gram, stream, share_count, share_index, accumulate);
 }
 
 // Identical rows must end up with bitwise identical distance rows, because the reference resolves their exactly tied

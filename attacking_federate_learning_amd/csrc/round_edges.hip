@@ -18,6 +18,8 @@
 // Bytes per element: initial 12 (2 reads, 1 write); clip 20 (4 reads, 1 write); assembly 8 (1 read, 1 write).
 #include "common.hpp"
 
+#include <vector>
+
 // hipcc contracts a * b - c into an FMA by default (-ffp-contract=fast, and the __fmul_rn / __fsub_rn wrappers do not
 // stop it: they are inline functions carrying the same flag); numpy rounds the product first.  This file is built
 // with -ffp-contract=off (build_native.py) and says so here as well.
@@ -135,6 +137,19 @@ __global__ __launch_bounds__(kThreads) void assemble_columns_kernel(SegmentTable
               static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x, static_cast<int64_t>(gridDim.x) * kThreads);
 }
 
+// Many clients, each with its OWN tensors (the reference's per-client loop, server.py:81-83, in one launch): the table lives
+// in device memory -- starts[0 .. n_segments], then n_clients x n_segments pointers, client-major.  blockIdx.y = client,
+// blockIdx.z = segment.
+__global__ __launch_bounds__(kThreads) void assemble_rows_kernel(const int64_t* __restrict__ starts,
+                                                                 const float* const* __restrict__ src, int n_segments,
+                                                                 float* __restrict__ G, int64_t ld) {
+    const int seg = blockIdx.z;
+    const int64_t r = blockIdx.y;
+    const int64_t begin = starts[seg], len = starts[seg + 1] - begin;
+    copy_span(src[r * n_segments + seg], G + r * ld + begin, len, static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x,
+              static_cast<int64_t>(gridDim.x) * kThreads);
+}
+
 bool aligned16(const void* p) { return reinterpret_cast<uintptr_t>(p) % 16 == 0; }
 
 }  // namespace
@@ -199,6 +214,39 @@ static int assemble(byz_ctx* ctx, float* dst, int64_t rows, int64_t ld, int64_t 
         BYZ_TRY(check_launch("assemble kernel"));
     }
     return BYZ_OK;
+}
+
+int launch_assemble_rows(byz_ctx* ctx, float* G, int64_t n_cols, int64_t ld, int64_t n_clients, int64_t n_segments,
+                         const float* const* segments, const int64_t* lengths, hipStream_t stream) {
+    BYZ_REQUIRE(n_clients <= 65535 && n_segments <= 65535, "assemble_rows: at most 65535 clients and tensors per call");
+    std::vector<int64_t> table(static_cast<size_t>(n_segments + 1 + n_clients * n_segments));
+    int64_t total = 0, longest = 1;
+    for (int64_t s = 0; s < n_segments; ++s) {
+        BYZ_REQUIRE(lengths[s] >= 0, "assemble_rows: bad length of tensor %lld", (long long)s);
+        table[static_cast<size_t>(s)] = total;
+        total += lengths[s];
+        if (lengths[s] > longest) longest = lengths[s];
+    }
+    table[static_cast<size_t>(n_segments)] = total;
+    BYZ_REQUIRE(total == n_cols, "assemble_rows: a client's tensors hold %lld values, a row %lld", (long long)total,
+                (long long)n_cols);
+    for (int64_t k = 0; k < n_clients * n_segments; ++k) {
+        BYZ_REQUIRE(segments[k] != nullptr || lengths[k % n_segments] == 0, "assemble_rows: null tensor (client %lld, tensor %lld)",
+                    (long long)(k / n_segments), (long long)(k % n_segments));
+        table[static_cast<size_t>(n_segments + 1 + k)] = static_cast<int64_t>(reinterpret_cast<uintptr_t>(segments[k]));
+    }
+    BYZ_TRY(ctx->assemble_table.ensure(table.size() * sizeof(int64_t)));
+    // (pageable source: the runtime stages it before the call returns, `table` may go out of scope)
+    BYZ_HIP(hipMemcpyAsync(ctx->assemble_table.ptr, table.data(), table.size() * sizeof(int64_t), hipMemcpyHostToDevice, stream));
+    KernelTimer t(ctx, BYZ_K_MISC, stream);
+    int64_t blocks = ceil_div(longest, static_cast<int64_t>(kThreads) * 4);
+    const int64_t cap = 64;     // n_clients x n_segments workgroup columns already fill the chip; the kernel strides
+    if (blocks > cap) blocks = cap;
+    const int64_t* starts = ctx->assemble_table.as<int64_t>();
+    assemble_rows_kernel<<<dim3(static_cast<unsigned>(blocks), static_cast<unsigned>(n_clients), static_cast<unsigned>(n_segments)),
+                           kThreads, 0, stream>>>(starts, reinterpret_cast<const float* const*>(starts + n_segments + 1),
+                                                  static_cast<int>(n_segments), G, ld);
+    return check_launch("assemble_rows_kernel");
 }
 
 int launch_assemble_row(byz_ctx* ctx, float* row, int64_t n_cols, int64_t n_segments, const float* const* segments,

@@ -242,6 +242,24 @@ class Engine:
         _check(self.lib.byz_gram_dev(self.ctx, _vp(m.ptr), m.rows, m.cols, m.ld, _vp(ptr), _vp(m.stream)))
         return out
 
+    def gram_share_add(self, panel, row_index, share_count, share_index, gram):
+        """`gram` (the caller's N x N fp64 device buffer, zeroed before the first panel) += this rank's share of the Gram
+        tiles of `panel`: the per-panel N x N addition pass of the clients layout folded into the reduction kernel."""
+        m = self._device_matrix(panel)
+        if m is None:
+            raise ValueError('gram_share_add() takes a device-resident matrix')
+        n_rows, idx_ptr, keep = m.rows, None, None
+        if row_index is not None:
+            idx_ptr, n_rows, keep = self._row_index(row_index, m, validate=False)
+        ptr = gram.data_ptr() if _is_torch(gram) else gram.ptr
+        if tuple(gram.shape) != (n_rows, n_rows):
+            raise ValueError('the accumulator must be %d x %d' % (n_rows, n_rows))
+        _check(self.lib.byz_gram_share_add_dev(self.ctx, _vp(m.ptr), int(n_rows), m.cols, m.ld, _vp(idx_ptr),
+                                               int(share_count), int(share_index), _vp(ptr), _vp(m.stream)))
+        if keep is not None and not _is_torch(keep):
+            self.synchronize(m.stream)
+        return gram
+
     def gram_share(self, panel, row_index, share_count, share_index):
         """This rank's share of the Gram tiles of `panel` (a device matrix every rank holds, e.g. an all-gathered column
         panel): zeros outside the share, so the ranks' outputs SUM to the Gram.  `row_index` (int32, on the device, or
@@ -633,6 +651,46 @@ class Engine:
         _check(self.lib.byz_assemble_row_host(self.ctx, _vp(m.ptr), m.rows, m.cols, m.ld, int(row),
                                               host.ctypes.data_as(ctypes.c_void_p), _vp(m.stream)))
         self.synchronize(m.stream)   # `host` may be a temporary
+
+    def assemble_rows(self, g, first_row, clients_grads):
+        """Rows first_row .. of the device-resident matrix := the clients' gradients, ONE launch for all of them
+        (server.py:81-83's loop).  `clients_grads[c]` is client c's sequence of device tensors, one per model parameter in
+        parameter order; every client has the same parameter sizes (one model)."""
+        m = self._device_matrix(g)
+        if m is None:
+            raise ValueError('assemble_rows() fills a device-resident matrix')
+        n_clients = len(clients_grads)
+        if n_clients == 0:
+            return
+        n_seg = len(clients_grads[0])
+        ptrs, keep, lens = [], [], None
+        for tensors in clients_grads:
+            if len(tensors) != n_seg:
+                raise ValueError('every client must hand over the same number of tensors')
+            mine = []
+            for t in tensors:
+                if isinstance(t, DeviceBuffer):
+                    assert t.dtype == np.float32
+                    ptrs.append(t.ptr)
+                    mine.append(int(np.prod(t.shape)))
+                elif _is_torch(t) and t.is_cuda:
+                    import torch
+                    if t.dtype != torch.float32:
+                        raise ValueError('gradient tensors must be float32')
+                    t = t if t.is_contiguous() else t.contiguous()
+                    ptrs.append(t.data_ptr())
+                    mine.append(t.numel())
+                else:
+                    raise ValueError('assemble_rows() takes device tensors; host vectors go through assemble_row()')
+                keep.append(t)
+            if lens is None:
+                lens = mine
+            elif mine != lens:
+                raise ValueError('clients disagree on the parameter sizes: %r and %r' % (lens, mine))
+        table = (ctypes.c_void_p * len(ptrs))(*ptrs)
+        lengths = (ctypes.c_int64 * n_seg)(*lens)
+        _check(self.lib.byz_assemble_rows_dev(self.ctx, _vp(m.ptr), m.rows, m.cols, m.ld, int(first_row), n_clients, n_seg,
+                                              table, lengths, _vp(m.stream)))
 
     def assemble_columns(self, g, batched_grads):
         """Every client at once: `batched_grads[s]` is the device tensor (n_clients, *shape_s) holding parameter

@@ -426,7 +426,10 @@ class Assembly(Workload):
         self.eng, self.n = eng, n
         self.d = sum(int(np.prod(sh)) for sh in shapes)
         gen = torch.Generator(device=device).manual_seed(seed)
-        self.grads = [torch.randn(sh, device=device, generator=gen) for sh in shapes]   # one client's .grad tensors
+        # every client's own .grad tensors, as N models that stepped on the GPU leave them
+        self.users = [type('Client', (), {'grads': [torch.randn(sh, device=device, generator=gen) for sh in shapes]})()
+                      for _ in range(n if not batched else 0)]
+        self.n_tensors = len(shapes)
         self.matrix = GradientMatrix(n, self.d, engine=eng, torch_device=device)
         self.batched = None
         if batched:   # what a batched client step hands over: (n, *shape) per parameter
@@ -436,11 +439,10 @@ class Assembly(Workload):
         if self.batched is not None:
             self.matrix.set_all(self.batched)
             return
-        for idx in range(self.n):
-            self.matrix.set_row(idx, self.grads)
+        self.matrix.collect_gradients(self.users)      # server.py:81-83; one launch for all device-resident clients
 
     def dominant(self):   # per launch: the rows it fills are read once and written once
-        rows = self.n if self.batched is not None else 1
+        rows = self.n
         return {'kernel': 'misc', 'bound': 'hbm', 'work': 8.0 * self.d * rows, 'peak': PEAK_HBM, 'unit': 'GB/s', 'scale': 1e9}
 
     def at_profiled_size(self):
@@ -448,7 +450,8 @@ class Assembly(Workload):
 
     def config(self):
         return {'workload': 'gradient assembly (%s): %d clients x %d tensors -> device matrix, D=%d' % (
-                    'one launch, batched gradients' if self.batched is not None else 'one launch per client', self.n, len(self.grads), self.d),
+                    'one launch, batched gradients' if self.batched is not None else
+                    "collect_gradients over every client's own tensors: one launch, pointer table on the device", self.n, self.n_tensors, self.d),
                 'clients': self.n, 'params': self.d}
 
 
@@ -493,9 +496,12 @@ class ClientStep(Workload):
 
 
 # ---- timing ---------------------------------------------------------------------------------------
-def timed_steps(torch, dist, wl, eng, steps, warmup, world, events=True):
+def timed_steps(torch, dist, wl, eng, steps, warmup, world, events=True, agg=None):
     for _ in range(warmup):
         wl.step()
+    if agg is not None:
+        torch.cuda.synchronize()
+        agg.comm_report()     # the collectives' books cover the timed steps only
     eng.timing(events)    # HIP events around every kernel launch, on the launch stream
     if world > 1:
         dist.barrier()
@@ -737,8 +743,7 @@ def collectives_table(agg, steps):
 
 def bulyan_record(torch, dist, wl, eng, agg, steps, warmup, world, traffic):
     """One timed leg of a BulyanSharded workload as a self-contained record (value, roofline, kernels, collectives)."""
-    agg.comm_report()     # drop whatever the set-up booked
-    elapsed, per_kernel = timed_steps(torch, dist, wl, eng, steps, warmup, world)
+    elapsed, per_kernel = timed_steps(torch, dist, wl, eng, steps, warmup, world, agg=agg)
     rec = {'config': wl.config(), 'value': steps / elapsed, 'unit': 'rounds/s', 'ms_per_step': elapsed / steps * 1e3,
            'steps': steps, 'warmup': warmup, 'roofline': roofline_of(wl, per_kernel, traffic, steps),
            'kernels': kernel_table(per_kernel, steps), 'collectives': collectives_table(agg, steps),
@@ -803,8 +808,7 @@ def main(argv=None):
     else:
         wl = AttackOnly(torch, eng, args.clients or 2400, args.params or 4_000_000, device, 1238)
 
-    agg.comm_report()     # drop whatever the set-up booked
-    elapsed, per_kernel = timed_steps(torch, dist, wl, eng, args.steps, args.warmup, world)
+    elapsed, per_kernel = timed_steps(torch, dist, wl, eng, args.steps, args.warmup, world, agg=agg)
     ms_per_step = elapsed / args.steps * 1e3
     line = {
         'metric': 'aggregation rounds/sec at N clients x D params (%s)' % wl.defence,
@@ -912,6 +916,11 @@ def sharded_path_at_one_rank(torch, dist, wl, eng, device, traffic, steps=2, war
     os.environ['RANK'], os.environ['WORLD_SIZE'] = '0', '1'
     out = {'note': 'BYZ_FORCE_COLLECTIVES=1 at world size 1: the W > 1 code path of sharded.py with every collective issued '
                    'through RCCL (send-to-self); %d timed steps per layout' % steps}
+    # RCCL prints its NCCL_DEBUG=VERSION banner through C stdio on fd 1; the contract's stdout is ONE JSON line, so fd 1 points
+    # at stderr while the process group of this leg lives
+    sys.stdout.flush()
+    saved_stdout = os.dup(1)
+    os.dup2(2, 1)
     dist.init_process_group('nccl', device_id=device)
     try:
         forced = ShardedAggregator(HipKernels(eng))
@@ -930,6 +939,13 @@ def sharded_path_at_one_rank(torch, dist, wl, eng, device, traffic, steps=2, war
             torch.cuda.empty_cache()
     finally:
         dist.destroy_process_group()
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except OSError:
+            pass
+        os.dup2(saved_stdout, 1)
+        os.close(saved_stdout)
         for key in ('BYZ_FORCE_COLLECTIVES', 'RANK', 'WORLD_SIZE', 'MASTER_PORT'):
             os.environ.pop(key, None)
     return out

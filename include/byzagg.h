@@ -93,6 +93,12 @@ int byz_gram_dev(byz_ctx* ctx, const float* G_dev, int64_t n_rows, int64_t n_col
 int byz_gram_share_dev(byz_ctx* ctx, const float* G_dev, int64_t n_rows, int64_t n_cols, int64_t ld,
                        const int32_t* row_index_dev, int share_count, int share_index, double* gram_dev,
                        void* stream);
+/* The same share ADDED into gram_dev (which the caller zeroed before the first panel): the sum over column  */
+/* panels accumulates in the caller's one N x N buffer, in panel order, instead of through a separate N x N    */
+/* addition pass per panel; entries of other ranks' tiles are left untouched.                                 */
+int byz_gram_share_add_dev(byz_ctx* ctx, const float* G_dev, int64_t n_rows, int64_t n_cols, int64_t ld,
+                           const int32_t* row_index_dev, int share_count, int share_index, double* gram_dev,
+                           void* stream);
 int byz_distances_from_gram_dev(byz_ctx* ctx, const double* gram_dev, int64_t n_rows,
                                 float* dist_dev, void* stream);
 /* Near-duplicate pairs.  c_ii + c_jj - 2 c_ij cannot resolve rows that nearly coincide, the reference's  */
@@ -192,6 +198,14 @@ int byz_backdoor_clip_dev(byz_ctx* ctx, const float* grads_mean_dev, const float
 int byz_assemble_row_dev(byz_ctx* ctx, float* G_dev, int64_t n_rows, int64_t n_cols, int64_t ld,
                          int64_t row, int64_t n_segments, const float* const* segments_dev,
                          const int64_t* lengths, void* stream);
+/* Many clients in ONE launch, each with its own tensors (server.py:81-83's loop over users):  */
+/* rows first_row .. first_row + n_clients - 1; segments_dev is a HOST array of n_clients x      */
+/* n_segments device pointers, client-major (client c's tensor s at [c * n_segments + s]);       */
+/* lengths (HOST, n_segments, summing to n_cols) is shared by all clients -- one model.  The     */
+/* pointer table is copied to a context-owned device buffer on `stream`.                         */
+int byz_assemble_rows_dev(byz_ctx* ctx, float* G_dev, int64_t n_rows, int64_t n_cols, int64_t ld,
+                          int64_t first_row, int64_t n_clients, int64_t n_segments,
+                          const float* const* segments_dev, const int64_t* lengths, void* stream);
 /* Every client at once (what a batched client step produces): segment s is the row-major    */
 /* (n_rows x lengths[s]) gradient of parameter s for all clients; G[:, start_s:start_s+len_s] */
 /* := that block.  One launch per 32 parameters.                                             */

@@ -121,3 +121,49 @@ def test_gram_with_128x64_wave_tiles_is_bitwise_the_production_gram(eng, monkeyp
     eng.check()
     assert torch.equal(base, wide), float((base - wide).abs().max())
     assert torch.equal(base, wide_many)
+
+
+def test_collect_gradients_writes_all_device_clients_in_one_launch(eng, golden):
+    """server.py:81-83 over clients whose gradients are per-parameter device tensors: `byz_assemble_rows_dev` places all of
+    them with ONE launch (pointer table on the device).  Bit-exact against the reference's golden assembly and against the
+    oracle's row assembly on awkward sizes and alignments; host-vector clients in between still take the row copy."""
+    torch = pytest.importorskip('torch')
+    from attacking_federate_learning_amd.assembly import GradientMatrix
+
+    class Client:
+        def __init__(self, grads):
+            self.grads = grads
+
+    c = golden['assemble_4x204']
+    gm = GradientMatrix(4, 204, engine=eng)
+    gm.collect_gradients([Client([eng.to_device(c['u%d_t%d' % (u, t)]) for t in range(5)]) for u in range(4)])
+    eng.synchronize()
+    assert np.array_equal(gm.numpy(), c['G'])
+
+    rng = np.random.default_rng(13)
+    sizes = [1, 3, 784 * 100, 100, 7, 100 * 10, 10, 5, 4096, 33] * 4          # 40 tensors per client
+    d = sum(sizes)
+    n = 9
+    gm = GradientMatrix(n, d, engine=eng, torch_device='cuda')
+    want = np.empty((n, d), dtype=np.float32)
+    users = []
+    for u in range(n):
+        pool = torch.from_numpy(rng.standard_normal(d + 64).astype(np.float32)).cuda()
+        tensors, off = [], u % 5          # misaligned views of one pool: every alignment case of the copy
+        for k in sizes:
+            tensors.append(pool[off:off + k])
+            off += k
+        faithful.assemble_row(want, u, [t.cpu().numpy() for t in tensors])
+        # clients 3 and 4 still hand over the reference's flat host vector (user.py:92): the run of device clients is cut
+        users.append(Client(want[u].copy() if u in (3, 4) else tensors))
+    eng.timing(True)
+    gm.collect_gradients(users)
+    torch.cuda.synchronize()
+    launches = eng.timing_read().get('misc', {}).get('launches', 0)
+    eng.timing(False)
+    assert np.array_equal(gm.numpy(), want)
+    assert launches == 2, launches        # rows 0-2 and rows 5-8: one launch each, whatever the number of clients
+    with pytest.raises(ValueError):
+        eng.assemble_rows(gm.data, 0, [users[0].grads, users[1].grads[:-1]])
+    with pytest.raises(ValueError):
+        eng.assemble_rows(gm.data, 7, [users[0].grads] * 3)      # rows 7..9 of a 9-row matrix

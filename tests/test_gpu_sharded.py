@@ -116,6 +116,14 @@ def test_gram_shares_sum_to_the_gram(eng, torch, monkeypatch, n, d, mode, with_i
             total.add_(part)
         assert torch.equal(total, full), 'W=%d: max |sum of shares - gram| = %.3e' % (
             world, float((total - full).abs().max()))
+        # the accumulating form (byz_gram_share_add_dev, round 4): the shares added in place into one buffer that already
+        # holds something -- other ranks' tiles untouched, own tiles = old + share, bitwise what the add_ pass gave
+        base = torch.arange(n * n, dtype=torch.float64, device=device).reshape(n, n) * 0.5
+        acc = base.clone()
+        for share in range(world):
+            eng.gram_share_add(panel, row_index, world, share, acc)
+        eng.check()
+        assert torch.equal(acc, base + full), 'W=%d: accumulating shares' % world
     assert bool(torch.isfinite(full).all())
 
 

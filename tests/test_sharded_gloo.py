@@ -40,6 +40,14 @@ class OracleKernels:
                 position += 1
         return torch.from_numpy(out)
 
+    def gram_accumulator(self, n, like):
+        return torch.zeros((n, n), dtype=torch.float64)
+
+    def gram_share_add(self, panel, row_index, share_count, share_index, gram):
+        """byz_gram_share_add_dev: the share is added into the caller's buffer, other ranks' tiles untouched."""
+        gram.add_(self.gram_share(panel, row_index, share_count, share_index))
+        return gram
+
     # ---- near-duplicate pairs: the same protocol as libbyzagg (gram.hip): distances_from_gram lists every pair i > j with
     # d^2 < (c_ii + c_jj) / 16 in CANONICAL order (ascending i, then j -- a function of the all-reduced Gram alone, so
     # slot p means the same pair on every rank), and POISONS their Gram-identity distances, so that a result is only right
