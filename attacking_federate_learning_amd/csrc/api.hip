@@ -405,11 +405,10 @@ int byz_krum_dev(byz_ctx* ctx, const float* G, int64_t n_rows, int64_t n_cols, i
     BYZ_TRY(ensure_distance_workspaces(ctx, n_rows));
     int32_t* winner = ctx->small.as<int32_t>();
     if (krum_small_applies(n_rows, n_cols)) {
-        // the reference's own sizes: five short launches (krum_small.hip), the row copy is part of the last one
+        // the reference's own sizes: two launches (krum_small.hip), the row copy is part of the second
         ctx->row_map_rows = 0;
         const int64_t prefix = python_prefix_len(n_rows - 1, users_count - corrupted_count);
-        BYZ_TRY(launch_small_distances(ctx, G, n_rows, n_cols, ld, ctx->dist.as<float>(), s));
-        BYZ_TRY(launch_small_select(ctx, ctx->dist.as<float>(), n_rows, prefix, G, n_cols, ld, winner, out_row, s));
+        BYZ_TRY(launch_small_krum(ctx, G, n_rows, n_cols, ld, ctx->dist.as<float>(), prefix, winner, out_row, s));
     } else {
         BYZ_TRY(launch_gram(ctx, G, n_rows, n_cols, ld, ctx->gram.as<double>(), s));
         BYZ_TRY(launch_distances_from_gram(ctx, ctx->gram.as<double>(), n_rows, ctx->dist.as<float>(), s, G, n_cols, ld));

@@ -266,6 +266,8 @@ bool krum_small_applies(int64_t n_rows, int64_t n_cols);
 int reserve_small_workspaces(byz_ctx* ctx);
 int launch_small_distances(byz_ctx* ctx, const float* G, int64_t n_rows, int64_t n_cols, int64_t ld, float* dist,
                            hipStream_t stream);
+int launch_small_krum(byz_ctx* ctx, const float* G, int64_t n_rows, int64_t n_cols, int64_t ld, float* dist, int64_t prefix_len,
+                      int32_t* winner_dev, float* out_row, hipStream_t stream);
 int launch_small_select(byz_ctx* ctx, const float* dist, int64_t n_rows, int64_t prefix_len, const float* G, int64_t n_cols,
                         int64_t ld, int32_t* winner_dev, float* out_row, hipStream_t stream);
 }  // namespace byz

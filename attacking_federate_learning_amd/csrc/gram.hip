@@ -517,10 +517,9 @@ __global__ __launch_bounds__(256) void gram_reduce_kernel(const PartialT* __rest
         part[threadIdx.x] = s;
         __syncthreads();
         if (q == 0 && live && !(accumulate && !mine)) {
-            double total = (part[jl] + part[64 + jl]) + (part[128 + jl] + part[192 + jl]);
-            if (accumulate) total += gram[i * n + j];
-            gram[i * n + j] = total;
-            gram[j * n + i] = total;
+            const double total = (part[jl] + part[64 + jl]) + (part[128 + jl] + part[192 + jl]);
+            gram[i * n + j] = accumulate ? gram[i * n + j] + total : total;
+            if (j != i) gram[j * n + i] = accumulate ? gram[j * n + i] + total : total;
         }
     }
 }

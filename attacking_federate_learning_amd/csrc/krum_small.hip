@@ -1,34 +1,32 @@
-// Krum for the reference's own sizes, N <= 128 clients (defences.py:16-42): five short launches instead of fifteen.
+// Krum for the reference's own sizes, N <= 128 clients (defences.py:16-42): TWO launches (round 2: five; the general path: ~15).
 //
 // The general path (gram.hip + select.hip) is built for N in the thousands: at N = 100, D = 79,510 (BASELINE configs[1]) it
-// spends 69 us per round in ~15 kernel launches and memsets, most of it waiting for the host to issue them (~3.5 us each),
-// and its exact fp32-input MFMA Gram alone takes 17-30 us.  A kernel boundary costs ~1.5-1.9 us on this part and an
-// in-kernel grid barrier 4-7 us (MI355X_MICROARCH.md, price list), so the phases below are separate launches wherever
-// EVERY workgroup needs EVERY other workgroup's output, and one launch wherever one workgroup can carry on alone:
+// spends 69 us per round in ~15 kernel launches and memsets.  Round 2's five launches took 30 us: K1 14.7 us, and 15 us for
+// four trivial dependent kernels (measured one by one, profiles/r04c_c2_launch_costs.txt: reduce 6.1, distances 1.5, score
+// 3.6, pick 3.7 -- a dependent launch costs ~3.6 us whatever it does, and the reduce walked its slabs in dependent round
+// trips).  Round 4: everything behind the Gram is ONE kernel, because everything a row's Krum score needs is that row.
 //
 //   K1 small_gram_kernel     all N rows x a 128-column slice per step, one row of the slice per thread: global fp32 ->
 //                            registers -> (row, slice) power-of-two scale -> two fp16 planes in LDS (row-major, 272-byte
 //                            pitch: conflict-free ds_write_b64 and ds_read_b128) -> v_mfma_f32_32x32x16_f16, three per
-//                            32 x 32 block and 16 columns (m h' + h m' + h h': gram_planes.hip's f16x2 arithmetic, 6e-8
-//                            against fp64), lower-triangle blocks only, spread over the 8 waves so that no SIMD carries
-//                            more than 3; the next two slices' loads are in flight meanwhile.  One fp32 slab (<= 10 blocks
-//                            x 4 KiB) and one compact diagonal per workgroup.
-//   K2 small_reduce_kernel   slabs -> fp64 Gram blocks, 64 entries per workgroup, fixed summation order; c_ii and c_jj by the
-//                            same sums out of the compact diagonals, so d_ij = sqrt(max(0, c_ii + c_jj - 2 c_ij)) is formed
-//                            here, on 160 CUs; two counters record pairs the identity cannot resolve and exact zeros.
-//   K3 small_distance_kernel leaves at once while both counters are zero.  Otherwise ONE workgroup redoes the distances with
-//                            identical rows folded and near-duplicate pairs listed exactly as gram.hip does (d^2 <
-//                            (c_ii + c_jj) / 16), helper workgroups of the same launch re-evaluate the listed pairs on the
-//                            difference itself (defences.py:20), and identical rows end up with bitwise identical distance
-//                            rows (the exact ties the reference resolves by visit order).
-//   K4 small_score_kernel    one wave per row: in-register bitonic sort of the row's distances (values only: equal
-//                            values add up the same in any order), then the SEQUENTIAL fp32 sum of the first n - f of
-//                            them, exactly as Python's sum() forms it (defences.py:33-34).
-//   K5 small_pick_kernel     every workgroup finds the winner itself (visit order 1, 0, 2, ..., strict '<' against 1e20,
-//                            defences.py:27-37) and copies its share of the winning row.
+//                            32 x 32 block and 16 columns -- (sum m h' + sum h m') + sum h h' on three accumulators, a
+//                            SYMMETRIC function of the two rows (gram_planes.hip's f16x2 planes, 6e-8 against fp64) --
+//                            lower-triangle blocks only, spread over the 8 waves so that no SIMD carries more than 3; the
+//                            next two slices' loads are in flight meanwhile.  One full 128 x 128 fp32 slab (both
+//                            orientations of every block) and one compact diagonal per workgroup.
+//   K2 small_rows_kernel     one workgroup per row i: the row of the Gram and the diagonal summed over the slabs in fp64
+//                            (fixed order, every load in flight at once), d_ij = sqrt(max(0, c_ii + c_jj - 2 c_ij)); pairs
+//                            the identity cannot resolve (d^2 < (c_ii + c_jj) / 16) re-evaluated on the difference itself
+//                            (defences.py:20), identical rows folded to one proof each; in-register bitonic sort of the
+//                            row's distances by one wave and the SEQUENTIAL fp32 sum of the first n - f, exactly as
+//                            Python's sum() forms it (defences.py:33-34); a ticket, the last workgroup finds the winner
+//                            (visit order 1, 0, 2, ..., strict '<' against 1e20, defences.py:27-37), everybody copies its
+//                            share of the winning row.
+//   K4 small_score_kernel, K5 small_pick_kernel: the selection on a distance matrix the CALLER supplies
+//                            (`krum(..., distances=...)`, byz_krum_select_dev): score per row, argmin + row copy.
 //
 // Algorithmic traffic: 4 N D bytes read once (K1); everything else is O(N^2).  Bound: HBM (N / 4 flop per byte is below
-// the machine balance of the 16-bit matrix pipe for every N <= 128).
+// the machine balance of the 16-bit matrix pipe for every N <= 128); in fact cache latency and the one kernel boundary.
 #include "common.hpp"
 #include "lane_exchange.hpp"
 
@@ -47,6 +45,7 @@ constexpr int kPlaneBytes = kMaxRows * kPitch;      // 34,816
 constexpr int kGramLds = 2 * kPlaneBytes + kMaxRows * 4;   // two planes + the rows' shifts
 constexpr int kBlockEntries = 32 * 32;
 constexpr int kMaxBlocks = 10;                      // lower triangle of 4 x 4 blocks
+constexpr int kSlabFloats = kMaxRows * kMaxRows;    // a workgroup's partial Gram: full 128 x 128, both triangles
 constexpr int kDistPitch = kMaxRows + 1;            // floats; odd pitch: a column walk touches every bank
 constexpr int kPairChunk = 8192;                    // columns per (pair, chunk) work item of the near-duplicate pass
 constexpr double kNearEps = 1.0 / 16.0;             // gram.hip's threshold
@@ -55,12 +54,6 @@ constexpr int kStatusPairOverflow = 2;              // bits of the context's sti
 constexpr int kStatusFalseTwin = 4;
 constexpr int kStatusSmallTimeout = 8;
 constexpr unsigned kSpinLimit = 1u << 18;   // ~0.1-0.3 s: the worker publishes within microseconds
-
-// LDS of K3 (one dynamic array, carved by hand)
-constexpr int kK3Gram = 0;                                           // fp64 Gram blocks
-constexpr int kK3Dist = kMaxBlocks * kBlockEntries * 8;              // 81,920: float [128][129]
-constexpr int kK3Misc = kK3Dist + kMaxRows * kDistPitch * 4;         // 147,968: rep[128], rep2[128], counters
-constexpr int kK3Lds = kK3Misc + 2 * kMaxRows * 4 + 64;
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -99,7 +92,7 @@ __device__ __forceinline__ f32x4 load4_guarded(const float* __restrict__ row, in
 // loop the compiler's load counting is exact and two slices really are in flight behind the one being multiplied; PER == 0
 // is the loop form for long rows (its header waits for everything outstanding).
 template <bool TINY, int PER>
-__global__ __launch_bounds__(kThreads, 2) void small_gram_kernel(const float* __restrict__ G, int n_rows, int64_t n_cols,
+__global__ __launch_bounds__(kThreads, 1) void small_gram_kernel(const float* __restrict__ G, int n_rows, int64_t n_cols,
                                                                  int64_t ld, int n_slices, float* __restrict__ slabs,
                                                                  float* __restrict__ diag_slabs, int32_t* __restrict__ flags) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
@@ -110,10 +103,7 @@ __global__ __launch_bounds__(kThreads, 2) void small_gram_kernel(const float* __
     const int half = lane >> 5, q4 = lane & 31;
     const int n_rb = (n_rows + 31) >> 5;                 // live 32-row blocks
     const int n_blocks = n_rb * (n_rb + 1) / 2;
-    if (blockIdx.x == 0 && tid == 0) {   // what K2 of this call will report to K3 (K3 of the previous call has read its own)
-        flags[0] = 0;
-        flags[1] = 0;
-    }
+    if (blockIdx.x == 0 && tid == 0) flags[4] = 0;   // K2's ticket counter (small_sync[8]); the previous call's K2 is done with it
 
     // lower-triangle blocks of this wave: waves w and w + 4 share a SIMD, no SIMD carries more than three blocks
     int bi0 = 0, bj0 = 0, bi1 = 0, bj1 = 0, nb = 0;
@@ -157,12 +147,20 @@ __global__ __launch_bounds__(kThreads, 2) void small_gram_kernel(const float* __
         }
     };
 
-    f32x16 acc[2], sum[2];
+    // Three MFMA chains per block -- x = sum m_a h_b, y = sum h_a m_b, z = sum h_a h_b -- combined as (x + y) + z.  Swapping the
+    // two operands swaps x and y and leaves every product and every chain as it is, and fp32 addition commutes: the Gram
+    // entry is a SYMMETRIC function of the two rows' planes, c(a, b) == c(b, a) bit for bit.  (One chain m h' + h m' + h h'
+    // added the cross terms in an order that depended on which operand a row was.)  Identical rows therefore get bitwise
+    // identical Gram ROWS -- not just c_ii == c_ij == c_jj -- and identical distance rows fall out of the arithmetic; the
+    // canonicalisation pass the first small path needed (a workgroup that rewrote the whole matrix) is gone.
+    f32x16 accx[2], accy[2], accz[2], sum[2];
 #pragma unroll
     for (int b = 0; b < 2; ++b)
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
-            acc[b][e] = 0.0f;
+            accx[b][e] = 0.0f;
+            accy[b][e] = 0.0f;
+            accz[b][e] = 0.0f;
             sum[b][e] = 0.0f;
         }
 
@@ -186,12 +184,12 @@ __global__ __launch_bounds__(kThreads, 2) void small_gram_kernel(const float* __
                 dh = *reinterpret_cast<const f16x8*>(b1 + t * 32);
                 dm = *reinterpret_cast<const f16x8*>(b1 + t * 32 + kPlaneBytes);
             }
-            acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(am, bh, acc[0], 0, 0, 0);
-            if constexpr (NB == 2) acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(cm, dh, acc[1], 0, 0, 0);
-            acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bm, acc[0], 0, 0, 0);
-            if constexpr (NB == 2) acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ch, dm, acc[1], 0, 0, 0);
-            acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc[0], 0, 0, 0);
-            if constexpr (NB == 2) acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ch, dh, acc[1], 0, 0, 0);
+            accx[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(am, bh, accx[0], 0, 0, 0);
+            if constexpr (NB == 2) accx[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(cm, dh, accx[1], 0, 0, 0);
+            accy[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bm, accy[0], 0, 0, 0);
+            if constexpr (NB == 2) accy[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ch, dm, accy[1], 0, 0, 0);
+            accz[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, accz[0], 0, 0, 0);
+            if constexpr (NB == 2) accz[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ch, dh, accz[1], 0, 0, 0);
         }
         // undo the rows' scales (powers of two: exact) and add the slice to the running sums
 #pragma unroll
@@ -201,8 +199,10 @@ __global__ __launch_bounds__(kThreads, 2) void small_gram_kernel(const float* __
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int si = shifts[32 * bi + (e & 3) + 8 * (e >> 2) + 4 * half];
-                sum[b][e] += __builtin_ldexpf(acc[b][e], -(si + sj));
-                acc[b][e] = 0.0f;
+                sum[b][e] += __builtin_ldexpf((accx[b][e] + accy[b][e]) + accz[b][e], -(si + sj));
+                accx[b][e] = 0.0f;
+                accy[b][e] = 0.0f;
+                accz[b][e] = 0.0f;
             }
         }
     };
@@ -293,161 +293,276 @@ __global__ __launch_bounds__(kThreads, 2) void small_gram_kernel(const float* __
         }
     }
 
-    float* out = slabs + static_cast<int64_t>(blockIdx.x) * n_blocks * kBlockEntries;
+    // The workgroup's slab: a full 128 x 128 row-major matrix (pitch kMaxRows), BOTH orientations of every off-diagonal
+    // block, so that whoever owns row i in K2 finds c_i0 .. c_i,127 as 512 contiguous bytes per slab.  The mirror image of
+    // an off-diagonal block goes out as 16-byte stores (four consecutive rows of the block = four consecutive columns of
+    // its transpose sit in consecutive accumulator registers).
+    (void)n_blocks;
+    float* out = slabs + static_cast<int64_t>(blockIdx.x) * kSlabFloats;
 #pragma unroll
     for (int b = 0; b < 2; ++b) {
         if (b < nb) {
             const int bi = b == 0 ? bi0 : bi1, bj = b == 0 ? bj0 : bj1;
-            float* blk = out + block_index(bi, bj) * kBlockEntries;
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int il = (e & 3) + 8 * (e >> 2) + 4 * half;
-                blk[il * 32 + q4] = sum[b][e];
-                // the diagonal once more, compactly: K2 needs c_ii and c_jj next to every c_ij
+                out[(32 * bi + il) * kMaxRows + 32 * bj + q4] = sum[b][e];
+                // the diagonal once more, compactly: K2 needs c_jj of every row next to its own row of the Gram
                 if (bi == bj && il == q4) diag_slabs[static_cast<int64_t>(blockIdx.x) * kMaxRows + 32 * bi + q4] = sum[b][e];
+            }
+            if (bi != bj) {
+#pragma unroll
+                for (int e4 = 0; e4 < 4; ++e4) {
+                    f32x4 v;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = sum[b][4 * e4 + e];
+                    *reinterpret_cast<f32x4*>(out + (32 * bj + q4) * kMaxRows + 32 * bi + 8 * e4 + 4 * half) = v;
+                }
             }
         }
     }
 }
 
 // ---- K2 ---------------------------------------------------------------------------------------------------------------
-// gram[entry] = sum over the slabs, fp64, fixed order: wave q adds slabs q, q + 8, ... on four independent chains, the
-// eight waves' sums are combined as a fixed tree.  Workgroup = 64 consecutive entries of one block (256 bytes per slab).
-// c_ii and c_jj come out of the compact diagonal slabs by the very same summation (bitwise the sums of the workgroups that
-// own those entries), so that d_ij = sqrt(max(0, c_ii + c_jj - 2 c_ij)) is formed right here, on 160 CUs instead of one.
-// flags[0] counts the pairs the Gram identity cannot resolve (d^2 < (c_ii + c_jj) / 16: near-duplicate or identical rows),
-// flags[1] the exact zeros: while both stay 0 -- the normal case -- K3 has nothing to do.
-__global__ __launch_bounds__(kThreads) void small_reduce_kernel(const float* __restrict__ slabs,
-                                                                const float* __restrict__ diag_slabs, int n_slabs, int n_blocks,
-                                                                int n, double* __restrict__ gram, float* __restrict__ dist,
-                                                                int32_t* __restrict__ flags) {
-    __shared__ double part[3][8][64];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int entry = static_cast<int>(blockIdx.x) * 64 + lane;
-    const int blk = entry >> 10, local = entry & 1023;
-    const int bi = blk >= 6 ? 3 : (blk >= 3 ? 2 : (blk >= 1 ? 1 : 0));
-    const int bj = blk - bi * (bi + 1) / 2;
-    const int il = local >> 5, jl = local & 31;
-    const int i = 32 * bi + il, j = 32 * bj + jl;
-    const int64_t slab = static_cast<int64_t>(n_blocks) * kBlockEntries;
-    double s[4] = {0.0, 0.0, 0.0, 0.0}, a[4] = {0.0, 0.0, 0.0, 0.0}, b[4] = {0.0, 0.0, 0.0, 0.0};
-    int sl = wave;
-    for (; sl + 24 < n_slabs; sl += 32) {
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            s[c] += static_cast<double>(slabs[(sl + 8 * c) * slab + entry]);
-            a[c] += static_cast<double>(diag_slabs[(sl + 8 * c) * kMaxRows + i]);
-            b[c] += static_cast<double>(diag_slabs[(sl + 8 * c) * kMaxRows + j]);
-        }
-    }
-    for (; sl < n_slabs; sl += 8) {
-        s[0] += static_cast<double>(slabs[sl * slab + entry]);
-        a[0] += static_cast<double>(diag_slabs[sl * kMaxRows + i]);
-        b[0] += static_cast<double>(diag_slabs[sl * kMaxRows + j]);
-    }
-    part[0][wave][lane] = (s[0] + s[1]) + (s[2] + s[3]);
-    part[1][wave][lane] = (a[0] + a[1]) + (a[2] + a[3]);
-    part[2][wave][lane] = (b[0] + b[1]) + (b[2] + b[3]);
-    __syncthreads();
-    if (wave != 0) return;
-    double tot[3];
-#pragma unroll
-    for (int v = 0; v < 3; ++v)
-        tot[v] = ((part[v][0][lane] + part[v][1][lane]) + (part[v][2][lane] + part[v][3][lane])) +
-                 ((part[v][4][lane] + part[v][5][lane]) + (part[v][6][lane] + part[v][7][lane]));
-    const double cij = tot[0], cii = tot[1], cjj = tot[2];
-    gram[entry] = cij;
-    if (i >= n || j >= n || j > i) return;   // padding rows; the upper half of a diagonal block (its mirror image is written)
-    if (i == j) {
-        dist[static_cast<int64_t>(i) * n + i] = __builtin_inff();   // the reference keeps no self-distance (defences.py:18-20)
-        return;
-    }
-    const double d2 = cii + cjj - 2.0 * cij;
-    const float d = static_cast<float>(sqrt(d2 < 0.0 ? 0.0 : d2));   // NaN (poisoned input) stays NaN
-    dist[static_cast<int64_t>(i) * n + j] = d;
-    dist[static_cast<int64_t>(j) * n + i] = d;
-    if (d2 < kNearEps * (cii + cjj)) atomicAdd(flags + 0, 1);
-    if (d == 0.0f) atomicAdd(flags + 1, 1);
-}
-
-// ---- K3 ---------------------------------------------------------------------------------------------------------------
-struct DistanceArgs {
-    const double* gram;        // K2's blocks
+// One workgroup per ROW of the distance matrix (round 4; it replaces the reduce kernel, the distance kernel with its worker /
+// helper hand-off, the score kernel and the pick kernel of round 2: five launches -> two).  Everything a row's Krum score
+// needs is the row itself, so nothing here waits for another workgroup until the very end:
+//
+//   1. c_i0 .. c_i,127 and the diagonal c_00 .. c_127,127 = sums over the K1 workgroups' slabs, fp64, in ONE fixed order for
+//      every entry (16 groups of threads take the slabs g, g + 16, ...; a fixed tree joins the groups).  Every load of the
+//      workgroup is in flight at once -- 16-byte loads, all issued before the first add; the reduce kernel of round 2 walked
+//      the slabs in dependent round trips and took 6 us of a 30 us round (profiles/r04c_c2_launch_costs.txt).
+//      c_ij here and c_ji in row j's workgroup are sums of the same numbers in the same order (K1 stores both orientations,
+//      and its arithmetic is symmetric): the matrix comes out symmetric bit for bit, and identical rows get identical rows.
+//   2. d_ij = sqrt(max(0, c_ii + c_jj - 2 c_ij)); a pair the Gram identity cannot resolve (d^2 < (c_ii + c_jj) / 16, or an
+//      exact zero) is re-evaluated on the difference itself (defences.py:20) by THIS workgroup -- and by row j's, which runs
+//      the same code on the same bytes and gets the same bits.  Identical rows (bitwise equal c_ii, c_ij, c_jj: the attack's
+//      clients, malicious.py:26-27) are folded first: only the proof pair (i, first twin) is evaluated, and it must come out
+//      as zero (a refuted nomination sets the status word, as in gram.hip).
+//   3. the row's n - 1 distances sorted in registers by one wave, the sequential fp32 sum of the first n - f (defences.py:33-34).
+//   4. a ticket; the LAST workgroup to arrive runs the argmin over the scores (visit order 1, 0, 2, ...; strict '<' against
+//      1e20) and publishes the winner; the others wait for it (all n <= 128 workgroups are resident: bounded spin, time-out
+//      -> status word) and everybody copies its share of the winning row.
+struct RowsArgs {
+    const float* slabs;        // [n_slabs][128][128] fp32
+    const float* diag_slabs;   // [n_slabs][128]
+    int n_slabs;
+    int n;                     // rows
     const float* G;
-    int n_rows;
     int64_t n_cols, ld;
     float* dist;               // n x n, pitch n
-    int32_t* rep;              // n: scratch in global memory (debugging aid only)
-    int2* pairs;               // near-duplicate pairs
-    int pair_capacity;
-    double* pair_partial;      // (pair, chunk) sums of squared differences
-    int64_t item_capacity;
-    int32_t* sync;             // [0] flag (epoch) [1] published pair count [2] arrivals [4], [5] K2's findings
+    int prefix_len;            // < 0: distances only
+    float* scores;             // n
+    int32_t* winner;           // device word the index goes to
+    float* out_row;            // optional: copy of the winning row
+    int32_t* sync;             // [8] arrivals, [9] winner flag (epoch), [10] winner
     int32_t epoch;
     int32_t* status;
 };
 
-// c_ij of the lower triangle (i >= j) out of the fp64 blocks in LDS
-__device__ __forceinline__ double gram_at(const double* gl, int i, int j) {
-    const int hi = i > j ? i : j, lo = i > j ? j : i;
-    return gl[block_index(hi >> 5, lo >> 5) * kBlockEntries + (hi & 31) * 32 + (lo & 31)];
-}
-
 __device__ __forceinline__ unsigned long long bits_of(double v) { return static_cast<unsigned long long>(__double_as_longlong(v)); }
 
-// sum over one column chunk of (g_a - g_b)^2: the difference in fp32 as the reference forms it (defences.py:20), squares
-// and sums in fp64; a fixed partition over the 512 threads and a fixed tree, so the result does not depend on who runs it
-__device__ double pair_chunk_sum(const DistanceArgs& p, int pair, int chunk, double* red) {
-    const int2 pr = p.pairs[pair];
-    const float* a = p.G + static_cast<int64_t>(pr.x) * p.ld;
-    const float* b = p.G + static_cast<int64_t>(pr.y) * p.ld;
-    const int64_t k0 = static_cast<int64_t>(chunk) * kPairChunk;
-    const int64_t k1 = k0 + kPairChunk < p.n_cols ? k0 + kPairChunk : p.n_cols;
-    const int64_t kv = k0 + ((k1 - k0) & ~static_cast<int64_t>(3));
-    double acc = 0.0;
-    for (int64_t k = k0 + 4 * threadIdx.x; k < kv; k += 4 * kThreads) {
-        const f32x4 x = *reinterpret_cast<const f32x4u*>(a + k), y = *reinterpret_cast<const f32x4u*>(b + k);
+// sum over all columns of (a - b)^2: the difference in fp32 as the reference forms it (defences.py:20), squares and sums in
+// fp64; chunks of kPairChunk columns in order, inside a chunk a fixed partition over the 512 threads and a fixed tree -- the
+// result depends on the two rows' bytes only, not on who computes it or which of the two comes first ((a - b)^2 == (b - a)^2).
+__device__ double pair_sq_distance(const float* __restrict__ a, const float* __restrict__ b, int64_t n_cols, double* red) {
+    double total = 0.0;
+    for (int64_t k0 = 0; k0 < n_cols; k0 += kPairChunk) {
+        const int64_t k1 = k0 + kPairChunk < n_cols ? k0 + kPairChunk : n_cols;
+        const int64_t kv = k0 + ((k1 - k0) & ~static_cast<int64_t>(3));
+        double acc = 0.0;
+        for (int64_t k = k0 + 4 * threadIdx.x; k < kv; k += 4 * kThreads) {
+            const f32x4 x = *reinterpret_cast<const f32x4u*>(a + k), y = *reinterpret_cast<const f32x4u*>(b + k);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const double df = static_cast<double>(__fsub_rn(x[e], y[e]));
+            for (int e = 0; e < 4; ++e) {
+                const double df = static_cast<double>(__fsub_rn(x[e], y[e]));
+                acc = fma(df, df, acc);
+            }
+        }
+        for (int64_t k = kv + threadIdx.x; k < k1; k += kThreads) {
+            const double df = static_cast<double>(__fsub_rn(a[k], b[k]));
             acc = fma(df, df, acc);
         }
-    }
-    for (int64_t k = kv + threadIdx.x; k < k1; k += kThreads) {
-        const double df = static_cast<double>(__fsub_rn(a[k], b[k]));
-        acc = fma(df, df, acc);
-    }
-    red[threadIdx.x] = acc;
-    __syncthreads();
-    for (int st = kThreads / 2; st > 0; st >>= 1) {
-        if (threadIdx.x < st) red[threadIdx.x] += red[threadIdx.x + st];
+        red[threadIdx.x] = acc;
+        __syncthreads();
+        for (int st = kThreads / 2; st > 0; st >>= 1) {
+            if (threadIdx.x < st) red[threadIdx.x] += red[threadIdx.x + st];
+            __syncthreads();
+        }
+        total += red[0];
         __syncthreads();
     }
-    const double total = red[0];
-    __syncthreads();
     return total;
 }
 
-// A helper of the near-duplicate pass: waits for the worker's pair count, leaves when it is zero, otherwise takes
-// (pair, chunk) items and reports back through one counter.  Every wait is bounded; a time-out sets the status word.
-__device__ __forceinline__ void distance_helper(const DistanceArgs& p, unsigned char* lds) {
-    double* gl = reinterpret_cast<double*>(lds + kK3Gram);
-    float* dl = reinterpret_cast<float*>(lds + kK3Dist);
-    int* rep = reinterpret_cast<int*>(lds + kK3Misc);
-    int* rep2 = rep + kMaxRows;
-    int* words = rep2 + kMaxRows;          // [0] pair counter [1] broadcast slot
-    double* red = reinterpret_cast<double*>(lds + kK3Gram);   // helpers only (they never hold a Gram)
-    const int tid = threadIdx.x;
-    const int n = p.n_rows;
-    const int n_chunks = static_cast<int>((p.n_cols + kPairChunk - 1) / kPairChunk);
-    const int helpers = static_cast<int>(gridDim.x) - 1;
-    (void)gl; (void)dl; (void)rep; (void)rep2; (void)words; (void)red; (void)n; (void)n_chunks; (void)helpers;
-    // ---- helper: wait for the worker's pair count
+constexpr int kGroups = 16;                       // thread groups of the slab sums (32 threads x 4 columns each)
+constexpr int kMaxPerGroup = 256 / kGroups;       // K1 launches at most 256 workgroups
+
+__global__ __launch_bounds__(kThreads, 1) void small_rows_kernel(RowsArgs p) {
+    __shared__ double part[2][kGroups][kMaxRows];   // [row entries | diagonal][group][column]
+    __shared__ double red[kThreads];
+    __shared__ double c_row[kMaxRows], c_diag[kMaxRows];
+    __shared__ float d_row[kMaxRows];
+    __shared__ float sorted[kMaxRows];
+    __shared__ unsigned char what[kMaxRows];        // 0 nothing, 1 re-evaluate on the difference, 2 twin of this row
+    __shared__ int words[4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i = blockIdx.x;
+    const int n = p.n;
+
+    // ---- 1. the row of the Gram and the diagonal
+    {
+        const int jq = tid & 31, grp = tid >> 5;
+        f32x4 rv[kMaxPerGroup], dv[kMaxPerGroup];
+        const float* row_src = p.slabs + static_cast<int64_t>(i) * kMaxRows + 4 * jq;
+        const float* diag_src = p.diag_slabs + 4 * jq;
+#pragma unroll
+        for (int k = 0; k < kMaxPerGroup; ++k) {
+            const int g = grp + kGroups * k;
+            const int gg = g < p.n_slabs ? g : 0;      // a clamped, unconditional load; discarded below
+            rv[k] = *reinterpret_cast<const f32x4*>(row_src + static_cast<int64_t>(gg) * kSlabFloats);
+            dv[k] = *reinterpret_cast<const f32x4*>(diag_src + static_cast<int64_t>(gg) * kMaxRows);
+        }
+        double rs[4] = {0.0, 0.0, 0.0, 0.0}, ds[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int k = 0; k < kMaxPerGroup; ++k) {
+            if (grp + kGroups * k < p.n_slabs) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    rs[e] += static_cast<double>(rv[k][e]);
+                    ds[e] += static_cast<double>(dv[k][e]);
+                }
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            part[0][grp][4 * jq + e] = rs[e];
+            part[1][grp][4 * jq + e] = ds[e];
+        }
+    }
+    __syncthreads();
+    if (tid < 2 * kMaxRows) {
+        const int v = tid >> 7, j = tid & (kMaxRows - 1);
+        double t8[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) t8[k] = part[v][2 * k][j] + part[v][2 * k + 1][j];
+        const double tot = ((t8[0] + t8[1]) + (t8[2] + t8[3])) + ((t8[4] + t8[5]) + (t8[6] + t8[7]));
+        if (v == 0) c_row[j] = tot;
+        else c_diag[j] = tot;
+    }
+    if (tid == 0) words[0] = 0;
+    __syncthreads();
+
+    // ---- 2. distances; what the Gram identity cannot resolve
+    if (tid < kMaxRows) {
+        const int j = tid;
+        float d = __builtin_inff();      // the self slot and the padding: the reference keeps no self-distance (defences.py:18-20)
+        unsigned char w = 0;
+        if (j < n && j != i) {
+            // c_ii and c_jj are the diagonal's sums, c_ij this row's: for identical rows all three are the same bits
+            const double cii = c_diag[i], cjj = c_diag[j], cij = c_row[j];
+            const double d2 = cii + cjj - 2.0 * cij;
+            d = static_cast<float>(sqrt(d2 < 0.0 ? 0.0 : d2));   // NaN (poisoned input) stays NaN
+            if (d2 < kNearEps * (cii + cjj) || d == 0.0f) {     // (both false for NaN)
+                const bool twin = bits_of(cij) == bits_of(cii) && bits_of(cjj) == bits_of(cii);
+                w = twin ? 2 : 1;
+            }
+        }
+        d_row[j] = d;
+        what[j] = w;
+        if (w != 0) atomicOr(&words[0], w);
+    }
+    __syncthreads();
+    if (words[0] != 0) {   // uniform; never taken for clients that are neither identical nor nearly so
+        const float* mine = p.G + static_cast<int64_t>(i) * p.ld;
+        bool proven = false;
+        for (int j = 0; j < n; ++j) {
+            const int w = what[j];          // uniform
+            if (w == 0) continue;
+            if (w == 2) {
+                // identical rows: ONE proof per row -- against the first member of its class, if that is not this row
+                if (proven || j > i) continue;
+                proven = true;
+                const double sq = pair_sq_distance(mine, p.G + static_cast<int64_t>(j) * p.ld, p.n_cols, red);
+                if (sq != 0.0 && tid == 0) atomicOr(p.status, kStatusFalseTwin);
+                continue;
+            }
+            const double sq = pair_sq_distance(mine, p.G + static_cast<int64_t>(j) * p.ld, p.n_cols, red);
+            if (tid == 0) d_row[j] = static_cast<float>(sqrt(sq));
+        }
+        __syncthreads();
+    }
+    if (tid < n) p.dist[static_cast<int64_t>(i) * n + tid] = d_row[tid];
+    if (p.prefix_len < 0) return;
+
+    // ---- 3. the score: one wave sorts the row in registers (two values per lane), lane 0 adds the prefix left to right
+    if (wave == 0) {
+        float x[1][2];
+#pragma unroll
+        for (int r = 0; r < 2; ++r) x[0][r] = d_row[r + 2 * lane];     // +inf in the self slot and past n
+        lanes::wave_bitonic_sort<2, 1>(x, lane);
+        sorted[2 * lane] = x[0][0];
+        sorted[2 * lane + 1] = x[0][1];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        if (lane == 0) {
+            float sc = 0.0f;
+            for (int r = 0; r < p.prefix_len; ++r) sc = __fadd_rn(sc, sorted[r]);
+            __hip_atomic_store(p.scores + i, sc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            // ---- 4. the ticket
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            words[1] = __hip_atomic_fetch_add(p.sync + 8, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    __syncthreads();
+    const bool last = words[1] == n - 1;      // uniform
+    if (last && wave == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        float best = kKrumInit;
+        int pos = 0x7fffffff, row = -1;
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const int u = lane + 64 * r;
+            if (u < n) {
+                const float sc = __hip_atomic_load(p.scores + u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const int vp = visit_position(u);
+                if (sc < kKrumInit && (sc < best || (sc == best && vp < pos))) {   // false for NaN, as in the reference
+                    best = sc;
+                    pos = vp;
+                    row = u;
+                }
+            }
+        }
+#pragma unroll
+        for (int m = 32; m > 0; m >>= 1) {
+            const float ob = __shfl_xor(best, m, 64);
+            const int op = __shfl_xor(pos, m, 64);
+            const int orow = __shfl_xor(row, m, 64);
+            if (op != 0x7fffffff && (pos == 0x7fffffff || ob < best || (ob == best && op < pos))) {
+                best = ob;
+                pos = op;
+                row = orow;
+            }
+        }
+        if (lane == 0) {
+            // a single row has an empty distance dict in the reference: nothing is visited, the index stays -1
+            const int chosen = n < 2 ? -1 : row;
+            *p.winner = chosen;
+            __hip_atomic_store(p.sync + 10, chosen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __hip_atomic_store(p.sync + 9, p.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    if (p.out_row == nullptr) return;
+    // ---- everybody copies its share of the winning row
     if (tid == 0) {
         unsigned spins = 0;
         int seen = 0;
-        while (__hip_atomic_load(p.sync + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != p.epoch) {
-            __builtin_amdgcn_s_sleep(16);
+        while (__hip_atomic_load(p.sync + 9, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != p.epoch) {
+            __builtin_amdgcn_s_sleep(2);
             if (++spins > kSpinLimit) {
                 seen = -2;
                 break;
@@ -455,208 +570,21 @@ __device__ __forceinline__ void distance_helper(const DistanceArgs& p, unsigned 
         }
         if (seen == 0) {
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            seen = __hip_atomic_load(p.sync + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        words[1] = seen;
-    }
-    __syncthreads();
-    const int count = words[1];
-    __syncthreads();
-    if (count == -2 && tid == 0) atomicOr(p.status, kStatusSmallTimeout);
-    if (count <= 0) return;
-    const int64_t items = static_cast<int64_t>(count) * n_chunks;
-    for (int64_t w = blockIdx.x - 1; w < items; w += helpers) {
-        const double v = pair_chunk_sum(p, static_cast<int>(w / n_chunks), static_cast<int>(w % n_chunks), red);
-        if (tid == 0) p.pair_partial[w] = v;
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (tid == 0) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __hip_atomic_fetch_add(p.sync + 2, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    return;
-}
-
-// The worker (workgroup 0): representatives, distances, the pair list; after the helpers' sums the canonical distance rows.
-__device__ __forceinline__ void distance_worker(const DistanceArgs& p, unsigned char* lds) {
-    double* gl = reinterpret_cast<double*>(lds + kK3Gram);
-    float* dl = reinterpret_cast<float*>(lds + kK3Dist);
-    int* rep = reinterpret_cast<int*>(lds + kK3Misc);
-    int* rep2 = rep + kMaxRows;
-    int* words = rep2 + kMaxRows;          // [0] pair counter [1] broadcast slot
-    double* red = reinterpret_cast<double*>(lds + kK3Gram);   // helpers only (they never hold a Gram)
-    const int tid = threadIdx.x;
-    const int n = p.n_rows;
-    const int n_chunks = static_cast<int>((p.n_cols + kPairChunk - 1) / kPairChunk);
-    const int helpers = static_cast<int>(gridDim.x) - 1;
-    (void)gl; (void)dl; (void)rep; (void)rep2; (void)words; (void)red; (void)n; (void)n_chunks; (void)helpers;
-    // ---- worker
-    const int lane = tid & 63, wave = tid >> 6;
-    const int n_rb = (n + 31) >> 5;
-    const int n_entries = n_rb * (n_rb + 1) / 2 * kBlockEntries;
-    {   // the Gram blocks into LDS: every load issued before the first use (a loop of dependent round trips otherwise)
-        typedef double f64x2 __attribute__((ext_vector_type(2)));
-        constexpr int kPer = kMaxBlocks * kBlockEntries / 2 / kThreads;   // 10 16-byte loads per thread
-        const f64x2* src = reinterpret_cast<const f64x2*>(p.gram);
-        const int n_vec = n_entries / 2;
-        f64x2 tmp[kPer];
-#pragma unroll
-        for (int k = 0; k < kPer; ++k) {
-            const int e = tid + k * kThreads;
-            tmp[k] = src[e < n_vec ? e : 0];
-        }
-#pragma unroll
-        for (int k = 0; k < kPer; ++k) {
-            const int e = tid + k * kThreads;
-            if (e < n_vec) reinterpret_cast<f64x2*>(gl)[e] = tmp[k];
-        }
-    }
-    if (tid == 0) words[0] = 0;
-    __syncthreads();
-    // rep[i] = the first j < i whose Gram entries are bitwise those of i (c_ij == c_ii == c_jj): identical rows nominate
-    // each other this way in any arithmetic; the proof is the pair (i, rep[i]) on the list below.  One wave per row, the
-    // lanes look at two candidates each.
-    for (int i = wave; i < n; i += kThreads / 64) {
-        const unsigned long long cii = bits_of(gram_at(gl, i, i));
-        const int j0 = lane, j1 = lane + 64;
-        const bool h0 = j0 < i && bits_of(gram_at(gl, i, j0)) == cii && bits_of(gram_at(gl, j0, j0)) == cii;
-        const bool h1 = j1 < i && bits_of(gram_at(gl, i, j1 < n ? j1 : 0)) == cii && bits_of(gram_at(gl, j1 < n ? j1 : 0, j1 < n ? j1 : 0)) == cii;
-        const unsigned long long m0 = __ballot(h0), m1 = __ballot(h1);
-        const int best = m0 ? __builtin_ctzll(m0) : (m1 ? 64 + __builtin_ctzll(m1) : i);
-        if (lane == 0) {
-            rep[i] = best;
-            p.rep[i] = best;
-        }
-    }
-    __syncthreads();
-    for (int idx = tid; idx < n * n; idx += kThreads) {
-        const int i = idx / n, j = idx - i * n;
-        float d;
-        if (i == j) {
-            d = __builtin_inff();   // the reference keeps no self-distance (defences.py:18-20)
+            seen = __hip_atomic_load(p.sync + 10, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (seen < 0) seen += n;      // numpy's G[-1]: the reference returns the last row when nothing won
+            words[2] = seen;
         } else {
-            const double cii = gram_at(gl, i, i), cjj = gram_at(gl, j, j);
-            const double d2 = cii + cjj - 2.0 * gram_at(gl, i, j);
-            d = static_cast<float>(sqrt(d2 < 0.0 ? 0.0 : d2));   // NaN (poisoned input) stays NaN
-            if (i > j && d2 < kNearEps * (cii + cjj)) {
-                const int ri = rep[i], rj = rep[j];
-                // representatives pair with each other; a folded row only with its representative (the proof of identity)
-                if ((ri == i && rj == j) || ri == j) {
-                    const int slot = atomicAdd(&words[0], 1);
-                    if (slot < p.pair_capacity) p.pairs[slot] = make_int2(i, j);
-                }
-            }
+            words[2] = -2;
+            atomicOr(p.status, kStatusSmallTimeout);
         }
-        dl[i * kDistPitch + j] = d;
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    int count = words[0];
-    const bool overflow = count > p.pair_capacity || static_cast<int64_t>(count) * n_chunks > p.item_capacity;
-    if (overflow) count = -1;
-    if (tid == 0) {
-        // publish the pair list and its length (zero lets the helpers go)
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __hip_atomic_store(p.sync + 1, count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __hip_atomic_store(p.sync + 0, p.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (overflow) atomicOr(p.status, kStatusPairOverflow);
-    }
-    if (overflow) return;   // the caller gets an error, not a half-patched matrix
-
-    if (count > 0) {
-        const int64_t items = static_cast<int64_t>(count) * n_chunks;
-        bool timed_out = false;
-        if (helpers > 0) {
-            int expected = helpers;   // every helper reports once
-            if (tid == 0) {
-                unsigned spins = 0;
-                while (__hip_atomic_load(p.sync + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != expected) {
-                    __builtin_amdgcn_s_sleep(4);
-                    if (++spins > kSpinLimit) {
-                        timed_out = true;
-                        break;
-                    }
-                }
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-                __hip_atomic_store(p.sync + 2, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // for the next call
-            }
-            timed_out = __syncthreads_or(timed_out ? 1 : 0) != 0;
-        } else {
-            // no helpers (a one-workgroup launch): the worker does the items itself; the Gram in LDS is no longer needed
-            for (int64_t w = 0; w < items; ++w) {
-                const double v = pair_chunk_sum(p, static_cast<int>(w / n_chunks), static_cast<int>(w % n_chunks), red);
-                if (tid == 0) p.pair_partial[w] = v;
-            }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-        }
-        if (timed_out) {
-            if (tid == 0) atomicOr(p.status, kStatusSmallTimeout);
-            return;
-        }
-        for (int q = tid; q < count; q += kThreads) {
-            double sq = 0.0;
-            for (int c = 0; c < n_chunks; ++c) sq += p.pair_partial[static_cast<int64_t>(q) * n_chunks + c];   // chunk order
-            const int2 pr = p.pairs[q];
-            // a row folded into pr.y whose difference from it is not zero after all: its other pairs were never listed
-            if (rep[pr.x] == pr.y && sq != 0.0) atomicOr(p.status, kStatusFalseTwin);
-            const float d = static_cast<float>(sqrt(sq));
-            dl[pr.x * kDistPitch + pr.y] = d;
-            dl[pr.y * kDistPitch + pr.x] = d;
-        }
-        __syncthreads();
-    }
-
-    // Identical rows must end up with bitwise identical distance rows (the reference resolves their exactly tied scores by
-    // visit order): rep2[i] = the smallest j with d_ij == 0, chains followed to their root, every member of a group takes
-    // the group's first row (gram.hip: canonicalise_duplicates).
-    bool any_twin = false;
-    for (int i = wave; i < n; i += kThreads / 64) {
-        const int j0 = lane, j1 = lane + 64;
-        const bool h0 = j0 < i && dl[i * kDistPitch + j0] == 0.0f;
-        const bool h1 = j1 < i && dl[i * kDistPitch + j1] == 0.0f;
-        const unsigned long long m0 = __ballot(h0), m1 = __ballot(h1);
-        const int best = m0 ? __builtin_ctzll(m0) : (m1 ? 64 + __builtin_ctzll(m1) : i);
-        if (lane == 0) rep2[i] = best;
-        any_twin = any_twin || best != i;
-    }
-    any_twin = __syncthreads_or(any_twin ? 1 : 0) != 0;
-    if (any_twin) {
-        for (int round = 0; round < 8; ++round) {   // rep2[i] < i along a chain: pointer jumping, log2(128) rounds at most
-            int r = 0, rr = 0;
-            if (tid < n) {
-                r = rep2[tid];
-                rr = rep2[r];
-            }
-            __syncthreads();
-            if (tid < n && rr != r) rep2[tid] = rr;
-            if (!__syncthreads_or(tid < n && rr != r ? 1 : 0)) break;
-        }
-    }
-    for (int idx = tid; idx < n * n; idx += kThreads) {
-        const int i = idx / n, j = idx - i * n;
-        float d = dl[i * kDistPitch + j];
-        if (i != j) {
-            const int ri = rep2[i], rj = rep2[j];
-            // reads touch only (root, root) entries, which nobody rewrites
-            if (!(ri == i && rj == j)) d = ri == rj ? 0.0f : dl[ri * kDistPitch + rj];
-        }
-        p.dist[idx] = d;
-    }
-}
-
-// Workgroup 0 is the worker, the others are helpers for the near-duplicate pass.
-__global__ __launch_bounds__(kThreads) void small_distance_kernel(DistanceArgs p) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-    // K2 has already written the distances; unless it met a pair the Gram identity cannot resolve (near-duplicate rows) or an
-    // exact zero (identical rows), there is nothing left to do here.  Uniform over the grid: nobody waits for anybody.
-    if (p.sync[4] == 0 && p.sync[5] == 0) return;
-    if (blockIdx.x != 0) distance_helper(p, lds);
-    else distance_worker(p, lds);
+    if (words[2] < 0) return;
+    const float* src = p.G + static_cast<int64_t>(words[2]) * p.ld;
+    const int64_t per = ((p.n_cols + gridDim.x - 1) / gridDim.x + 3) & ~static_cast<int64_t>(3);
+    const int64_t k0 = per * blockIdx.x;
+    const int64_t k1 = k0 + per < p.n_cols ? k0 + per : p.n_cols;
+    for (int64_t k = k0 + tid; k < k1; k += kThreads) p.out_row[k] = src[k];
 }
 
 // ---- K4 ---------------------------------------------------------------------------------------------------------------
@@ -767,12 +695,8 @@ bool krum_small_applies(int64_t n_rows, int64_t n_cols) {
 
 // byz_ctx_reserve's share: everything the N <= 128 path allocates, so that its first call allocates nothing
 int reserve_small_workspaces(byz_ctx* ctx) {
-    const size_t slab_floats = static_cast<size_t>(ctx->num_cus) * kMaxBlocks * kBlockEntries;
+    const size_t slab_floats = static_cast<size_t>(ctx->num_cus) * kSlabFloats;
     BYZ_TRY(ctx->gram_partials.ensure((slab_floats + static_cast<size_t>(ctx->num_cus) * kMaxRows) * sizeof(float)));
-    BYZ_TRY(ctx->gram.ensure(static_cast<size_t>(kMaxBlocks) * kBlockEntries * sizeof(double)));
-    BYZ_TRY(ctx->gram_rep.ensure(static_cast<size_t>(kMaxRows) * sizeof(int32_t)));
-    BYZ_TRY(ctx->near_pairs.ensure(static_cast<size_t>(kMaxRows * (kMaxRows - 1) / 2) * sizeof(int2)));
-    BYZ_TRY(ctx->near_partial.ensure((static_cast<size_t>(1) << 20) * sizeof(double)));
     BYZ_TRY(ctx->scores.ensure(static_cast<size_t>(kMaxRows) * sizeof(float)));
     if (ctx->small_sync.ptr == nullptr) {
         BYZ_TRY(ctx->small_sync.ensure(64));
@@ -781,9 +705,10 @@ int reserve_small_workspaces(byz_ctx* ctx) {
     return BYZ_OK;
 }
 
-// dist (n x n fp32, pitch n) of the n_rows x n_cols matrix G: K1..K3
-static int small_distances(byz_ctx* ctx, const float* G, int64_t n_rows, int64_t n_cols, int64_t ld, float* dist,
-                           hipStream_t stream) {
+// K1 + K2: dist (n x n fp32, pitch n) of the n_rows x n_cols matrix G and, with prefix_len >= 0, the Krum scores, the winner
+// (winner_dev) and the copy of the winning row (out_row, optional)
+static int small_round(byz_ctx* ctx, const float* G, int64_t n_rows, int64_t n_cols, int64_t ld, float* dist,
+                       int64_t prefix_len, int32_t* winner_dev, float* out_row, hipStream_t stream) {
     BYZ_REQUIRE(G && dist && n_rows >= 1 && n_rows <= kMaxRows && n_cols > 0 && ld >= n_cols,
                 "small distances: bad shape %lld x %lld ld %lld", (long long)n_rows, (long long)n_cols, (long long)ld);
     const int n = static_cast<int>(n_rows);
@@ -791,17 +716,12 @@ static int small_distances(byz_ctx* ctx, const float* G, int64_t n_rows, int64_t
     const int n_blocks = n_rb * (n_rb + 1) / 2;
     const int64_t n_slices = ceil_div(n_cols, kSlice);
     // one workgroup per CU at most; the grid is sized so that everybody gets the same number of slices (+- 1)
-    const int grid = static_cast<int>(ceil_div(n_slices, ceil_div(n_slices, ctx->num_cus)));
+    const int grid = static_cast<int>(ceil_div(n_slices, ceil_div(n_slices, ctx->num_cus < 256 ? ctx->num_cus : 256)));
     const int64_t per = ceil_div(n_slices, grid);   // (per - 1) * grid < n_slices: only a workgroup's last slice can be ragged or missing
-    // one slab of blocks per workgroup, then one compact diagonal per workgroup
-    const size_t slab_floats = static_cast<size_t>(grid) * n_blocks * kBlockEntries;
+    // one full 128 x 128 slab per workgroup, then one compact diagonal per workgroup
+    const size_t slab_floats = static_cast<size_t>(grid) * kSlabFloats;
     BYZ_TRY(ctx->gram_partials.ensure((slab_floats + static_cast<size_t>(grid) * kMaxRows) * sizeof(float)));
-    BYZ_TRY(ctx->gram.ensure(static_cast<size_t>(kMaxBlocks) * kBlockEntries * sizeof(double)));
-    BYZ_TRY(ctx->gram_rep.ensure(static_cast<size_t>(kMaxRows) * sizeof(int32_t)));
-    const int pair_capacity = kMaxRows * (kMaxRows - 1) / 2;
-    BYZ_TRY(ctx->near_pairs.ensure(static_cast<size_t>(pair_capacity) * sizeof(int2)));
-    const int64_t item_capacity = static_cast<int64_t>(1) << 20;
-    BYZ_TRY(ctx->near_partial.ensure(static_cast<size_t>(item_capacity) * sizeof(double)));
+    BYZ_TRY(ctx->scores.ensure(static_cast<size_t>(kMaxRows) * sizeof(float)));
     if (ctx->small_sync.ptr == nullptr) {
         BYZ_TRY(ctx->small_sync.ensure(64));
         BYZ_HIP(hipMemsetAsync(ctx->small_sync.ptr, 0, 64, stream));
@@ -824,11 +744,11 @@ static int small_distances(byz_ctx* ctx, const float* G, int64_t n_rows, int64_t
         BYZ_ATTR(false, 7);
         BYZ_ATTR(false, 8);
 #undef BYZ_ATTR
-        BYZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&small_distance_kernel),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, kK3Lds));
         ctx->small_configured = true;
     }
-    {
+    // BYZ_KRUM_SMALL_SKIP (timing experiments only, WRONG results): bit 0 no K1, bit 1 no K2 (scripts/c2_skip_probe.sh)
+    const int skip = env_int("BYZ_KRUM_SMALL_SKIP", 0);
+    if (!(skip & 1)) {
         KernelTimer t(ctx, BYZ_K_GRAM, stream);
         const int unrolled = env_int("BYZ_KRUM_SMALL_UNROLL", 1) != 0 && per <= 8 ? static_cast<int>(per) : 0;
 #define BYZ_K1(T, P)                                                                               \
@@ -849,44 +769,42 @@ static int small_distances(byz_ctx* ctx, const float* G, int64_t n_rows, int64_t
 #undef BYZ_K1
         BYZ_TRY(check_launch("small_gram_kernel"));
     }
-    {
-        KernelTimer t(ctx, BYZ_K_GRAM_REDUCE, stream);
-        small_reduce_kernel<<<static_cast<unsigned>(n_blocks * kBlockEntries / 64), kThreads, 0, stream>>>(
-            slabs, diag_slabs, grid, n_blocks, n, ctx->gram.as<double>(), dist, flags);
-        BYZ_TRY(check_launch("small_reduce_kernel"));
-    }
-    {
-        KernelTimer t(ctx, BYZ_K_DISTANCES, stream);
-        DistanceArgs p;
-        p.gram = ctx->gram.as<double>();
+    (void)n_blocks;
+    if (!(skip & 2)) {
+        KernelTimer t(ctx, prefix_len >= 0 ? BYZ_K_ROW_SORT : BYZ_K_DISTANCES, stream);
+        RowsArgs p;
+        p.slabs = slabs;
+        p.diag_slabs = diag_slabs;
+        p.n_slabs = n_cols < kSlice ? 1 : grid;
+        p.n = n;
         p.G = G;
-        p.n_rows = n;
         p.n_cols = n_cols;
         p.ld = ld;
         p.dist = dist;
-        p.rep = ctx->gram_rep.as<int32_t>();
-        p.pairs = ctx->near_pairs.as<int2>();
-        p.pair_capacity = pair_capacity;
-        p.pair_partial = ctx->near_partial.as<double>();
-        p.item_capacity = item_capacity;
+        p.prefix_len = static_cast<int>(prefix_len);
+        p.scores = ctx->scores.as<float>();
+        p.winner = winner_dev;
+        p.out_row = out_row;
         p.sync = ctx->small_sync.as<int32_t>();
         ctx->small_epoch = ctx->small_epoch == 0x7fffffff ? 1 : ctx->small_epoch + 1;
         p.epoch = ctx->small_epoch;
         p.status = device_status_word(ctx);
-        // helpers only where a near-duplicate pass could be long enough to need them; all of them must be resident with the
-        // worker (one workgroup per CU: 148 KiB of LDS)
-        int helpers = env_int("BYZ_KRUM_SMALL_HELPERS", n_cols >= 4096 ? ctx->num_cus / 2 : 0);
-        if (helpers > ctx->num_cus - 1) helpers = ctx->num_cus - 1;
-        if (helpers < 0) helpers = 0;
-        small_distance_kernel<<<static_cast<unsigned>(1 + helpers), kThreads, kK3Lds, stream>>>(p);
-        BYZ_TRY(check_launch("small_distance_kernel"));
+        small_rows_kernel<<<static_cast<unsigned>(n), kThreads, 0, stream>>>(p);
+        BYZ_TRY(check_launch("small_rows_kernel"));
     }
     return BYZ_OK;
 }
 
 int launch_small_distances(byz_ctx* ctx, const float* G, int64_t n_rows, int64_t n_cols, int64_t ld, float* dist,
                            hipStream_t stream) {
-    return small_distances(ctx, G, n_rows, n_cols, ld, dist, stream);
+    return small_round(ctx, G, n_rows, n_cols, ld, dist, -1, nullptr, nullptr, stream);
+}
+
+// The whole Krum round of defences.py:23-42 at N <= 128 in TWO launches: distances, scores, winner, the winning row's copy
+int launch_small_krum(byz_ctx* ctx, const float* G, int64_t n_rows, int64_t n_cols, int64_t ld, float* dist, int64_t prefix_len,
+                      int32_t* winner_dev, float* out_row, hipStream_t stream) {
+    BYZ_REQUIRE(winner_dev && prefix_len >= 0, "small krum: bad arguments");
+    return small_round(ctx, G, n_rows, n_cols, ld, dist, prefix_len, winner_dev, out_row, stream);
 }
 
 // scores (ctx->scores) and the winner (winner_dev) from a distance matrix of n <= 128 rows; out_row (optional): the copy of
