@@ -30,6 +30,7 @@
 #include "common.hpp"
 #include "lane_exchange.hpp"
 
+#include <cstdio>
 #include <cstdlib>
 #include <type_traits>
 
@@ -94,16 +95,17 @@ __device__ __forceinline__ f32x4 load4_guarded(const float* __restrict__ row, in
 template <bool TINY, int PER>
 __global__ __launch_bounds__(kThreads, 1) void small_gram_kernel(const float* __restrict__ G, int n_rows, int64_t n_cols,
                                                                  int64_t ld, int n_slices, float* __restrict__ slabs,
-                                                                 float* __restrict__ diag_slabs, int32_t* __restrict__ flags) {
+                                                                 float* __restrict__ diag_slabs, float* __restrict__ score_board,
+                                                                 int dbg) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-    int* shifts = reinterpret_cast<int*>(lds + 2 * kPlaneBytes);
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int half = lane >> 5, q4 = lane & 31;
     const int n_rb = (n_rows + 31) >> 5;                 // live 32-row blocks
     const int n_blocks = n_rb * (n_rb + 1) / 2;
-    if (blockIdx.x == 0 && tid == 0) flags[4] = 0;   // K2's ticket counter (small_sync[8]); the previous call's K2 is done with it
+    // K2's arrival board: the previous call's K2 is done with it, this call's K2 starts behind this kernel
+    if (blockIdx.x == 0 && tid < kMaxRows) reinterpret_cast<uint32_t*>(score_board)[tid] = 0xffc0deadu;
 
     // lower-triangle blocks of this wave: waves w and w + 4 share a SIMD, no SIMD carries more than three blocks
     int bi0 = 0, bj0 = 0, bi1 = 0, bj1 = 0, nb = 0;
@@ -164,12 +166,13 @@ __global__ __launch_bounds__(kThreads, 1) void small_gram_kernel(const float* __
             sum[b][e] = 0.0f;
         }
 
-    auto multiply = [&](auto nb_c) __attribute__((always_inline)) {
+    auto multiply = [&](auto nb_c, const unsigned char* buf) __attribute__((always_inline)) {
         constexpr int NB = decltype(nb_c)::value;
-        const unsigned char* a0 = lds + (32 * bi0 + q4) * kPitch + half * 16;
-        const unsigned char* b0 = lds + (32 * bj0 + q4) * kPitch + half * 16;
-        const unsigned char* a1 = lds + (32 * bi1 + q4) * kPitch + half * 16;
-        const unsigned char* b1 = lds + (32 * bj1 + q4) * kPitch + half * 16;
+        const int* shifts = reinterpret_cast<const int*>(buf + 2 * kPlaneBytes);
+        const unsigned char* a0 = buf + (32 * bi0 + q4) * kPitch + half * 16;
+        const unsigned char* b0 = buf + (32 * bj0 + q4) * kPitch + half * 16;
+        const unsigned char* a1 = buf + (32 * bi1 + q4) * kPitch + half * 16;
+        const unsigned char* b1 = buf + (32 * bj1 + q4) * kPitch + half * 16;
 #pragma unroll
         for (int t = 0; t < kSteps; ++t) {
             // m h' + h m' + h h' per block (gram_planes.hip's order), the two blocks' MFMAs interleaved
@@ -207,11 +210,18 @@ __global__ __launch_bounds__(kThreads, 1) void small_gram_kernel(const float* __
         }
     };
 
-    // one slice: scale + split into LDS, prefetch into the freed registers, MFMAs, unscaled into `sum`
+    // scale + split of one slice into the LDS buffer `buf` (planes, then the rows' shifts)
     // MASKED: the slice may be the ragged one (its window overlaps the slice before it) or lie past the end (all zeros)
-    auto consume = [&](f32x4 (&v)[8], int s, int next_slice, auto prefetch_c, auto masked_c) __attribute__((always_inline)) {
-        constexpr bool kPrefetch = decltype(prefetch_c)::value;
+    auto split_to = [&](f32x4 (&v)[8], int s, unsigned char* buf, auto masked_c) __attribute__((always_inline)) {
         constexpr bool kMasked = decltype(masked_c)::value;
+        int* shifts = reinterpret_cast<int*>(buf + 2 * kPlaneBytes);
+        if (dbg & 2) {           // timing experiment: the loads are consumed, nothing is split
+            float any = 0.0f;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) any += v[k][0];
+            if (any == 1.2345e38f) shifts[r_local] = 1;
+            return;
+        }
         if constexpr (kMasked && !TINY) {
             // columns of the ragged slice's window that belong to the slice before it
             const int64_t k0 = static_cast<int64_t>(s) * kSlice;
@@ -235,7 +245,7 @@ __global__ __launch_bounds__(kThreads, 1) void small_gram_kernel(const float* __
         shift = shift < -126 ? -126 : shift;
         const float scale = __uint_as_float(static_cast<uint32_t>(shift + 127) << 23);
         if (chunk == 0) shifts[r_local] = shift;
-        unsigned char* dst = lds + r_local * kPitch + chunk * 8;
+        unsigned char* dst = buf + r_local * kPitch + chunk * 8;
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
             f16x4 h, m;
@@ -248,10 +258,19 @@ __global__ __launch_bounds__(kThreads, 1) void small_gram_kernel(const float* __
             *reinterpret_cast<u32x2*>(dst + 32 * k) = __builtin_bit_cast(u32x2, h);
             *reinterpret_cast<u32x2*>(dst + 32 * k + kPlaneBytes) = __builtin_bit_cast(u32x2, m);
         }
+    };
+    auto multiply_from = [&](const unsigned char* buf) __attribute__((always_inline)) {
+        if (dbg & 1) return;     // timing experiment: no MFMAs (BYZ_KRUM_SMALL_DBG)
+        if (nb == 2) multiply(std::integral_constant<int, 2>{}, buf);
+        else if (nb == 1) multiply(std::integral_constant<int, 1>{}, buf);
+    };
+    // one slice through ONE buffer (the loop form for long rows): split, MFMAs, two barriers
+    auto consume = [&](f32x4 (&v)[8], int s, int next_slice, auto prefetch_c, auto masked_c) __attribute__((always_inline)) {
+        constexpr bool kPrefetch = decltype(prefetch_c)::value;
+        split_to(v, s, lds, masked_c);
         __syncthreads();
         if constexpr (!TINY && kPrefetch) load_slice(v, next_slice);   // lands while the MFMAs run (a dummy word past the last slice)
-        if (nb == 2) multiply(std::integral_constant<int, 2>{});
-        else if (nb == 1) multiply(std::integral_constant<int, 1>{});
+        multiply_from(lds);
         __syncthreads();   // the planes and shifts are rewritten by the next slice
     };
 
@@ -263,7 +282,11 @@ __global__ __launch_bounds__(kThreads, 1) void small_gram_kernel(const float* __
         load_slice(va, 0);
         consume(va, 0, 1, no, no);
     } else if constexpr (PER > 0) {
-        // the host sizes the grid so that (PER - 1) * grid < n_slices: only the last step can hold the ragged slice or none
+        // the host sizes the grid so that (PER - 1) * grid < n_slices: only the last step can hold the ragged slice or none.
+        // (Round 4 measured a double-buffered form -- two LDS buffers, one barrier per slice, waves 0-3 splitting slice c + 1
+        // while waves 4-7 multiply slice c -- at 16.1 us against 15.6-16.0 for this one: the kernel's time is additive in its
+        // parts -- 9.4 us of loads + stores + launch, 5.0 of MFMAs, 1.6 of splitting, profiles/r04j_k1_decomposition.txt --
+        // because with three slices per workgroup the "pipeline" is all fill and drain.  Removed again.)
         const int s = blockIdx.x;
         load_slice(va, s);
         if constexpr (PER > 1) load_slice(vb, s + g);
@@ -395,6 +418,16 @@ __device__ double pair_sq_distance(const float* __restrict__ a, const float* __r
     return total;
 }
 
+// development aid (BYZ_KRUM_SMALL_TIMING=1): s_memtime stamps of K2's phases, taken by thread 0 of every workgroup
+constexpr int kRowStamps = 8;
+__device__ int g_rows_timing;
+__device__ unsigned long long g_rows_stamps[kMaxRows * kRowStamps];
+#define BYZ_STAMP(k)                                                                              \
+    do {                                                                                          \
+        if (timing && threadIdx.x == 0) g_rows_stamps[blockIdx.x * kRowStamps + (k)] = __builtin_amdgcn_s_memtime();   \
+    } while (0)
+
+constexpr uint32_t kScoreSentinel = 0xffc0dead;   // "no score yet": K1 writes it, K2's rows overwrite it (never a published score)
 constexpr int kGroups = 16;                       // thread groups of the slab sums (32 threads x 4 columns each)
 constexpr int kMaxPerGroup = 256 / kGroups;       // K1 launches at most 256 workgroups
 
@@ -403,19 +436,21 @@ __global__ __launch_bounds__(kThreads, 1) void small_rows_kernel(RowsArgs p) {
     __shared__ double red[kThreads];
     __shared__ double c_row[kMaxRows], c_diag[kMaxRows];
     __shared__ float d_row[kMaxRows];
-    __shared__ float sorted[kMaxRows];
     __shared__ unsigned char what[kMaxRows];        // 0 nothing, 1 re-evaluate on the difference, 2 twin of this row
     __shared__ int words[4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i = blockIdx.x;
     const int n = p.n;
+    const bool timing = g_rows_timing != 0;
+    BYZ_STAMP(0);
 
     // ---- 1. the row of the Gram and the diagonal
     {
         const int jq = tid & 31, grp = tid >> 5;
         f32x4 rv[kMaxPerGroup], dv[kMaxPerGroup];
-        const float* row_src = p.slabs + static_cast<int64_t>(i) * kMaxRows + 4 * jq;
-        const float* diag_src = p.diag_slabs + 4 * jq;
+        const int jq_read = 4 * jq < n ? jq : 0;     // columns past n: the lane repeats lane 0's request (no extra bytes)
+        const float* row_src = p.slabs + static_cast<int64_t>(i) * kMaxRows + 4 * jq_read;
+        const float* diag_src = p.diag_slabs + 4 * jq_read;
 #pragma unroll
         for (int k = 0; k < kMaxPerGroup; ++k) {
             const int g = grp + kGroups * k;
@@ -423,15 +458,27 @@ __global__ __launch_bounds__(kThreads, 1) void small_rows_kernel(RowsArgs p) {
             rv[k] = *reinterpret_cast<const f32x4*>(row_src + static_cast<int64_t>(gg) * kSlabFloats);
             dv[k] = *reinterpret_cast<const f32x4*>(diag_src + static_cast<int64_t>(gg) * kMaxRows);
         }
+        // Four slabs at a time are first added in fp32 -- (a + b) + (c + d), the same kind of rounding K1 makes when it adds
+        // its slices into a slab, on numbers a fiftieth of the total -- and the quads in fp64: a quarter of the conversions
+        // and fp64 additions, which (with the load issue) were what this phase cost (9,300 of the kernel's 24,000 ticks).
+        // Slabs past the last are zeros.  The order is the same for every entry of every row: symmetry and ties are kept.
         double rs[4] = {0.0, 0.0, 0.0, 0.0}, ds[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
         for (int k = 0; k < kMaxPerGroup; ++k) {
-            if (grp + kGroups * k < p.n_slabs) {
+            if (!(grp + kGroups * k < p.n_slabs)) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    rs[e] += static_cast<double>(rv[k][e]);
-                    ds[e] += static_cast<double>(dv[k][e]);
+                    rv[k][e] = 0.0f;
+                    dv[k][e] = 0.0f;
                 }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < kMaxPerGroup; k += 4) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                rs[e] += static_cast<double>(__fadd_rn(__fadd_rn(rv[k][e], rv[k + 1][e]), __fadd_rn(rv[k + 2][e], rv[k + 3][e])));
+                ds[e] += static_cast<double>(__fadd_rn(__fadd_rn(dv[k][e], dv[k + 1][e]), __fadd_rn(dv[k + 2][e], dv[k + 3][e])));
             }
         }
 #pragma unroll
@@ -452,6 +499,7 @@ __global__ __launch_bounds__(kThreads, 1) void small_rows_kernel(RowsArgs p) {
     }
     if (tid == 0) words[0] = 0;
     __syncthreads();
+    BYZ_STAMP(1);
 
     // ---- 2. distances; what the Gram identity cannot resolve
     if (tid < kMaxRows) {
@@ -493,99 +541,103 @@ __global__ __launch_bounds__(kThreads, 1) void small_rows_kernel(RowsArgs p) {
         __syncthreads();
     }
     if (tid < n) p.dist[static_cast<int64_t>(i) * n + tid] = d_row[tid];
+    BYZ_STAMP(2);
     if (p.prefix_len < 0) return;
 
-    // ---- 3. the score: one wave sorts the row in registers (two values per lane), lane 0 adds the prefix left to right
+    // ---- 3. the score: one wave sorts the row in registers (two values per lane, bitonic network); the prefix is then added
+    // left to right out of the registers (v_readlane with a uniform lane index: ~8 cycles per term where a walk through LDS
+    // took ~70).  (Sorting by counting on all eight waves -- every thread a quarter of the row's compares -- was measured:
+    // 8,600 ticks against 4,100 for the network.)
     if (wave == 0) {
         float x[1][2];
 #pragma unroll
         for (int r = 0; r < 2; ++r) x[0][r] = d_row[r + 2 * lane];     // +inf in the self slot and past n
         lanes::wave_bitonic_sort<2, 1>(x, lane);
-        sorted[2 * lane] = x[0][0];
-        sorted[2 * lane + 1] = x[0][1];
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-        if (lane == 0) {
-            float sc = 0.0f;
-            for (int r = 0; r < p.prefix_len; ++r) sc = __fadd_rn(sc, sorted[r]);
-            __hip_atomic_store(p.scores + i, sc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            // ---- 4. the ticket
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            words[1] = __hip_atomic_fetch_add(p.sync + 8, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const float x0 = x[0][0], x1 = x[0][1];                        // sorted index 2 l, 2 l + 1 live in lane l
+        float sc = 0.0f;
+        const int pairs = p.prefix_len >> 1;
+        for (int l = 0; l < pairs; ++l) {
+            sc = __fadd_rn(sc, __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x0), l)));
+            sc = __fadd_rn(sc, __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x1), l)));
         }
+        if (p.prefix_len & 1)
+            sc = __fadd_rn(sc, __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x0), pairs)));
+        // ---- 4. the score goes out as ONE relaxed device-scope store and doubles as this row's arrival: K1 filled the score
+        // array with a sentinel (a NaN no score can be: a NaN score is published as the canonical quiet NaN), nothing else
+        // has to be visible to the other workgroups, so there is no fence and no counter
+        if (sc != sc) sc = __uint_as_float(0x7fc00000u);
+        if (lane == 0) __hip_atomic_store(p.scores + i, sc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    __syncthreads();
-    const bool last = words[1] == n - 1;      // uniform
-    if (last && wave == 0) {
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        float best = kKrumInit;
-        int pos = 0x7fffffff, row = -1;
+    BYZ_STAMP(3);
+    if (p.out_row == nullptr && i != 0) return;     // only the index is wanted: workgroup 0 reports it
+    // Everybody who needs the winner polls the n scores until none is the sentinel and runs the argmin on what it polled
+    // (128 scores, two per lane).  All n <= 128 workgroups are resident: the spin is bounded, a time-out sets the status word.
+    if (wave == 0) {
+        float s0 = 0.0f, s1 = 0.0f;
+        unsigned spins = 0;
+        bool ok = true;
+        while (true) {
+            const uint32_t b0 = lane < n ? __hip_atomic_load(reinterpret_cast<const uint32_t*>(p.scores) + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+            const uint32_t b1 = lane + 64 < n ? __hip_atomic_load(reinterpret_cast<const uint32_t*>(p.scores) + lane + 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+            s0 = __uint_as_float(b0);
+            s1 = __uint_as_float(b1);
+            if (__ballot(b0 == kScoreSentinel || b1 == kScoreSentinel) == 0ull) break;
+            if (++spins > kSpinLimit) {
+                ok = false;
+                break;
+            }
+            __builtin_amdgcn_s_sleep(1);
+        }
+        if (!ok && lane == 0) atomicOr(p.status, kStatusSmallTimeout);
+        if (timing && lane == 0) g_rows_stamps[blockIdx.x * kRowStamps + 4] = __builtin_amdgcn_s_memtime();
+        // argmin in visit order 1, 0, 2, ... with a strict '<' against 1e20 (defences.py:27-37) = the smallest 64-bit key
+        // (order-preserving score bits << 32 | visit position) among the scores below 1e20 (NaN and +inf are not; + 0.0f
+        // folds a -0.0 onto +0.0, which compare equal)
+        unsigned long long key = ~0ull;
 #pragma unroll
         for (int r = 0; r < 2; ++r) {
             const int u = lane + 64 * r;
-            if (u < n) {
-                const float sc = __hip_atomic_load(p.scores + u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                const int vp = visit_position(u);
-                if (sc < kKrumInit && (sc < best || (sc == best && vp < pos))) {   // false for NaN, as in the reference
-                    best = sc;
-                    pos = vp;
-                    row = u;
-                }
+            const float sc = (r == 0 ? s0 : s1) + 0.0f;
+            if (u < n && sc < kKrumInit) {     // false for NaN, as in the reference
+                const uint32_t bits = __float_as_uint(sc);
+                const uint32_t ordered = (bits & 0x80000000u) ? ~bits : (bits | 0x80000000u);   // monotone in the value
+                const unsigned long long k = (static_cast<unsigned long long>(ordered) << 32) | static_cast<unsigned>(visit_position(u));
+                key = k < key ? k : key;
             }
         }
 #pragma unroll
-        for (int m = 32; m > 0; m >>= 1) {
-            const float ob = __shfl_xor(best, m, 64);
-            const int op = __shfl_xor(pos, m, 64);
-            const int orow = __shfl_xor(row, m, 64);
-            if (op != 0x7fffffff && (pos == 0x7fffffff || ob < best || (ob == best && op < pos))) {
-                best = ob;
-                pos = op;
-                row = orow;
-            }
+        for (int m = 1; m < 64; m <<= 1) {
+            const uint32_t lo = static_cast<uint32_t>(key), hi = static_cast<uint32_t>(key >> 32);
+            const uint32_t olo = __float_as_uint(lanes::lane_xor(__uint_as_float(lo), m, lane));
+            const uint32_t ohi = __float_as_uint(lanes::lane_xor(__uint_as_float(hi), m, lane));
+            const unsigned long long other = (static_cast<unsigned long long>(ohi) << 32) | olo;
+            key = other < key ? other : key;
+        }
+        int row = -1;
+        if (key != ~0ull) {
+            const int vp = static_cast<int>(key & 0xffffffffu);
+            row = vp == 0 ? 1 : (vp == 1 ? 0 : vp);
         }
         if (lane == 0) {
             // a single row has an empty distance dict in the reference: nothing is visited, the index stays -1
-            const int chosen = n < 2 ? -1 : row;
-            *p.winner = chosen;
-            __hip_atomic_store(p.sync + 10, chosen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __hip_atomic_store(p.sync + 9, p.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-    }
-    if (p.out_row == nullptr) return;
-    // ---- everybody copies its share of the winning row
-    if (tid == 0) {
-        unsigned spins = 0;
-        int seen = 0;
-        while (__hip_atomic_load(p.sync + 9, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != p.epoch) {
-            __builtin_amdgcn_s_sleep(2);
-            if (++spins > kSpinLimit) {
-                seen = -2;
-                break;
-            }
-        }
-        if (seen == 0) {
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            seen = __hip_atomic_load(p.sync + 10, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (seen < 0) seen += n;      // numpy's G[-1]: the reference returns the last row when nothing won
-            words[2] = seen;
-        } else {
-            words[2] = -2;
-            atomicOr(p.status, kStatusSmallTimeout);
+            int chosen = n < 2 ? -1 : row;
+            if (i == 0 && ok) *p.winner = chosen;
+            if (chosen < 0) chosen += n;      // numpy's G[-1]: the reference returns the last row when nothing won
+            words[2] = ok ? chosen : -2;
         }
     }
     __syncthreads();
-    if (words[2] < 0) return;
+    BYZ_STAMP(5);
+    if (p.out_row == nullptr || words[2] < 0) return;
+    // ---- everybody copies its share of the winning row
     const float* src = p.G + static_cast<int64_t>(words[2]) * p.ld;
     const int64_t per = ((p.n_cols + gridDim.x - 1) / gridDim.x + 3) & ~static_cast<int64_t>(3);
     const int64_t k0 = per * blockIdx.x;
     const int64_t k1 = k0 + per < p.n_cols ? k0 + per : p.n_cols;
     for (int64_t k = k0 + tid; k < k1; k += kThreads) p.out_row[k] = src[k];
+    BYZ_STAMP(6);
 }
+#undef BYZ_STAMP
 
 // ---- K4 ---------------------------------------------------------------------------------------------------------------
 // One wave per row: the row's n - 1 distances (+inf in the self slot and past n) sorted ascending in registers, two per
@@ -728,7 +780,6 @@ static int small_round(byz_ctx* ctx, const float* G, int64_t n_rows, int64_t n_c
     }
     float* slabs = ctx->gram_partials.as<float>();
     float* diag_slabs = slabs + slab_floats;
-    int32_t* flags = ctx->small_sync.as<int32_t>() + 4;
     if (!ctx->small_configured) {   // per context: the attribute belongs to the (function, device) pair
 #define BYZ_ATTR(T, P)                                                                            \
     BYZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&small_gram_kernel<T, P>),          \
@@ -753,7 +804,7 @@ static int small_round(byz_ctx* ctx, const float* G, int64_t n_rows, int64_t n_c
         const int unrolled = env_int("BYZ_KRUM_SMALL_UNROLL", 1) != 0 && per <= 8 ? static_cast<int>(per) : 0;
 #define BYZ_K1(T, P)                                                                               \
     small_gram_kernel<T, P><<<static_cast<unsigned>(T ? 1 : grid), kThreads, kGramLds, stream>>>(    \
-        G, n, n_cols, ld, static_cast<int>(T ? 1 : n_slices), slabs, diag_slabs, flags)
+        G, n, n_cols, ld, static_cast<int>(T ? 1 : n_slices), slabs, diag_slabs, ctx->scores.as<float>(), env_int("BYZ_KRUM_SMALL_DBG", 0))
         if (n_cols < kSlice) BYZ_K1(true, 0);
         else switch (unrolled) {
             case 1: BYZ_K1(false, 1); break;
@@ -789,8 +840,31 @@ static int small_round(byz_ctx* ctx, const float* G, int64_t n_rows, int64_t n_c
         ctx->small_epoch = ctx->small_epoch == 0x7fffffff ? 1 : ctx->small_epoch + 1;
         p.epoch = ctx->small_epoch;
         p.status = device_status_word(ctx);
+        const bool stamps = env_int("BYZ_KRUM_SMALL_TIMING", 0) != 0;
+        if (stamps) {
+            const int on = 1;
+            BYZ_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_rows_timing), &on, sizeof(int)));
+        }
         small_rows_kernel<<<static_cast<unsigned>(n), kThreads, 0, stream>>>(p);
         BYZ_TRY(check_launch("small_rows_kernel"));
+        if (stamps) {
+            static unsigned long long host[kMaxRows * kRowStamps];
+            BYZ_HIP(hipStreamSynchronize(stream));
+            BYZ_HIP(hipMemcpyFromSymbol(host, HIP_SYMBOL(g_rows_stamps), sizeof(host)));
+            const int off = 0;
+            BYZ_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_rows_timing), &off, sizeof(int)));
+            const char* names[7] = {"", "slab sums", "distances", "sort + score + ticket", "wait for all", "argmin", "row copy"};
+            for (int k = 1; k <= 6; ++k) {
+                if (k == 4 && prefix_len < 0) break;
+                double sum = 0, mx = 0;
+                for (int w = 0; w < n; ++w) {
+                    const double dt = static_cast<double>(host[w * kRowStamps + k] - host[w * kRowStamps + k - 1]);
+                    sum += dt;
+                    if (dt > mx) mx = dt;
+                }
+                std::fprintf(stderr, "small_rows %-22s mean %8.0f  max %8.0f ticks\n", names[k], sum / n, mx);
+            }
+        }
     }
     return BYZ_OK;
 }
