@@ -13,8 +13,14 @@ exchange step, the selection loop runs replicated, the median-window mean runs o
 D-vector is all-gathered (attacking_federate_learning_amd/sharded.py; DESIGN.md section "Multi-GPU").
 
 Other workloads (`--workload`): c2 (Krum N=100, D=79,510 and 21,840), c3 (trimmed_mean N=1000, D=1e6,
-trim 200), c5s (attack + Krum + Bulyan, N=10000, one D-slice of 8's worth), attack.  At --gpus 1 the c2/c3
-numbers ride along in the JSON line under "other_workloads" (they take < 1 s).
+trim 200), c5s (attack + Krum + Bulyan, N=10000, one D-slice of 8's worth; the attack's rows are one vector),
+c5u (the same with 10,000 distinct rows), attack.  At --gpus 1 all of them ride along in the JSON line under
+"other_workloads", c5s / c5u with the projection of BASELINE configs[4] onto eight GPUs.
+
+`--gpus N` IS an N-rank run: started by torch.distributed.run / the driver (WORLD_SIZE == N), or spawned by this
+script itself when nobody did; anything else exits non-zero (launch_plan).  `n_gpus` is the process group's size,
+`ranks_seen` a sum of ones through the collective library.  At one GPU the line also carries `sharded_path_w1`: the
+code path of W > 1 (both layouts) timed with every collective forced through RCCL at world size 1.
 
 Added objects: "roofline" for the dominant kernel (live HIP-event timing around every launch of that kernel on
 the stream it is launched on, via the library's byz_timing_* entry points) and "cpu_baseline" (the numpy
