@@ -55,9 +55,8 @@ int read_small(byz_ctx* ctx, int32_t (&words)[32], hipStream_t stream) {
             return BYZ_E_HIP;
         }
         if (sticky & 8) {
-            set_error("krum (N <= 128): the helper workgroups of the distance kernel lost contact with its worker (GPU shared "
-                      "with another process?); the result of this call is invalid");
-            if (ctx->small_sync.ptr) BYZ_HIP(hipMemsetAsync(ctx->small_sync.ptr, 0, 64, stream));
+            set_error("krum (N <= 128): not every row's workgroup reported its score in time (GPU shared with another "
+                      "process?); the result of this call is invalid");
             return BYZ_E_HIP;
         }
         if (sticky & 4) {
@@ -206,7 +205,6 @@ void byz_ctx_destroy(byz_ctx* ctx) {
     ctx->redo_tiles.release();
     ctx->xchg.release();
     ctx->small.release();
-    ctx->small_sync.release();
     ctx->stage_in.release();
     ctx->stage_out.release();
     ctx->pinned.release();

@@ -136,8 +136,6 @@ struct byz_ctx {
     int64_t bulyan_rescored = 0; // rows the last Bulyan loop re-scored in the reference's fp32 arithmetic
     byz::Buffer selection;       // theta int32
     byz::Buffer small;           // misc device scalars (winner index, status words)
-    byz::Buffer small_sync;      // krum_small.hip: flag / pair count / arrivals of the distance kernel's helpers
-    int32_t small_epoch = 0;     // krum_small.hip: value the flag takes in the current launch
     bool small_configured = false;   // krum_small.hip: dynamic-LDS attributes set for this context's device
     byz::Buffer assemble_table;  // byz_assemble_rows_dev: segment starts + every client's tensor pointers
     byz::Buffer stage_in;        // device copy of a host matrix
@@ -155,8 +153,8 @@ inline hipStream_t as_stream(void* s) { return static_cast<hipStream_t>(s); }
 // ctx->small (256 bytes, allocated and zeroed with the context) holds the device-side scalars:
 //   [0] Krum winner   [8] Bulyan loop status   [9] rows the Bulyan loop re-scored
 //   [16] sticky device status (bit 0: a Gram chunk lost its ticket, bit 1: near-duplicate pair list overflowed,
-//        bit 2: two rows with bitwise equal Gram entries turned out to differ, bit 3: the helpers of the small-N distance
-//        kernel lost contact with its worker)
+//        bit 2: two rows with bitwise equal Gram entries turned out to differ, bit 3: the row workgroups of the small-N
+//        path did not all report their scores in time)
 //   [17] number of near-duplicate pairs listed by the last distance kernel
 inline int32_t* device_status_word(byz_ctx* ctx) { return ctx->small.as<int32_t>() + 16; }
 inline int32_t* near_pair_count_word(byz_ctx* ctx) { return ctx->small.as<int32_t>() + 17; }

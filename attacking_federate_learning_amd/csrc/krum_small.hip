@@ -44,15 +44,11 @@ constexpr int kSteps = kSlice / 16;                 // MFMA k-steps per slice
 constexpr int kPitch = 2 * kSlice + 16;             // bytes per row and plane in LDS: 272 (17 x 16)
 constexpr int kPlaneBytes = kMaxRows * kPitch;      // 34,816
 constexpr int kGramLds = 2 * kPlaneBytes + kMaxRows * 4;   // two planes + the rows' shifts
-constexpr int kBlockEntries = 32 * 32;
-constexpr int kMaxBlocks = 10;                      // lower triangle of 4 x 4 blocks
 constexpr int kSlabFloats = kMaxRows * kMaxRows;    // a workgroup's partial Gram: full 128 x 128, both triangles
-constexpr int kDistPitch = kMaxRows + 1;            // floats; odd pitch: a column walk touches every bank
 constexpr int kPairChunk = 8192;                    // columns per (pair, chunk) work item of the near-duplicate pass
 constexpr double kNearEps = 1.0 / 16.0;             // gram.hip's threshold
 constexpr float kKrumInit = 1e20f;                  // defences.py:27
-constexpr int kStatusPairOverflow = 2;              // bits of the context's sticky status word (gram.hip)
-constexpr int kStatusFalseTwin = 4;
+constexpr int kStatusFalseTwin = 4;                 // bits of the context's sticky status word (gram.hip)
 constexpr int kStatusSmallTimeout = 8;
 constexpr unsigned kSpinLimit = 1u << 18;   // ~0.1-0.3 s: the worker publishes within microseconds
 
@@ -63,7 +59,6 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 
-__device__ __forceinline__ int block_index(int bi, int bj) { return bi * (bi + 1) / 2 + bj; }
 __device__ __forceinline__ int visit_position(int u) { return u == 0 ? 1 : (u == 1 ? 0 : u); }
 
 // 4 consecutive floats of a row starting at column k (any 4-byte alignment), zero past n_cols.  Branch-free: every lane
@@ -103,7 +98,6 @@ __global__ __launch_bounds__(kThreads, 1) void small_gram_kernel(const float* __
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int half = lane >> 5, q4 = lane & 31;
     const int n_rb = (n_rows + 31) >> 5;                 // live 32-row blocks
-    const int n_blocks = n_rb * (n_rb + 1) / 2;
     // K2's arrival board: the previous call's K2 is done with it, this call's K2 starts behind this kernel
     if (blockIdx.x == 0 && tid < kMaxRows) reinterpret_cast<uint32_t*>(score_board)[tid] = 0xffc0deadu;
 
@@ -320,7 +314,6 @@ __global__ __launch_bounds__(kThreads, 1) void small_gram_kernel(const float* __
     // block, so that whoever owns row i in K2 finds c_i0 .. c_i,127 as 512 contiguous bytes per slab.  The mirror image of
     // an off-diagonal block goes out as 16-byte stores (four consecutive rows of the block = four consecutive columns of
     // its transpose sit in consecutive accumulator registers).
-    (void)n_blocks;
     float* out = slabs + static_cast<int64_t>(blockIdx.x) * kSlabFloats;
 #pragma unroll
     for (int b = 0; b < 2; ++b) {
@@ -378,8 +371,6 @@ struct RowsArgs {
     float* scores;             // n
     int32_t* winner;           // device word the index goes to
     float* out_row;            // optional: copy of the winning row
-    int32_t* sync;             // [8] arrivals, [9] winner flag (epoch), [10] winner
-    int32_t epoch;
     int32_t* status;
 };
 
@@ -750,10 +741,6 @@ int reserve_small_workspaces(byz_ctx* ctx) {
     const size_t slab_floats = static_cast<size_t>(ctx->num_cus) * kSlabFloats;
     BYZ_TRY(ctx->gram_partials.ensure((slab_floats + static_cast<size_t>(ctx->num_cus) * kMaxRows) * sizeof(float)));
     BYZ_TRY(ctx->scores.ensure(static_cast<size_t>(kMaxRows) * sizeof(float)));
-    if (ctx->small_sync.ptr == nullptr) {
-        BYZ_TRY(ctx->small_sync.ensure(64));
-        BYZ_HIP(hipMemset(ctx->small_sync.ptr, 0, 64));
-    }
     return BYZ_OK;
 }
 
@@ -764,8 +751,6 @@ static int small_round(byz_ctx* ctx, const float* G, int64_t n_rows, int64_t n_c
     BYZ_REQUIRE(G && dist && n_rows >= 1 && n_rows <= kMaxRows && n_cols > 0 && ld >= n_cols,
                 "small distances: bad shape %lld x %lld ld %lld", (long long)n_rows, (long long)n_cols, (long long)ld);
     const int n = static_cast<int>(n_rows);
-    const int n_rb = (n + 31) / 32;
-    const int n_blocks = n_rb * (n_rb + 1) / 2;
     const int64_t n_slices = ceil_div(n_cols, kSlice);
     // one workgroup per CU at most; the grid is sized so that everybody gets the same number of slices (+- 1)
     const int grid = static_cast<int>(ceil_div(n_slices, ceil_div(n_slices, ctx->num_cus < 256 ? ctx->num_cus : 256)));
@@ -774,10 +759,6 @@ static int small_round(byz_ctx* ctx, const float* G, int64_t n_rows, int64_t n_c
     const size_t slab_floats = static_cast<size_t>(grid) * kSlabFloats;
     BYZ_TRY(ctx->gram_partials.ensure((slab_floats + static_cast<size_t>(grid) * kMaxRows) * sizeof(float)));
     BYZ_TRY(ctx->scores.ensure(static_cast<size_t>(kMaxRows) * sizeof(float)));
-    if (ctx->small_sync.ptr == nullptr) {
-        BYZ_TRY(ctx->small_sync.ensure(64));
-        BYZ_HIP(hipMemsetAsync(ctx->small_sync.ptr, 0, 64, stream));
-    }
     float* slabs = ctx->gram_partials.as<float>();
     float* diag_slabs = slabs + slab_floats;
     if (!ctx->small_configured) {   // per context: the attribute belongs to the (function, device) pair
@@ -820,7 +801,6 @@ static int small_round(byz_ctx* ctx, const float* G, int64_t n_rows, int64_t n_c
 #undef BYZ_K1
         BYZ_TRY(check_launch("small_gram_kernel"));
     }
-    (void)n_blocks;
     if (!(skip & 2)) {
         KernelTimer t(ctx, prefix_len >= 0 ? BYZ_K_ROW_SORT : BYZ_K_DISTANCES, stream);
         RowsArgs p;
@@ -836,9 +816,6 @@ static int small_round(byz_ctx* ctx, const float* G, int64_t n_rows, int64_t n_c
         p.scores = ctx->scores.as<float>();
         p.winner = winner_dev;
         p.out_row = out_row;
-        p.sync = ctx->small_sync.as<int32_t>();
-        ctx->small_epoch = ctx->small_epoch == 0x7fffffff ? 1 : ctx->small_epoch + 1;
-        p.epoch = ctx->small_epoch;
         p.status = device_status_word(ctx);
         const bool stamps = env_int("BYZ_KRUM_SMALL_TIMING", 0) != 0;
         if (stamps) {
