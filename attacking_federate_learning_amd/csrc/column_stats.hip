@@ -12,8 +12,16 @@
 // Algorithmic traffic: 4*rows*cols bytes read + 4*cols written.
 #include "common.hpp"
 
+#include <cstdlib>
+
 namespace byz {
 namespace {
+
+int env_int(const char* name, int fallback) {
+    const char* v = std::getenv(name);
+    return v ? std::atoi(v) : fallback;
+}
+
 
 constexpr int kThreads = 256;
 typedef float float4u __attribute__((ext_vector_type(4), aligned(4)));
@@ -96,25 +104,52 @@ __global__ __launch_bounds__(kThreads) void column_finalize_kernel(
     }
 }
 
-// vec -> every row of G (malicious.py:26-27: all malicious clients get ONE array).  VEC = 4: 16-byte stores, 4 KiB of a row per
-// workgroup and step (rows and the vector 16-byte aligned); VEC = 1: any alignment.
-template <int VEC>
+// vec -> every row of G (malicious.py:26-27: all malicious clients get ONE array).  VEC = 4: 16-byte stores (rows and the
+// vector 16-byte aligned), a workgroup owns RUN x 4 KiB CONSECUTIVE bytes of every row it visits -- with one 4 KiB piece per
+// row visit (round 3) every wave's next store lay a whole row further on and HBM saw 1 KiB writes scattered over thousands of
+// rows: 8.0 ms for 2400 rows x 3.125e6 columns (30 GB), 6.9 / 6.1 / 5.9 ms with RUN = 4 / 8 / 16 (5.1 TB/s;
+// scripts/broadcast_probe.py, BYZ_BROADCAST_RUN); VEC = 1: any alignment.
+template <int VEC, int RUN>
 __global__ __launch_bounds__(kThreads) void broadcast_rows_kernel(float* __restrict__ G, int64_t n_rows,
                                                                   int64_t n_cols, int64_t ld,
                                                                   const float* __restrict__ vec) {
     typedef float f32x4 __attribute__((ext_vector_type(4)));
-    const int64_t c = (static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x) * VEC;
-    if (c >= n_cols) return;
+    const int64_t c0 = (static_cast<int64_t>(blockIdx.x) * RUN * kThreads + threadIdx.x) * VEC;
     if constexpr (VEC == 4) {
-        if (c + 3 < n_cols) {
-            const f32x4 v = *reinterpret_cast<const f32x4*>(vec + c);
-            for (int64_t r = blockIdx.y; r < n_rows; r += gridDim.y) *reinterpret_cast<f32x4*>(G + r * ld + c) = v;
-            return;
+        f32x4 v[RUN];
+        bool whole[RUN];
+#pragma unroll
+        for (int k = 0; k < RUN; ++k) {
+            const int64_t c = c0 + static_cast<int64_t>(k) * kThreads * VEC;
+            whole[k] = c + 3 < n_cols;
+            v[k] = whole[k] ? *reinterpret_cast<const f32x4*>(vec + c) : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
         }
-    }
-    for (int e = 0; e < VEC && c + e < n_cols; ++e) {
-        const float v = vec[c + e];
-        for (int64_t r = blockIdx.y; r < n_rows; r += gridDim.y) G[r * ld + c + e] = v;
+        for (int64_t r = blockIdx.y; r < n_rows; r += gridDim.y) {
+            float* row = G + r * ld;
+#pragma unroll
+            for (int k = 0; k < RUN; ++k) {
+                const int64_t c = c0 + static_cast<int64_t>(k) * kThreads * VEC;
+                if (whole[k]) *reinterpret_cast<f32x4*>(row + c) = v[k];
+            }
+        }
+        // the ragged tail of the row (fewer than four columns): one thread's business
+#pragma unroll
+        for (int k = 0; k < RUN; ++k) {
+            const int64_t c = c0 + static_cast<int64_t>(k) * kThreads * VEC;
+            if (!whole[k] && c < n_cols)
+                for (int64_t e = c; e < n_cols; ++e) {
+                    const float x = vec[e];
+                    for (int64_t r = blockIdx.y; r < n_rows; r += gridDim.y) G[r * ld + e] = x;
+                }
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < RUN; ++k) {
+            const int64_t c = c0 + static_cast<int64_t>(k) * kThreads;
+            if (c >= n_cols) continue;
+            const float x = vec[c];
+            for (int64_t r = blockIdx.y; r < n_rows; r += gridDim.y) G[r * ld + c] = x;
+        }
     }
 }
 
@@ -204,12 +239,28 @@ int launch_broadcast_rows(byz_ctx* ctx, float* G, int64_t n_rows, int64_t n_cols
                           hipStream_t stream) {
     KernelTimer t(ctx, BYZ_K_MISC, stream);
     const bool wide = ld % 4 == 0 && (reinterpret_cast<uintptr_t>(G) & 15u) == 0 && (reinterpret_cast<uintptr_t>(vec) & 15u) == 0;
-    const unsigned blocks = static_cast<unsigned>(ceil_div(n_cols, kThreads * (wide ? 4 : 1)));
+    const int run = env_int("BYZ_BROADCAST_RUN", 16);      // 4 KiB pieces of a row a workgroup writes back to back (1, 2, 4, 8, 16)
+    const int64_t per_wg = static_cast<int64_t>(kThreads) * (wide ? 4 : 1) * run;
+    const unsigned blocks = static_cast<unsigned>(ceil_div(n_cols, per_wg));
     unsigned ysplit = static_cast<unsigned>(ceil_div(static_cast<int64_t>(ctx->num_cus) * 8, blocks));
     if (ysplit > n_rows) ysplit = static_cast<unsigned>(n_rows);
     if (ysplit < 1) ysplit = 1;
-    if (wide) broadcast_rows_kernel<4><<<dim3(blocks, ysplit), kThreads, 0, stream>>>(G, n_rows, n_cols, ld, vec);
-    else broadcast_rows_kernel<1><<<dim3(blocks, ysplit), kThreads, 0, stream>>>(G, n_rows, n_cols, ld, vec);
+    const dim3 grid(blocks, ysplit);
+#define BYZ_BC(V, R) broadcast_rows_kernel<V, R><<<grid, kThreads, 0, stream>>>(G, n_rows, n_cols, ld, vec)
+    if (wide) {
+        if (run == 1) BYZ_BC(4, 1);
+        else if (run == 2) BYZ_BC(4, 2);
+        else if (run == 4) BYZ_BC(4, 4);
+        else if (run == 8) BYZ_BC(4, 8);
+        else BYZ_BC(4, 16);
+    } else {
+        if (run == 1) BYZ_BC(1, 1);
+        else if (run == 2) BYZ_BC(1, 2);
+        else if (run == 4) BYZ_BC(1, 4);
+        else if (run == 8) BYZ_BC(1, 8);
+        else BYZ_BC(1, 16);
+    }
+#undef BYZ_BC
     return check_launch("broadcast_rows_kernel");
 }
 
