@@ -271,7 +271,7 @@ class BulyanSharded(Workload):
         if self.n <= 256:
             return 'f32'
         mode = self.dominant().get('arithmetic')
-        return {'f16x2': 'f32 (Gram: fp16x2 split of every fp32 operand, 3 fp16 MFMAs per block, fp32/fp64 accumulate; 6e-8 vs fp64)',
+        return {'f16x2': 'f32 (Gram: fp16x2 split of every fp32 operand, 3 fp16 MFMAs per block, fp32/fp64 accumulate; <= 2e-7 of |gi||gj| vs fp64, distances <= 1e-6)',
                 'split': 'f32 (Gram: bf16x3 exact-split MFMA, fp32 accumulate)'}.get(mode, 'f32')
 
     def dominant(self):
