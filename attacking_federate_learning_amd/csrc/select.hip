@@ -198,16 +198,65 @@ __device__ __forceinline__ bool better(const Candidate& a, const Candidate& b) {
     return a.score < b.score || (a.score == b.score && a.pos < b.pos);
 }
 
-__device__ __forceinline__ Candidate wave_best(Candidate c) {
-#pragma unroll
-    for (int m = 32; m > 0; m >>= 1) {
-        Candidate o;
-        o.score = __shfl_xor(c.score, m, 64);
-        o.pos = __shfl_xor(c.pos, m, 64);
-        o.row = __shfl_xor(c.row, m, 64);
-        if (better(o, c)) c = o;
+// Wave-wide reductions without the LDS pipe: four DPP steps inside every 16-lane row (xor 1, xor 2, half mirror, mirror: each
+// an involution, so every lane ends up with its row's result), then the four rows' results through v_readlane.  A
+// ds_bpermute shuffle costs ~100 cycles of dependent latency and the loop makes ~30 of them per pick; a DPP move ~8.
+template <int CTRL>
+__device__ __forceinline__ int dpp_i(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, true); }
+template <int CTRL>
+__device__ __forceinline__ double dpp_d(double v) {
+    const long long b = __double_as_longlong(v);
+    const int lo = dpp_i<CTRL>(static_cast<int>(b)), hi = dpp_i<CTRL>(static_cast<int>(b >> 32));
+    return __longlong_as_double((static_cast<long long>(hi) << 32) | static_cast<unsigned>(lo));
+}
+__device__ __forceinline__ double readlane_d(double v, int l) {
+    const long long b = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_readlane(static_cast<int>(b), l), hi = __builtin_amdgcn_readlane(static_cast<int>(b >> 32), l);
+    return __longlong_as_double((static_cast<long long>(hi) << 32) | static_cast<unsigned>(lo));
+}
+
+__device__ __forceinline__ Candidate wave_best(Candidate c) {   // wave-uniform result
+#define BYZ_STEP(CTRL)                                                                              \
+    {                                                                                               \
+        Candidate o;                                                                                \
+        o.score = dpp_d<CTRL>(c.score);                                                             \
+        o.pos = dpp_i<CTRL>(c.pos);                                                                 \
+        o.row = dpp_i<CTRL>(c.row);                                                                 \
+        if (better(o, c)) c = o;                                                                    \
     }
-    return c;
+    BYZ_STEP(0xB1) BYZ_STEP(0x4E) BYZ_STEP(0x141) BYZ_STEP(0x140)
+#undef BYZ_STEP
+    Candidate best{readlane_d(c.score, 0), __builtin_amdgcn_readlane(c.pos, 0), __builtin_amdgcn_readlane(c.row, 0)};
+#pragma unroll
+    for (int l = 16; l < 64; l += 16) {
+        const Candidate o{readlane_d(c.score, l), __builtin_amdgcn_readlane(c.pos, l), __builtin_amdgcn_readlane(c.row, l)};
+        if (better(o, best)) best = o;
+    }
+    return best;
+}
+__device__ __forceinline__ double wave_min_d(double v) {   // wave-uniform; NaN-free inputs
+    v = fmin(v, dpp_d<0xB1>(v));
+    v = fmin(v, dpp_d<0x4E>(v));
+    v = fmin(v, dpp_d<0x141>(v));
+    v = fmin(v, dpp_d<0x140>(v));
+    return fmin(fmin(readlane_d(v, 0), readlane_d(v, 16)), fmin(readlane_d(v, 32), readlane_d(v, 48)));
+}
+__device__ __forceinline__ float wave_min_f(float v) {
+    v = __builtin_fminf(v, __int_as_float(dpp_i<0xB1>(__float_as_int(v))));
+    v = __builtin_fminf(v, __int_as_float(dpp_i<0x4E>(__float_as_int(v))));
+    v = __builtin_fminf(v, __int_as_float(dpp_i<0x141>(__float_as_int(v))));
+    v = __builtin_fminf(v, __int_as_float(dpp_i<0x140>(__float_as_int(v))));
+    const int b = __float_as_int(v);
+    return __builtin_fminf(__builtin_fminf(__int_as_float(__builtin_amdgcn_readlane(b, 0)), __int_as_float(__builtin_amdgcn_readlane(b, 16))),
+                           __builtin_fminf(__int_as_float(__builtin_amdgcn_readlane(b, 32)), __int_as_float(__builtin_amdgcn_readlane(b, 48))));
+}
+__device__ __forceinline__ int wave_min_i(int v) {
+    v = min(v, dpp_i<0xB1>(v));
+    v = min(v, dpp_i<0x4E>(v));
+    v = min(v, dpp_i<0x141>(v));
+    v = min(v, dpp_i<0x140>(v));
+    return min(min(__builtin_amdgcn_readlane(v, 0), __builtin_amdgcn_readlane(v, 16)),
+               min(__builtin_amdgcn_readlane(v, 32), __builtin_amdgcn_readlane(v, 48)));
 }
 
 // Block-wide best candidate, broadcast to every thread.  `slots` holds blockDim.x/64 candidates.
@@ -807,8 +856,7 @@ __global__ __launch_bounds__(kGridThreads) void bulyan_grid_kernel(
         const Candidate best = block_best(c, slots);
         const int best_class = best.row >= 0 ? cls[best.row] : -1;
         double second = (candidate && my_class != best_class) ? score : __builtin_inf();
-#pragma unroll
-        for (int m = 32; m > 0; m >>= 1) second = fmin(second, __shfl_xor(second, m, 64));
+        second = wave_min_d(second);
         if (lane == 0) second_slots[wave] = second;
         __syncthreads();
         if (wave == 0) {
@@ -842,9 +890,7 @@ __global__ __launch_bounds__(kGridThreads) void bulyan_grid_kernel(
             const float b = __uint_as_float(static_cast<uint32_t>(gb >> 32));
             const int a_row = static_cast<int>((ga >> 18) & 0x3fffu);
             const int a_cls = static_cast<int>((ga >> 4) & 0x3fffu);
-            float m1 = a;
-#pragma unroll
-            for (int m = 32; m > 0; m >>= 1) m1 = __builtin_fminf(m1, __shfl_xor(m1, m, 64));
+            const float m1 = wave_min_f(a);
             GridDecision d{0, -1, 0.0};
             if (!ok) {
                 d.mode = 3;
@@ -866,9 +912,7 @@ __global__ __launch_bounds__(kGridThreads) void bulyan_grid_kernel(
                 const int lead_cls = __builtin_amdgcn_readlane(a_cls, __builtin_ctzll(first));
                 const bool one_class = __ballot(in_b) == 0ull && __ballot(in_a && a_cls != lead_cls) == 0ull;
                 if (one_class) {
-                    int pos = in_a ? visit_position(a_row) : 0x7fffffff;
-#pragma unroll
-                    for (int m = 32; m > 0; m >>= 1) pos = min(pos, __shfl_xor(pos, m, 64));
+                    const int pos = wave_min_i(in_a ? visit_position(a_row) : 0x7fffffff);
                     d.winner = pos == 0 ? 1 : (pos == 1 ? 0 : pos);   // visit_position is its own inverse
                 } else {
                     d.mode = 1;
