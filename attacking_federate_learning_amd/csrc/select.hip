@@ -191,6 +191,7 @@ struct Candidate {
     double score;
     int pos;   // position in the reference's visit order; INT_MAX = none
     int row;
+    int cls;   // the row's twin class where the caller needs it (the Bulyan loop), else 0: travels with the winner
 };
 
 __device__ __forceinline__ bool better(const Candidate& a, const Candidate& b) {
@@ -222,14 +223,17 @@ __device__ __forceinline__ Candidate wave_best(Candidate c) {   // wave-uniform 
         o.score = dpp_d<CTRL>(c.score);                                                             \
         o.pos = dpp_i<CTRL>(c.pos);                                                                 \
         o.row = dpp_i<CTRL>(c.row);                                                                 \
+        o.cls = dpp_i<CTRL>(c.cls);                                                                 \
         if (better(o, c)) c = o;                                                                    \
     }
     BYZ_STEP(0xB1) BYZ_STEP(0x4E) BYZ_STEP(0x141) BYZ_STEP(0x140)
 #undef BYZ_STEP
-    Candidate best{readlane_d(c.score, 0), __builtin_amdgcn_readlane(c.pos, 0), __builtin_amdgcn_readlane(c.row, 0)};
+    Candidate best{readlane_d(c.score, 0), __builtin_amdgcn_readlane(c.pos, 0), __builtin_amdgcn_readlane(c.row, 0),
+                   __builtin_amdgcn_readlane(c.cls, 0)};
 #pragma unroll
     for (int l = 16; l < 64; l += 16) {
-        const Candidate o{readlane_d(c.score, l), __builtin_amdgcn_readlane(c.pos, l), __builtin_amdgcn_readlane(c.row, l)};
+        const Candidate o{readlane_d(c.score, l), __builtin_amdgcn_readlane(c.pos, l), __builtin_amdgcn_readlane(c.row, l),
+                          __builtin_amdgcn_readlane(c.cls, l)};
         if (better(o, best)) best = o;
     }
     return best;
@@ -851,10 +855,10 @@ __global__ __launch_bounds__(kGridThreads) void bulyan_grid_kernel(
         const double score = tot - top;
         // (a non-finite distance inside the summed prefix makes the reference's score inf / NaN: never below 1e20)
         const bool candidate = alive && bad <= drop && score < static_cast<double>(kKrumInit);   // false for NaN
-        Candidate c{static_cast<double>(kKrumInit), 0x7fffffff, -1};
-        if (candidate) c = Candidate{score, my_pos, u};
+        Candidate c{static_cast<double>(kKrumInit), 0x7fffffff, -1, -1};
+        if (candidate) c = Candidate{score, my_pos, u, my_class};
         const Candidate best = block_best(c, slots);
-        const int best_class = best.row >= 0 ? cls[best.row] : -1;
+        const int best_class = best.cls;      // (travels with the winner: a load of cls[best.row] here cost every pick a round trip)
         double second = (candidate && my_class != best_class) ? score : __builtin_inf();
         second = wave_min_d(second);
         if (lane == 0) second_slots[wave] = second;
