@@ -672,7 +672,6 @@ __device__ __forceinline__ float integer_passes(uint32_t (&M)[8], const int (&ex
 
 // development aid (BYZ_BULYAN_CLOCKS=1): re-scores, their batches, integer passes and cycles
 __device__ unsigned long long g_rescore_clock[8];
-__device__ unsigned long long g_coop_stats[8];   // batches: sequential by kind, clean, split, window too wide, failed check A, failed check B
 
 // One wave; wave-uniform result; `ok` = false when the row holds a negative value (the passes assume distances: the caller
 // then takes the literal chain).  `head`: 512 floats of LDS for the literal chain over the first entries.
@@ -798,423 +797,6 @@ __device__ __forceinline__ float reference_score_marked(const float* sorted_val,
     return s;
 }
 
-// ---------------------------------------------------------------------------------------------------
-// The same score by ALL FOUR WAVES of the workgroup (round 4; prototype and its checks: scripts/proto/seqsum_pred.py).
-//
-// The integer passes are sequential only because a batch of 512 entries needs the unit (binade) of the running sum it starts
-// from.  But the running sum is known in advance to within its rounding error: with E_j the exact sum of the first j entries
-// (fp64), the fp32 partial sum of j non-negative terms satisfies |s_j - E_j| <= u j E_j (u = 2^-24).  So
-//   1. every wave takes the batches b = wave, wave + 4, ...: live entries and their fp64 sum per batch           [barrier]
-//   2. everybody forms the prefix over the (at most 32) batches.  A batch whose enclosure [E_b (1 - d), E_b+1 (1 + d)] lies
-//      inside ONE binade is CLEAN: every partial sum inside it has that exponent, so its total increment under an incoming
-//      parity of 0 / 1 (ties) is formed right away, by any wave, independently of every other batch -- waves 1 .. 3 do that
-//      while wave 0 adds batch 0 literally (the sum changes binade every other step there)                        [barrier]
-//   3. wave 0 chains: one integer addition per clean batch (checked against the actual sum: exponent and no overflow past
-//      2^24 -- a failed check sends the batch down the sequential path, so the result does not hang on the enclosure), and the
-//      existing integer passes, with the exact running sum, for the batches whose enclosure touches a power of two (the
-//      ~log2(m / 512) crossings) -- unless the batch holds exactly ONE crossing: then the entries that stay below the power
-//      of two for sure (unit q) and the entries that start above it for sure (unit 2 q) are totalled separately, in advance
-//      like a clean batch, and only the <= 8 entries in between (the window) are added literally by the chain.
-// The batches are dealt out as the waves come free (an LDS counter; wave 0 joins after the head).  Measured (same box,
-// scripts/bulyan_ab.py, selections identical pick for pick): a re-score of a 7600-entry prefix ~22,000 cycles where one wave
-// alone needs ~46,000.  Used when the workgroup has ONE contender (with several, one wave each keeps all four busy anyway;
-// two contenders one after the other were measured: slower): the loop 28.8 -> 26.3 ms at N = 4000, 151.8 -> 143 ms at
-// N = 10,000 (scaled family), 90.7 -> 87 ms under the attack.
-constexpr int kCoopMaxBatches = kMaxSelectRows / 512;   // 32
-constexpr int kCoopWaves = 4;                            // = kGridThreads / 64
-constexpr int kCoopPerWave = kCoopMaxBatches / kCoopWaves;   // batches a wave holds in registers: b = wave + 4 q
-constexpr int kCoopWindow = 8;                           // entries around a crossing that are added literally (one register each)
-struct CoopShared {
-    double sum[kCoopMaxBatches];          // exact sum of the live entries of batch b
-    int cnt[kCoopMaxBatches];             // live entries of batch b
-    uint32_t total[kCoopMaxBatches][2];   // increment of the clean batch / of the part in front of the window, by incoming parity
-    uint32_t total_b[kCoopMaxBatches][2]; // split batches: the part behind the window, under the next unit
-    int win_n[kCoopMaxBatches];           // -1 clean, >= 0 entries in the window of a split batch, -2 sequential
-    float win[kCoopMaxBatches][kCoopWindow];
-    __attribute__((aligned(16))) float head[512];   // batch 0 as it enters the literal chain
-    int flags;                            // bit 0: a live entry carries a sign bit (the passes assume distances)
-    int next;                             // the next batch nobody has taken yet (phase 2 deals them out as the waves come free)
-    float result;
-};
-
-__device__ __forceinline__ double wave_sum_d(double v) {   // wave-uniform (only enclosures are built on it: any order will do)
-    v += dpp_d<0xB1>(v);
-    v += dpp_d<0x4E>(v);
-    v += dpp_d<0x141>(v);
-    v += dpp_d<0x140>(v);
-    return (readlane_d(v, 0) + readlane_d(v, 16)) + (readlane_d(v, 32) + readlane_d(v, 48));
-}
-__device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v) { return static_cast<uint32_t>(wave_sum_int(static_cast<int>(v))); }
-__device__ __forceinline__ double dpp_d_ctl(double v, int step) {   // the moves of wave_scan_u32, on both halves of a double
-    const long long b = __double_as_longlong(v);
-    int lo = static_cast<int>(b), hi = static_cast<int>(b >> 32);
-    switch (step) {
-        case 0: lo = __builtin_amdgcn_update_dpp(0, lo, 0x111, 0xF, 0xF, true), hi = __builtin_amdgcn_update_dpp(0, hi, 0x111, 0xF, 0xF, true); break;
-        case 1: lo = __builtin_amdgcn_update_dpp(0, lo, 0x112, 0xF, 0xF, true), hi = __builtin_amdgcn_update_dpp(0, hi, 0x112, 0xF, 0xF, true); break;
-        case 2: lo = __builtin_amdgcn_update_dpp(0, lo, 0x114, 0xF, 0xF, true), hi = __builtin_amdgcn_update_dpp(0, hi, 0x114, 0xF, 0xF, true); break;
-        case 3: lo = __builtin_amdgcn_update_dpp(0, lo, 0x118, 0xF, 0xF, true), hi = __builtin_amdgcn_update_dpp(0, hi, 0x118, 0xF, 0xF, true); break;
-        case 4: lo = __builtin_amdgcn_update_dpp(0, lo, 0x142, 0xA, 0xF, false), hi = __builtin_amdgcn_update_dpp(0, hi, 0x142, 0xA, 0xF, false); break;
-        default: lo = __builtin_amdgcn_update_dpp(0, lo, 0x143, 0xC, 0xF, false), hi = __builtin_amdgcn_update_dpp(0, hi, 0x143, 0xC, 0xF, false); break;
-    }
-    return __longlong_as_double((static_cast<long long>(hi) << 32) | static_cast<unsigned>(lo));
-}
-__device__ __forceinline__ double wave_scan_d(double v) {   // inclusive, lane order (non-negative terms: +0.0 shifted in)
-#pragma unroll
-    for (int step = 0; step < 6; ++step) v += dpp_d_ctl(v, step);
-    return v;
-}
-
-// The enclosure of the fp32 partial sums of `terms` non-negative entries whose exact sum is e: |s - e| <= u terms e.
-__device__ __forceinline__ double enclosure_margin(int terms) { return 1.1 * 5.9604644775390625e-08 * static_cast<double>(terms + 2); }
-__device__ __forceinline__ int exponent_of(double v) { return static_cast<int>((__double_as_longlong(v) >> 52) & 0x7ff) - 1023; }
-
-// increments of one batch under the unit of exponent `es`, for an incoming parity of 0 and of 1 (integer_passes' first half)
-__device__ __forceinline__ void batch_totals(const uint32_t (&M)[8], const int (&ex)[8], int es, int lane, uint32_t& t0, uint32_t& t1) {
-    const unsigned long long lt = (1ull << lane) - 1ull;
-    uint32_t a[8], y[8];
-    uint32_t mine = 0;
-    bool any_tie = false;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const int sh = es - ex[j];
-        const int shc = sh < 0 ? 0 : (sh > 25 ? 25 : sh);
-        const unsigned long long w = (static_cast<unsigned long long>(M[j]) << 32) >> shc;
-        y[j] = static_cast<uint32_t>(w);
-        a[j] = sh < 0 ? (M[j] != 0u ? (1u << 24) : 0u) : static_cast<uint32_t>(w >> 32);
-        mine += a[j] + (y[j] > 0x80000000u ? 1u : 0u);
-        any_tie = any_tie || y[j] == 0x80000000u;
-    }
-    uint32_t m0 = mine, m1 = mine;
-    const unsigned long long tie_lanes = __ballot(any_tie);
-    if (tie_lanes != 0ull) {   // uniform
-        uint32_t s0 = mine, s1 = mine, p0 = mine & 1u, p1 = p0 ^ 1u;
-        if (any_tie) {
-            s0 = 0, s1 = 0, p0 = 0, p1 = 1;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const uint32_t alpha = a[j] & 1u, ab = y[j] > 0x80000000u ? 1u : 0u, ti = y[j] == 0x80000000u ? 1u : 0u;
-                s0 += a[j] + (ab | (ti & (p0 ^ alpha)));
-                s1 += a[j] + (ab | (ti & (p1 ^ alpha)));
-                p0 = ti ? 0u : (p0 ^ alpha ^ ab);
-                p1 = ti ? 0u : (p1 ^ alpha ^ ab);
-            }
-        }
-        // the parity in front of this lane: behind the last lane that holds a tie its outgoing parity is absolute; in front
-        // of the first one it is the batch's incoming parity times the xor of the lanes in between
-        const unsigned long long valm = __ballot(p0 == 1u);
-        const unsigned long long cm = tie_lanes & lt;
-        uint32_t pin0, pin1;
-        if (cm == 0ull) {
-            pin0 = static_cast<uint32_t>(__popcll(valm & lt)) & 1u;
-            pin1 = pin0 ^ 1u;
-        } else {
-            const int j = 63 - __clzll(static_cast<long long>(cm));
-            const unsigned long long after = lt & ~((2ull << j) - 1ull);
-            pin0 = (static_cast<uint32_t>(valm >> j) & 1u) ^ (static_cast<uint32_t>(__popcll(valm & after)) & 1u);
-            pin1 = pin0;
-        }
-        m0 = pin0 ? s1 : s0;
-        m1 = pin1 ? s1 : s0;
-    }
-    m0 = m0 < (1u << 25) ? m0 : (1u << 25);
-    m1 = m1 < (1u << 25) ? m1 : (1u << 25);
-    t0 = wave_sum_u32(m0);
-    t1 = wave_sum_u32(m1);
-}
-
-// All kGridThreads threads of the workgroup call this (it synchronises); the result is uniform over the workgroup.  `ok` =
-// false when the row holds a negative value (the caller then takes the literal chain).  `raw`: 2 KiB of LDS per batch of the
-// row (dynamic shared memory of the kernel): the batches are requested once, all at the same time, and every later step reads
-// them from there in rolled loops -- with the batches held in registers and the loops over them unrolled (the first version)
-// the kernel's code no longer fitted the instruction cache and a re-score took as long as one wave alone.
-__device__ float reference_score_coop(const float* sorted_val, int n, int u, int take, CoopShared& sh, uint32_t* __restrict__ raw,
-                                      bool clocks, bool& ok) {
-    typedef uint32_t u32x4u __attribute__((ext_vector_type(4), aligned(4)));
-    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-    typedef float f32x4 __attribute__((ext_vector_type(4)));
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const uint32_t* vals = reinterpret_cast<const uint32_t*>(sorted_val + static_cast<int64_t>(u) * n);
-    const int n_batches = (n + 511) >> 9;
-    const unsigned long long c_begin = clocks ? __builtin_readcyclecounter() : 0ull;
-    // ---- 0. every wave requests its batches (b = wave + 4 q) all at once and parks them in LDS
-    {
-        u32x4 lo[kCoopPerWave], hi[kCoopPerWave];
-#pragma unroll
-        for (int q = 0; q < kCoopPerWave; ++q) {
-            const int b = wave + kCoopWaves * q;
-            int p = 512 * (b < n_batches ? b : 0) + 8 * lane;
-            p = p < n ? p : n;   // eight dwords from here stay inside the table's padding; what lies past the row is masked
-            lo[q] = *reinterpret_cast<const u32x4u*>(vals + p);
-            hi[q] = *reinterpret_cast<const u32x4u*>(vals + p + 4);
-        }
-#pragma unroll
-        for (int q = 0; q < kCoopPerWave; ++q) {
-            const int b = wave + kCoopWaves * q;
-            if (b < n_batches) {
-                *reinterpret_cast<u32x4*>(raw + 512 * b + 8 * lane) = lo[q];
-                *reinterpret_cast<u32x4*>(raw + 512 * b + 8 * lane + 4) = hi[q];
-            }
-        }
-    }
-    if (tid == 0) {
-        sh.flags = 0;
-        sh.next = 1;
-    }
-    auto load_raw = [&](int b, uint32_t (&x)[8]) __attribute__((always_inline)) {
-        const u32x4 lo = *reinterpret_cast<const u32x4*>(raw + 512 * b + 8 * lane), hi = *reinterpret_cast<const u32x4*>(raw + 512 * b + 8 * lane + 4);
-        x[0] = lo.x, x[1] = lo.y, x[2] = lo.z, x[3] = lo.w;
-        x[4] = hi.x, x[5] = hi.y, x[6] = hi.z, x[7] = hi.w;
-    };
-    // the batch's entries as they enter the sum: 0 for removed entries, for what lies past the row and for what lies past
-    // the prefix (`before` live entries precede the batch)
-    auto prepare = [&](int b, int before, uint32_t (&xb)[8]) __attribute__((always_inline)) {
-        uint32_t x[8];
-        load_raw(b, x);
-        const int inside = n - 512 * b - 8 * lane;
-        uint32_t cnt = 0;
-        bool live[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            live[j] = j < inside && x[j] != kGoneBits;
-            xb[j] = live[j] ? x[j] : 0u;
-            cnt += live[j] ? 1u : 0u;
-        }
-        const uint32_t incl = wave_scan_u32(cnt);
-        int room = take - before - static_cast<int>(incl - cnt);   // live entries of this lane that still belong to the prefix
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            if (live[j]) {
-                if (room <= 0) xb[j] = 0u;   // past the prefix: + 0.0 (exact)
-                --room;
-            }
-        }
-    };
-    auto to_significands = [&](const uint32_t (&xb)[8], uint32_t (&M)[8], int (&ex)[8]) __attribute__((always_inline)) {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const uint32_t e = xb[j] >> 23;
-            ex[j] = e != 0u ? static_cast<int>(e) : 1;
-            M[j] = e != 0u ? ((xb[j] & 0x7fffffu) | 0x800000u) : xb[j];
-        }
-    };
-    __syncthreads();
-    // ---- 1. live entries and exact sums per batch
-#pragma nounroll
-    for (int b = wave; b < n_batches; b += kCoopWaves) {
-        uint32_t x[8];
-        load_raw(b, x);
-        const int inside = n - 512 * b - 8 * lane;
-        uint32_t cnt = 0, top = 0;
-        double acc = 0.0;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const bool live = j < inside && x[j] != kGoneBits;
-            const uint32_t v = live ? x[j] : 0u;
-            cnt += live ? 1u : 0u;
-            top = v > top ? v : top;
-            acc += static_cast<double>(__uint_as_float(v));
-        }
-        const unsigned long long neg = __ballot(top > kGoneBits);
-        const double total = wave_sum_d(acc);
-        const uint32_t c = wave_sum_u32(cnt);
-        if (lane == 0) {
-            sh.sum[b] = total;
-            sh.cnt[b] = static_cast<int>(c);
-            if (neg != 0ull) atomicOr(&sh.flags, 1);
-        }
-    }
-    __syncthreads();
-    ok = sh.flags == 0;
-    if (!ok) return 0.0f;   // uniform
-    const unsigned long long c_phase1 = clocks ? __builtin_readcyclecounter() : 0ull;
-    // ---- 2. the prefix over the batches: lane b of every wave holds batch b's numbers (32 batches at most), the prefix is a
-    // DPP scan; where the prefix ends and what kind every batch is follow per lane and travel by ballot / v_readlane
-    const int my_cnt = lane < n_batches ? sh.cnt[lane] : 0;
-    const double my_sum = lane < n_batches ? sh.sum[lane] : 0.0;
-    const int cnt_incl = static_cast<int>(wave_scan_u32(static_cast<uint32_t>(my_cnt)));
-    const double sum_incl = wave_scan_d(my_sum);
-    const int cnt_before = cnt_incl - my_cnt;          // live entries in front of batch `lane`
-    const double e_before = sum_incl - my_sum;         // their exact sum (fp64: far inside the enclosure's margin)
-    const unsigned long long reach = __ballot(lane < n_batches && cnt_incl >= take);
-    const int last = reach != 0ull ? __builtin_ctzll(reach) : n_batches - 1;   // the batch that holds the take-th live entry
-    int my_es = 0, my_kind = 0;
-    if (lane >= 1 && lane <= last && e_before > 0.0 && sum_incl < 1.0e38) {
-        const double lo = e_before * (1.0 - enclosure_margin(512 * lane)), hi = sum_incl * (1.0 + enclosure_margin(512 * (lane + 1)));
-        if (lo >= 7.52316384526264e-37 && hi < 1.7014118346046923e38) {   // 2^-120 .. 2^127
-            const int k_lo = exponent_of(lo), k_hi = exponent_of(hi);
-            my_es = k_lo + 127;
-            my_kind = k_hi == k_lo ? 1 : (k_hi == k_lo + 1 ? 2 : 0);
-        }
-    }
-    // ---- 2b. wave 0 adds batch 0 literally; every wave (wave 0 after that) takes the next batch nobody has taken yet
-    float s = 0.0f;
-    if (wave == 0) {
-        // the head: the sum changes binade every other step at first; chunks of +0.0 add nothing
-        uint32_t xb[8];
-        prepare(0, 0, xb);
-        uint32_t any = 0;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) any |= xb[j];
-        const unsigned long long holds = __ballot(any != 0u);   // lanes 8 k .. 8 k + 7 hold the 64-entry chunk k
-        float* head = sh.head;
-        *reinterpret_cast<f32x4*>(head + 8 * lane) = f32x4{__uint_as_float(xb[0]), __uint_as_float(xb[1]), __uint_as_float(xb[2]), __uint_as_float(xb[3])};
-        *reinterpret_cast<f32x4*>(head + 8 * lane + 4) = f32x4{__uint_as_float(xb[4]), __uint_as_float(xb[5]), __uint_as_float(xb[6]), __uint_as_float(xb[7])};
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-        const f32x4* src = reinterpret_cast<const f32x4*>(head);
-#pragma nounroll
-        for (int k = 0; k < 8; ++k) {
-            if (((holds >> (8 * k)) & 0xffull) == 0ull) continue;
-            f32x4 e[16];
-#pragma unroll
-            for (int i = 0; i < 16; ++i) e[i] = src[16 * k + i];
-#pragma unroll
-            for (int i = 0; i < 16; ++i) s = __fadd_rn(__fadd_rn(__fadd_rn(__fadd_rn(s, e[i].x), e[i].y), e[i].z), e[i].w);
-        }
-    }
-#pragma nounroll
-    for (;;) {
-        int b = 0;
-        if (lane == 0) b = atomicAdd(&sh.next, 1);
-        b = __builtin_amdgcn_readfirstlane(b);
-        if (b > last) break;
-        const int kind = __builtin_amdgcn_readlane(my_kind, b);
-        if (kind == 0) continue;
-        const int es = __builtin_amdgcn_readlane(my_es, b);
-        uint32_t xb[8], M[8];
-        int ex[8];
-        prepare(b, __builtin_amdgcn_readlane(cnt_before, b), xb);
-        to_significands(xb, M, ex);
-        if (kind == 1) {
-            uint32_t t0, t1;
-            batch_totals(M, ex, es, lane, t0, t1);
-            if (lane == 0) {
-                sh.total[b][0] = t0;
-                sh.total[b][1] = t1;
-                sh.win_n[b] = -1;
-            }
-            continue;
-        }
-        // one crossing inside the batch, at 2^K: entries whose sum stays below it for sure (A: unit es), entries that start
-        // above it for sure (B: unit es + 1), and the few in between (the window: added literally by the chain)
-        const double boundary = __longlong_as_double(static_cast<long long>(es - 127 + 1 + 1023) << 52);   // 2^K
-        const double margin = enclosure_margin(512 * (b + 1));
-        double mine = 0.0;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) mine += static_cast<double>(__uint_as_float(xb[j]));
-        double run = readlane_d(e_before, b) + (wave_scan_d(mine) - mine);   // exact sum in front of this lane's first entry
-        uint32_t Ma[8], Mb[8];
-        uint32_t n_win = 0;
-        bool in_win[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const double after = run + static_cast<double>(__uint_as_float(xb[j]));
-            const bool is_a = after * (1.0 + margin) < boundary;
-            const bool is_b = run * (1.0 - margin) >= boundary;
-            in_win[j] = xb[j] != 0u && !is_a && !is_b;
-            Ma[j] = is_a ? M[j] : 0u;
-            Mb[j] = is_b ? M[j] : 0u;
-            n_win += in_win[j] ? 1u : 0u;
-            run = after;
-        }
-        const uint32_t win_incl = wave_scan_u32(n_win);
-        const int win_total = __builtin_amdgcn_readlane(static_cast<int>(win_incl), 63);
-        if (win_total > kCoopWindow) {
-            if (lane == 0) sh.win_n[b] = -2;   // too wide a window: the sequential passes
-            continue;
-        }
-        int at = static_cast<int>(win_incl - n_win);
-#pragma unroll
-        for (int j = 0; j < 8; ++j)
-            if (in_win[j]) sh.win[b][at++] = __uint_as_float(xb[j]);
-        uint32_t t0, t1, u0, u1;
-        batch_totals(Ma, ex, es, lane, t0, t1);
-        batch_totals(Mb, ex, es + 1, lane, u0, u1);
-        if (lane == 0) {
-            sh.total[b][0] = t0;
-            sh.total[b][1] = t1;
-            sh.total_b[b][0] = u0;
-            sh.total_b[b][1] = u1;
-            sh.win_n[b] = win_total;
-        }
-    }
-    const unsigned long long c_mine = clocks ? __builtin_readcyclecounter() : 0ull;
-    __syncthreads();
-    const unsigned long long c_phase2 = clocks ? __builtin_readcyclecounter() : 0ull;
-    // ---- 3. the chain (wave 0): one integer addition per clean batch, a few literal additions per crossing; lane b holds
-    // batch b's numbers
-    if (wave == 0) {
-        unsigned long long n_passes = 0;
-        const bool mine = lane >= 1 && lane <= last && my_kind != 0;
-        const int my_win = mine ? sh.win_n[lane] : -2;
-        const uint32_t ta0 = mine ? sh.total[lane][0] : 0u, ta1 = mine ? sh.total[lane][1] : 0u;
-        const uint32_t tb0 = (mine && my_win >= 0) ? sh.total_b[lane][0] : 0u, tb1 = (mine && my_win >= 0) ? sh.total_b[lane][1] : 0u;
-        float w[kCoopWindow];   // lane b: the window entries of batch b
-#pragma unroll
-        for (int k = 0; k < kCoopWindow; ++k) w[k] = (mine && k < my_win) ? sh.win[lane][k] : 0.0f;
-#pragma nounroll
-        for (int b = 1; b <= last; ++b) {
-            const float s_in = s;
-            const int win = __builtin_amdgcn_readlane(my_win, b);     // -1 clean, >= 0 split with that many window entries, -2 sequential
-            bool done = false;
-            if (clocks && lane == 0) {
-                const int kind_b = __builtin_amdgcn_readlane(my_kind, b);
-                atomicAdd(&g_coop_stats[win == -1 ? 1 : (win >= 0 ? 2 : (kind_b == 2 ? 3 : 0))], 1ull);
-            }
-            if (win != -2) {
-                uint32_t sbits = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(__float_as_uint(s))));
-                const int es = __builtin_amdgcn_readlane(my_es, b);
-                uint32_t I = (sbits & 0x7fffffu) | 0x800000u;
-                uint32_t t = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>((I & 1u) ? ta1 : ta0), b));
-                if (static_cast<int>(sbits >> 23) == es && I + t < (1u << 24)) {
-                    s = __uint_as_float((static_cast<uint32_t>(es) << 23) | ((I + t) & 0x7fffffu));
-                    done = true;
-                    if (win >= 0) {
-#pragma unroll
-                        for (int k = 0; k < kCoopWindow; ++k)   // (entries past the window are + 0.0: exact)
-                            s = __fadd_rn(s, __int_as_float(__builtin_amdgcn_readlane(__float_as_int(w[k]), b)));
-                        sbits = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(__float_as_uint(s))));
-                        I = (sbits & 0x7fffffu) | 0x800000u;
-                        const uint32_t u0 = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(tb0), b));
-                        const uint32_t u1 = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(tb1), b));
-                        t = (I & 1u) ? u1 : u0;
-                        if ((u0 | u1) == 0u) {
-                            // nothing behind the window (the crossing sits at the batch's end, or not in it after all)
-                        } else if (static_cast<int>(sbits >> 23) == es + 1 && I + t < (1u << 24)) {
-                            s = __uint_as_float((static_cast<uint32_t>(es + 1) << 23) | ((I + t) & 0x7fffffu));
-                        } else {
-                            done = false;
-                        }
-                    }
-                }
-            }
-            if (!done) {
-                // the sequential passes over the whole batch from the sum in front of it (more than one crossing, anything the
-                // enclosure could not promise, and every failed check above)
-                if (clocks && lane == 0 && win != -2) atomicAdd(&g_coop_stats[win == -1 ? 4 : 5], 1ull);
-                s = s_in;
-                uint32_t xb[8], M[8];
-                int ex[8];
-                prepare(b, __builtin_amdgcn_readlane(cnt_before, b), xb);
-                to_significands(xb, M, ex);
-                s = integer_passes(M, ex, s, lane, n_passes);
-            }
-        }
-        if (lane == 0) sh.result = s;
-        if (clocks && lane == 0) {
-            atomicAdd(&g_rescore_clock[1], static_cast<unsigned long long>(last + 1));
-            atomicAdd(&g_rescore_clock[2], n_passes);
-            atomicAdd(&g_rescore_clock[4], c_phase1 - c_begin);                    // loads + counts + sums, first two barriers
-            atomicAdd(&g_rescore_clock[5], c_mine - c_phase1);                     // wave 0's own work (the head)
-            atomicAdd(&g_rescore_clock[6], c_phase2 - c_mine);                     // waiting for the other waves
-            atomicAdd(&g_rescore_clock[7], __builtin_readcyclecounter() - c_phase2);   // the chain
-        }
-    }
-    __syncthreads();
-    return sh.result;
-}
-
 struct GridDecision {
     int mode;        // 0 winner known, 1 round 2, 2 no candidate, 3 exchange timed out
     int winner;
@@ -1226,11 +808,8 @@ __global__ __launch_bounds__(kGridThreads) void bulyan_grid_kernel(
     const uint16_t* __restrict__ sorted_idx, const uint16_t* __restrict__ rank_t, float* sorted_val,
     const double* __restrict__ row_total, const double* __restrict__ row_top, const int32_t* __restrict__ cls,
     unsigned long long* __restrict__ xchg, float band_scale, int32_t* __restrict__ selection,
-    int32_t* __restrict__ status, int32_t* __restrict__ rescored, int rescore_mode, int head_chunks, int coop_min_take,
-    int coop_max_lead) {
+    int32_t* __restrict__ status, int32_t* __restrict__ rescored, int rescore_mode, int head_chunks) {
     __shared__ __attribute__((aligned(16))) float rescore_stage[kGridThreads / 64][512];
-    __shared__ CoopShared coop;
-    extern __shared__ __attribute__((aligned(16))) unsigned char coop_raw[];   // 2 KiB per 512-entry batch of a row
     __shared__ Candidate slots[kGridThreads / 64];
     __shared__ double second_slots[kGridThreads / 64];
     __shared__ uint32_t removed[kMaxSelectRows / 32];
@@ -1366,28 +945,6 @@ __global__ __launch_bounds__(kGridThreads) void bulyan_grid_kernel(
             __syncthreads();
             const int n_lead = n_leaders;
             Candidate r{static_cast<double>(kKrumInit), 0x7fffffff, -1};
-            // ONE contender in this workgroup and a long prefix: all four waves on it (reference_score_coop: 2.1x sooner than one
-            // wave); several contenders, or a short prefix: one wave per contender, as before (the waves are busy either way)
-            const bool together = marked && coop_min_take > 0 && take >= coop_min_take && n_lead <= coop_max_lead;   // uniform
-            if (together) {
-                for (int k = 0; k < n_lead; ++k) {
-                    const int row = wg * kGridThreads + leaders[k];
-                    const unsigned long long c0 = rescore_mode >= 2 ? __builtin_readcyclecounter() : 0ull;
-                    bool done = false;
-                    float s32 = reference_score_coop(sorted_val, n, row, take, coop, reinterpret_cast<uint32_t*>(coop_raw), rescore_mode >= 2, done);
-                    if (!done && wave == 0)   // (a sign bit on a live entry: the literal chain, by one wave)
-                        s32 = reference_score_plain(sorted_val, sorted_idx, removed, n, row, take, lane, rescore_stage[0]);
-                    if (rescore_mode >= 2 && tid == 0) {
-                        atomicAdd(&g_rescore_clock[0], 1ull);
-                        atomicAdd(&g_rescore_clock[3], __builtin_readcyclecounter() - c0);
-                    }
-                    if (wave == 0 && s32 < kKrumInit) {
-                        Candidate o{static_cast<double>(s32), visit_position(row), row};
-                        if (better(o, r)) r = o;
-                    }
-                    __syncthreads();   // rescore_stage[0] and the shared record are reused by the next contender
-                }
-            } else
             for (int k = wave; k < n_lead; k += kGridThreads / 64) {
                 const int row = wg * kGridThreads + leaders[k];
                 float s32 = 0.0f;
@@ -1546,19 +1103,12 @@ int launch_bulyan_loop(byz_ctx* ctx, const float* dist, int64_t n, int64_t theta
     // 64-entry chunks of a re-score that go through the literal chain before the passes take over (measured, N = 4000 / 10,000
     // scaled / 10,000 attack: 1 chunk 32.7 / 163 / 95.7 ms, 4 chunks 30.9 / 158 / 95.8, 8 chunks 30.4 / 157 / 94.1)
     const int head_chunks = 8;
-    // BYZ_BULYAN_COOP: shortest prefix that all four waves of a workgroup re-score together (reference_score_coop); 0 = never
-    // (one wave per contender: round 3's form, the comparison)
-    int coop_min_take = 1024;
-    if (const char* e = std::getenv("BYZ_BULYAN_COOP")) coop_min_take = std::atoi(e);
-    int coop_max_lead = 1;   // contenders of one workgroup that are still re-scored together, one after the other
-    if (const char* e = std::getenv("BYZ_BULYAN_COOP_MAX")) coop_max_lead = std::atoi(e);
     const char* clocks_env = std::getenv("BYZ_BULYAN_CLOCKS");
     const bool clocks = rescore_mode != 0 && clocks_env != nullptr && std::atoi(clocks_env) != 0;
     if (clocks) {
         rescore_mode += 1;
         const unsigned long long zero[8] = {0};
         BYZ_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_rescore_clock), zero, sizeof(zero)));
-        BYZ_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_coop_stats), zero, sizeof(zero)));
     }
     BYZ_HIP(hipMemsetAsync(ctx->xchg.ptr, 0, static_cast<size_t>(2 * 3 * kGridMaxWgs) * sizeof(unsigned long long), stream));
     BYZ_HIP(hipMemsetAsync(status_dev, 0, 2 * sizeof(int32_t), stream));
@@ -1568,27 +1118,18 @@ int launch_bulyan_loop(byz_ctx* ctx, const float* dist, int64_t n, int64_t theta
     twin_class_fix_kernel<<<static_cast<unsigned>(ceil_div(n, 256)), 256, 0, stream>>>(cls_tmp, (int)n, cls);
     BYZ_TRY(check_launch("twin_class_fix_kernel"));
     const unsigned n_wgs = static_cast<unsigned>(ceil_div(n, kGridThreads));   // <= 64: all resident, they wait for each other
-    const size_t raw_bytes = static_cast<size_t>(ceil_div(n, 512)) * 2048;
-    BYZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&bulyan_grid_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                static_cast<int>(raw_bytes)));
-    bulyan_grid_kernel<<<n_wgs, kGridThreads, raw_bytes, stream>>>(
+    bulyan_grid_kernel<<<n_wgs, kGridThreads, 0, stream>>>(
         dist, (int)n, (int)theta, (int)drop_count, (int)users_count, (int)corrupted, ctx->sorted_idx.as<uint16_t>(),
         ctx->rank_t.as<uint16_t>(), ctx->sorted_val.as<float>(), ctx->row_total.as<double>(), ctx->row_top.as<double>(), cls,
-        ctx->xchg.as<unsigned long long>(), band_scale, selection_dev, status_dev, status_dev + 1, rescore_mode, head_chunks,
-        coop_min_take, coop_max_lead);
+        ctx->xchg.as<unsigned long long>(), band_scale, selection_dev, status_dev, status_dev + 1, rescore_mode, head_chunks);
     BYZ_TRY(check_launch("bulyan_grid_kernel"));
     if (clocks) {
         unsigned long long c[8];
         BYZ_HIP(hipStreamSynchronize(stream));
         BYZ_HIP(hipMemcpyFromSymbol(c, HIP_SYMBOL(g_rescore_clock), sizeof(c)));
         const double r = c[0] ? static_cast<double>(c[0]) : 1.0;
-        std::fprintf(stderr, "bulyan re-scores: %llu; per re-score: %.1f batches, %.1f integer passes, %.0f cycles (%.0f inside the passes / "
-                     "cooperative: %.0f until the sums are out, %.0f wave 0's batches, %.0f waiting for the others, %.0f the chain)\n",
-                     c[0], c[1] / r, c[2] / r, c[3] / r, c[4] / r, c[4] / r, c[5] / r, c[6] / r, c[7] / r);
-        unsigned long long k[8];
-        BYZ_HIP(hipMemcpyFromSymbol(k, HIP_SYMBOL(g_coop_stats), sizeof(k)));
-        std::fprintf(stderr, "  cooperative batches per re-score: %.2f sequential by enclosure, %.2f clean, %.2f split, %.2f window too wide; "
-                     "failed checks: %.3f clean, %.3f split\n", k[0] / r, k[1] / r, k[2] / r, k[3] / r, k[4] / r, k[5] / r);
+        std::fprintf(stderr, "bulyan re-scores: %llu; per re-score: %.1f batches, %.1f integer passes, %.0f cycles (%.0f inside the passes)\n",
+                     c[0], c[1] / r, c[2] / r, c[3] / r, c[4] / r);
     }
     return BYZ_OK;
 }

@@ -167,52 +167,3 @@ def test_collect_gradients_writes_all_device_clients_in_one_launch(eng, golden):
         eng.assemble_rows(gm.data, 0, [users[0].grads, users[1].grads[:-1]])
     with pytest.raises(ValueError):
         eng.assemble_rows(gm.data, 7, [users[0].grads] * 3)      # rows 7..9 of a 9-row matrix
-
-
-@pytest.mark.parametrize('n,family', [(1500, 'lattice'), (3000, 'lattice'), (2500, 'points'), (4000, 'points'), (3000, 'ties'),
-                                      (2049, 'zeros'), (2000, 'negative'), (2000, 'inf'), (5000, 'points')])
-def test_bulyan_cooperative_rescore_is_the_sequential_one(eng, monkeypatch, n, family):
-    """reference_score_coop (round 4): all four waves of a workgroup on its one contender -- batch units predicted from
-    enclosures of the running sum, clean and split batches totalled in advance, a chain of integer additions.  Forced on for
-    every re-score (BYZ_BULYAN_COOP=1, BYZ_BULYAN_COOP_MAX=99), switched off (BYZ_BULYAN_COOP=0: one wave per contender,
-    round 3's form) and against the literal chain (BYZ_BULYAN_RESCORE=plain): the same selection pick for pick, and the C
-    oracle's -- on round-to-even ties at every other addition, live zeros, negative entries (handed back to the chain),
-    clients at an infinite distance, and prefixes of up to 3800 entries."""
-    import sys, os
-    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
-    from test_gpu_scale import MAL_PROP, check_selection, lattice_distances, point_distances as scale_points
-    f = int(n * MAL_PROP)
-    if family == 'lattice':
-        dist = lattice_distances(4700 + n, n)
-    elif family == 'ties':
-        dist = scale_points(4700 + n, n, identical=f)
-    else:
-        dist = scale_points(4700 + n, n)
-        if family == 'zeros':
-            grp = np.arange(n) // 3
-            dist[grp[:, None] == grp[None, :]] = 0.0
-            np.fill_diagonal(dist, np.inf)
-        elif family == 'inf':
-            for bad in (17, 300, n - 2):
-                dist[bad, :] = np.inf
-                dist[:, bad] = np.inf
-            np.fill_diagonal(dist, np.inf)
-        elif family == 'negative':
-            dist[5, 9] = dist[9, 5] = -0.25
-            dist[40, 41] = dist[41, 40] = -0.0
-    monkeypatch.setenv('BYZ_BULYAN_COOP', '0')
-    alone = eng.bulyan_select(dist, n, f).tolist()
-    rescored = eng.bulyan_rescored()
-    monkeypatch.setenv('BYZ_BULYAN_COOP', '1')
-    monkeypatch.setenv('BYZ_BULYAN_COOP_MAX', '99')
-    together = eng.bulyan_select(dist, n, f).tolist()
-    assert eng.bulyan_rescored() == rescored
-    assert together == alone, 'first difference at pick %d' % next(i for i, (a, b) in enumerate(zip(together, alone)) if a != b)
-    monkeypatch.delenv('BYZ_BULYAN_COOP')
-    monkeypatch.delenv('BYZ_BULYAN_COOP_MAX')
-    assert eng.bulyan_select(dist, n, f).tolist() == alone          # the default policy (one contender, long prefixes)
-    monkeypatch.setenv('BYZ_BULYAN_RESCORE', 'plain')
-    assert eng.bulyan_select(dist, n, f).tolist() == alone
-    monkeypatch.delenv('BYZ_BULYAN_RESCORE')
-    if family != 'negative':
-        check_selection(dist, n, f, together)
