@@ -1,4 +1,4 @@
-"""Prototype of the PARALLEL form of the exact sequential fp32 sum (round 4; the GPU's cooperative re-score, csrc/select.hip).
+"""Prototype of the PARALLEL form of the exact sequential fp32 sum (round 4; its GPU form -- a cooperative re-score by all four waves of a workgroup -- was built, exact, and removed: profiles/r04r_bulyan_cooperative_rescore.txt).
 
 The integer passes of seqsum_int.py are sequential only because a batch needs the unit (binade) of the running sum it starts
 from.  But the running sum is known in advance to within its rounding error: with E_j the exact sum of the first j entries

@@ -1,4 +1,4 @@
-"""Prototype of the multi-segment form of the parallel sequential sum (csrc/select.hip reference_score_coop, second version):
+"""Prototype of the multi-segment form of the parallel sequential sum (the second version of the GPU's cooperative re-score; built, exact, removed: profiles/r04r_bulyan_cooperative_rescore.txt):
 the head is the first NON-EMPTY batch; inside every later batch each entry whose partial sums before and after it lie in one
 binade for sure belongs to that binade's segment (up to 4 segments per batch), the entries in between are windows (<= 8 each),
 added literally by the chain."""

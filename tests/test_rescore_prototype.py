@@ -65,8 +65,9 @@ def test_four_wave_composition_reproduces_it_too(proto):
 
 @pytest.fixture(scope='module')
 def proto_pred():
-    """scripts/proto/seqsum_pred.py: the PARALLEL form (round 4; csrc/select.hip reference_score_coop): batch units predicted
-    from rigorous enclosures of the running sum, totals per batch in advance, a chain of integer additions."""
+    """scripts/proto/seqsum_pred.py: the PARALLEL form (round 4): batch units predicted from rigorous enclosures of the running
+    sum, totals per batch in advance, a chain of integer additions.  Its GPU form was built, exact and removed again (3-6% of the
+    loop: profiles/r04r_bulyan_cooperative_rescore.txt); the prototype stays as the statement of the method."""
     import sys
     sys.path.insert(0, os.path.join(ROOT, 'scripts', 'proto'))
     spec = importlib.util.spec_from_file_location('seqsum_pred', os.path.join(ROOT, 'scripts', 'proto', 'seqsum_pred.py'))
