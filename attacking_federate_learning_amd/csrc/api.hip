@@ -173,6 +173,8 @@ void byz_ctx_destroy(byz_ctx* ctx) {
     (void)hipSetDevice(ctx->device);
     (void)hipDeviceSynchronize();
     byz_timing_reset(ctx);
+    ctx->assemble_table.release();
+    if (ctx->assemble_copied != nullptr) (void)hipEventDestroy(ctx->assemble_copied);
     ctx->gram_partials.release();
     ctx->gram.release();
     ctx->tile_order.release();

@@ -138,6 +138,8 @@ struct byz_ctx {
     byz::Buffer small;           // misc device scalars (winner index, status words)
     bool small_configured = false;   // krum_small.hip: dynamic-LDS attributes set for this context's device
     byz::Buffer assemble_table;  // byz_assemble_rows_dev: segment starts + every client's tensor pointers
+    std::vector<int64_t> assemble_host;   // its host image: owned by the context, because an async copy out of pageable memory
+    hipEvent_t assemble_copied = nullptr; // may still be reading it when the call returns; recorded behind that copy
     byz::Buffer stage_in;        // device copy of a host matrix
     byz::Buffer stage_out;       // device result before download
     byz::PinnedBuffer pinned;    // host bounce buffer for small results

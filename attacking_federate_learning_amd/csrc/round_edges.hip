@@ -219,7 +219,13 @@ static int assemble(byz_ctx* ctx, float* dst, int64_t rows, int64_t ld, int64_t 
 int launch_assemble_rows(byz_ctx* ctx, float* G, int64_t n_cols, int64_t ld, int64_t n_clients, int64_t n_segments,
                          const float* const* segments, const int64_t* lengths, hipStream_t stream) {
     BYZ_REQUIRE(n_clients <= 65535 && n_segments <= 65535, "assemble_rows: at most 65535 clients and tensors per call");
-    std::vector<int64_t> table(static_cast<size_t>(n_segments + 1 + n_clients * n_segments));
+    // The table's host image belongs to the context: hipMemcpyAsync out of pageable memory may pin the pages and copy later
+    // (large tables: thousands of clients), so the source must outlive this call; the event behind the copy says when the
+    // image may be rewritten.
+    if (ctx->assemble_copied == nullptr) BYZ_HIP(hipEventCreateWithFlags(&ctx->assemble_copied, hipEventDisableTiming));
+    else BYZ_HIP(hipEventSynchronize(ctx->assemble_copied));
+    std::vector<int64_t>& table = ctx->assemble_host;
+    table.assign(static_cast<size_t>(n_segments + 1 + n_clients * n_segments), 0);
     int64_t total = 0, longest = 1;
     for (int64_t s = 0; s < n_segments; ++s) {
         BYZ_REQUIRE(lengths[s] >= 0, "assemble_rows: bad length of tensor %lld", (long long)s);
@@ -236,8 +242,8 @@ int launch_assemble_rows(byz_ctx* ctx, float* G, int64_t n_cols, int64_t ld, int
         table[static_cast<size_t>(n_segments + 1 + k)] = static_cast<int64_t>(reinterpret_cast<uintptr_t>(segments[k]));
     }
     BYZ_TRY(ctx->assemble_table.ensure(table.size() * sizeof(int64_t)));
-    // (pageable source: the runtime stages it before the call returns, `table` may go out of scope)
     BYZ_HIP(hipMemcpyAsync(ctx->assemble_table.ptr, table.data(), table.size() * sizeof(int64_t), hipMemcpyHostToDevice, stream));
+    BYZ_HIP(hipEventRecord(ctx->assemble_copied, stream));
     KernelTimer t(ctx, BYZ_K_MISC, stream);
     int64_t blocks = ceil_div(longest, static_cast<int64_t>(kThreads) * 4);
     const int64_t cap = 64;     // n_clients x n_segments workgroup columns already fill the chip; the kernel strides
