@@ -45,6 +45,7 @@ _PROTOTYPES = {
     'byz_trimmed_mean_dev': [c_vp, c_vp, c_i64, c_i64, c_i64, c_vp, c_i64, c_vp, c_vp],
     'byz_trimmed_mean_redone': [c_vp, _P(c_i64), c_vp],
     'byz_bulyan_select_dev': [c_vp, c_vp, c_i64, c_i64, c_i64, c_vp, c_vp],
+    'byz_krum_bulyan_select_dev': [c_vp, c_vp, c_i64, c_i64, c_i64, _P(c_i32), c_vp, c_vp],
     'byz_bulyan_dev': [c_vp, c_vp, c_i64, c_i64, c_i64, c_i64, c_i64, c_vp, c_vp, c_vp],
     'byz_drift_attack_dev': [c_vp, c_vp, c_i64, c_i64, c_i64, c_f32, c_vp, c_vp, c_vp, c_int, c_vp],
     'byz_drift_axpy_dev': [c_vp, c_vp, c_vp, c_i64, c_f32, c_vp],

@@ -96,8 +96,11 @@ int krum_select(byz_ctx* ctx, const float* dist, int64_t n, int64_t users_count,
     return BYZ_OK;
 }
 
+// krum_winner_dev != nullptr: the same row sort also forms the Krum scores of defences.py:33-34 (prefix users_count - corrupted
+// of the full rows) and the Krum index goes to krum_winner_dev: configs[4]'s round runs Krum and Bulyan on ONE distance matrix,
+// and a second sort of its 10,000 rows costs 7 ms
 int bulyan_select(byz_ctx* ctx, const float* dist, int64_t n, int64_t users_count, int64_t corrupted,
-                  int32_t* selection_dev, hipStream_t stream) {
+                  int32_t* selection_dev, hipStream_t stream, int32_t* krum_winner_dev = nullptr) {
     const int64_t theta = users_count - 2 * corrupted;
     if (theta < 0 || theta > n) {
         set_error("bulyan: selection size %lld does not fit %lld rows", (long long)theta, (long long)n);
@@ -109,7 +112,9 @@ int bulyan_select(byz_ctx* ctx, const float* dist, int64_t n, int64_t users_coun
     int64_t drop = (n - 1) - users_count + corrupted;
     if (drop < 0) drop = 0;
     if (drop > n - 1) drop = n - 1;
-    BYZ_TRY(launch_row_sort(ctx, dist, n, 0, drop, true, stream));
+    const int64_t krum_prefix = krum_winner_dev != nullptr ? python_prefix_len(n - 1, users_count - corrupted) : 0;
+    BYZ_TRY(launch_row_sort(ctx, dist, n, krum_prefix, drop, true, stream));
+    if (krum_winner_dev != nullptr) BYZ_TRY(launch_krum_argmin(ctx, n, krum_winner_dev, stream));
     int32_t* status_dev = ctx->small.as<int32_t>() + 8;
     BYZ_TRY(launch_bulyan_loop(ctx, dist, n, theta, drop, users_count, corrupted, selection_dev, status_dev, stream));
     int32_t words[32];
@@ -448,6 +453,18 @@ int byz_bulyan_select_dev(byz_ctx* ctx, const float* dist, int64_t n_rows, int64
     BYZ_TRY(enter(ctx));
     BYZ_REQUIRE(dist && selection && n_rows > 0, "bulyan_select: bad arguments");
     return bulyan_select(ctx, dist, n_rows, users_count, corrupted_count, selection, as_stream(stream));
+}
+
+int byz_krum_bulyan_select_dev(byz_ctx* ctx, const float* dist, int64_t n_rows, int64_t users_count,
+                               int64_t corrupted_count, int32_t* krum_index_host, int32_t* selection, void* stream) {
+    BYZ_TRY(enter(ctx));
+    BYZ_REQUIRE(dist && selection && krum_index_host && n_rows > 0, "krum_bulyan_select: bad arguments");
+    hipStream_t s = as_stream(stream);
+    BYZ_TRY(bulyan_select(ctx, dist, n_rows, users_count, corrupted_count, selection, s, ctx->small.as<int32_t>()));
+    int32_t words[32];
+    BYZ_TRY(read_small(ctx, words, s));
+    *krum_index_host = words[0];
+    return BYZ_OK;
 }
 
 int byz_bulyan_dev(byz_ctx* ctx, const float* G, int64_t n_rows, int64_t n_cols, int64_t ld, int64_t users_count,

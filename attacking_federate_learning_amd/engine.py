@@ -493,6 +493,24 @@ class Engine:
         picked = sel.numpy()[:theta]
         return picked if keys is None else np.asarray([keys[i] for i in picked], dtype=np.int32)
 
+    def krum_bulyan_select(self, distances, users_count, corrupted_count, on_device=False):
+        """(Krum index, Bulyan selection) from ONE distance matrix with one sort of its rows -- what a round that runs both
+        defences on the same distances needs (BASELINE configs[4]); the same values `krum_select` and `bulyan_select` return."""
+        d, keys = self._as_distances(distances)
+        theta = int(users_count) - 2 * int(corrupted_count)
+        sel = DeviceBuffer(self, (max(theta, 1),), np.int32)
+        idx = ctypes.c_int32(-2)
+        _check(self.lib.byz_krum_bulyan_select_dev(self.ctx, _vp(d.ptr), d.n, int(users_count), int(corrupted_count),
+                                                   ctypes.byref(idx), _vp(sel.ptr), None))
+        index = int(idx.value)
+        index = index if (keys is None or index < 0) else keys[index]
+        if on_device and keys is None:
+            sel.shape = (theta,)
+            sel.nbytes = theta * 4
+            return index, sel
+        picked = sel.numpy()[:theta]
+        return index, (picked if keys is None else np.asarray([keys[i] for i in picked], dtype=np.int32))
+
     def bulyan_rescored(self):
         """Rows the last Bulyan loop re-scored with the reference's sequential fp32 sums (0: every pick was clear)."""
         rows = ctypes.c_int64(0)

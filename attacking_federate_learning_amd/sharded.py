@@ -70,6 +70,9 @@ class HipKernels:
     def bulyan_select(self, dist, users_count, corrupted_count, on_device=False):
         return self.engine.bulyan_select(dist, users_count, corrupted_count, on_device=on_device)
 
+    def krum_bulyan_select(self, dist, users_count, corrupted_count, on_device=False):
+        return self.engine.krum_bulyan_select(dist, users_count, corrupted_count, on_device=on_device)
+
     def trimmed_mean(self, g_local, corrupted_count, row_index=None):
         # row_index comes from this package (a selection the kernels produced): no bounds re-check, no host sync
         return self.engine.trimmed_mean(g_local, g_local.shape[0], corrupted_count, row_index=row_index,

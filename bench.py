@@ -232,8 +232,8 @@ class BulyanSharded(Workload):
             if self.with_attack:
                 self.agg.drift_attack_clients(self.g, self.rows_per_rank, self.f, 1.5, write_back=not self.distinct)
                 dist_m = self.agg.client_distances(self.g, self.rows_per_rank)
-                idx = self.agg.kernels.krum_select(dist_m, self.n, self.f)
-                sel = np.asarray(self.agg.kernels.bulyan_select(dist_m, self.n, self.f), dtype=np.int64)
+                idx, sel = self.agg.kernels.krum_bulyan_select(dist_m, self.n, self.f)    # one sort of the rows for both
+                sel = np.asarray(sel, dtype=np.int64)
                 cols, row_index = self.agg.reshard_rows_to_columns(self.g, self.rows_per_rank, sel)
                 out = self.agg.kernels.trimmed_mean(cols, 2 * self.f, row_index=row_index)
                 self.last = (self.agg._maybe_gather(out, True, total=self.d_total), sel, idx)
@@ -244,8 +244,8 @@ class BulyanSharded(Workload):
             # rows 0..m-1 are the malicious clients (reference main.py:28); per column, no exchange
             self.agg.drift_attack(self.g, self.f, 1.5, write_back=not self.distinct)
             dist_m = self.agg.global_distances(self.g)
-            idx = self.agg.kernels.krum_select(dist_m, self.n, self.f)
-            sel = self.agg.kernels.bulyan_select(dist_m, self.n, self.f, on_device=True)   # stays on the device
+            # Krum's index and Bulyan's selection from the one distance matrix, one sort of its rows; the selection stays on the device
+            idx, sel = self.agg.kernels.krum_bulyan_select(dist_m, self.n, self.f, on_device=True)
             out = self.agg.kernels.trimmed_mean(self.g, 2 * self.f, row_index=sel)
             self.last = (self.agg._maybe_gather(out, True, total=self.d_total), sel, idx)
         else:

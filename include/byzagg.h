@@ -150,6 +150,12 @@ int byz_trimmed_mean_redone(byz_ctx* ctx, int64_t* tiles_host, void* stream);
 /* selection_dev: theta int32 indices in selection order.                                   */
 int byz_bulyan_select_dev(byz_ctx* ctx, const float* dist_dev, int64_t n_rows, int64_t users_count,
                           int64_t corrupted_count, int32_t* selection_dev, void* stream);
+/* Krum's index AND Bulyan's selection from one distance matrix with ONE sort of its rows (BASELINE       */
+/* configs[4] runs both defences on the same distances): *krum_index_host as byz_krum_select_dev gives it, */
+/* selection_dev as byz_bulyan_select_dev.                                                                  */
+int byz_krum_bulyan_select_dev(byz_ctx* ctx, const float* dist_dev, int64_t n_rows, int64_t users_count,
+                               int64_t corrupted_count, int32_t* krum_index_host, int32_t* selection_dev,
+                               void* stream);
 /* Rows the last selection loop had to re-score in the reference's sequential fp32 arithmetic because   */
 /* their exact scores lay within that arithmetic's rounding band (0 for well separated clients).        */
 int byz_bulyan_rescored(const byz_ctx* ctx, int64_t* rows_host);

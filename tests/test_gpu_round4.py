@@ -167,3 +167,20 @@ def test_collect_gradients_writes_all_device_clients_in_one_launch(eng, golden):
         eng.assemble_rows(gm.data, 0, [users[0].grads, users[1].grads[:-1]])
     with pytest.raises(ValueError):
         eng.assemble_rows(gm.data, 7, [users[0].grads] * 3)      # rows 7..9 of a 9-row matrix
+
+
+@pytest.mark.parametrize('n,identical', [(40, 0), (200, 0), (700, 168), (3000, 0), (4000, 960)])
+def test_krum_and_bulyan_from_one_row_sort(eng, n, identical):
+    """byz_krum_bulyan_select_dev: Krum's index and Bulyan's selection from one distance matrix with ONE sort of its rows
+    (BASELINE configs[4] runs both on the same distances): the values the two separate calls return, and the C oracle's."""
+    import os, sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from test_gpu_scale import check_selection, point_distances as scale_points
+    f = int(0.24 * n)
+    dist = scale_points(5100 + n, n, identical=identical)
+    idx, sel = eng.krum_bulyan_select(dist, n, f)
+    assert idx == eng.krum_select(dist, n, f) == scale.krum_pick(dist, n, f)
+    assert list(sel) == list(eng.bulyan_select(dist, n, f))
+    check_selection(dist, n, f, list(sel))
+    idx2, sel_dev = eng.krum_bulyan_select(eng.pairwise_distances(np.random.default_rng(n).standard_normal((n, 64)).astype(np.float32)), n, f, on_device=True)
+    assert len(sel_dev.numpy()) == n - 2 * f and 0 <= idx2 < n
