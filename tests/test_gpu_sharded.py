@@ -155,7 +155,9 @@ def check_against_unsharded(torch, want, got, label, g=None):
     assert torch.allclose(out_g, out_w, rtol=1e-5, atol=1e-5), '%s: max |d| = %.3e' % (label, float((out_g - out_w).abs().max()))
 
 
-@pytest.mark.parametrize('n,d,world', [(1200, 24641, 3), (3000, 3 * 16400 + 1, 3), (640, 9000, 8)])
+# (the last two: BASELINE's own client counts -- configs[3] N = 4000 and configs[4] N = 10,000 -- at a width the box holds)
+@pytest.mark.parametrize('n,d,world', [(1200, 24641, 3), (3000, 3 * 16400 + 1, 3), (640, 9000, 8), (4000, 2 * 16400 + 3, 2),
+                                       (10000, 20001, 8)])
 def test_columns_layout_looped_over_the_shards_equals_one_gpu(eng, torch, n, d, world):
     """columns layout, rank by rank: uneven slices (widths differ by one) with the 16-byte row pitch of
     `reshard_rows_to_columns`, the Gram all-reduce as a sum on the device, the near-pair exchange as a sum of the per-slice
@@ -191,7 +193,8 @@ def test_columns_layout_looped_over_the_shards_equals_one_gpu(eng, torch, n, d, 
     check_against_unsharded(torch, want, got, 'columns W=%d' % world, g)
 
 
-@pytest.mark.parametrize('n,d,world,panel_cols', [(1200, 24640, 3, 8192), (3000, 2 * 16400, 2, 16400), (520, 6000, 8, 2048)])
+@pytest.mark.parametrize('n,d,world,panel_cols', [(1200, 24640, 3, 8192), (3000, 2 * 16400, 2, 16400), (520, 6000, 8, 2048),
+                                                  (4000, 2 * 16400, 4, 16400)])
 def test_clients_layout_looped_over_the_shards_equals_one_gpu(eng, torch, n, d, world, panel_cols):
     """clients layout, rank by rank: uneven row shares gathered panel by panel into a padded (W n_max)-row buffer, every
     rank's share of the panel's Gram tiles through the row indirection, all shares and panels summed (the all-reduce), the
