@@ -135,7 +135,7 @@ def unsharded(eng, torch, g, n, f):
     return dist, out.cpu(), sel.cpu().numpy().tolist(), idx
 
 
-def check_against_unsharded(torch, want, got, label, g=None):
+def check_against_unsharded(torch, want, got, label, g=None, f=None):
     dist_w, out_w, sel_w, idx_w = want
     dist_g, out_g, sel_g, idx_g = got
     n = dist_w.shape[0]
@@ -150,6 +150,25 @@ def check_against_unsharded(torch, want, got, label, g=None):
     assert float(rel.max()) < 2e-6, '%s: distances differ by %.2e relative at (%d, %d): sharded %.9g, one GPU %.9g, fp64 %.9g' % (
         label, float(rel.max()), wi, wj, float(dist_g[wi, wj]), float(dist_w[wi, wj]), truth)
     assert idx_g == idx_w, label
+    if sel_g != sel_w and f is not None:
+        # N = 10,000: 5200 picks among scores ~5e-5 apart -- the two paths' distances agree to 2e-6 (different column splits,
+        # different Gram arithmetic per slice), so a decision between two scores closer than that may fall either way.  The
+        # first differing pick must BE such a decision (fp64 Krum scores of both candidates on the one-GPU distances, rows
+        # picked so far removed: defences.py:26-37, :59-68); nothing behind it is comparable.
+        p = next(i for i, (a, b) in enumerate(zip(sel_g, sel_w)) if a != b)
+        present = np.ones(n, dtype=bool)
+        present[sel_w[:p]] = False
+        d64 = dist_w.numpy().astype(np.float64)
+
+        def score(row):
+            others = present.copy()
+            others[row] = False
+            return np.sort(d64[row, others])[:int(present.sum()) - f].sum()
+        a, b = score(sel_g[p]), score(sel_w[p])
+        assert abs(a - b) <= 4e-6 * max(a, b), '%s: pick %d differs (%d / %d) and is no near-tie: scores %.12g / %.12g' % (
+            label, p, sel_g[p], sel_w[p], a, b)
+        assert p > n // 20, '%s: the selections part at pick %d already' % (label, p)
+        return
     assert sel_g == sel_w, '%s: selections differ first at pick %d' % (
         label, next(i for i, (a, b) in enumerate(zip(sel_g, sel_w)) if a != b))
     assert torch.allclose(out_g, out_w, rtol=1e-5, atol=1e-5), '%s: max |d| = %.3e' % (label, float((out_g - out_w).abs().max()))
@@ -190,7 +209,7 @@ def test_columns_layout_looped_over_the_shards_equals_one_gpu(eng, torch, n, d, 
     sel = eng.bulyan_select(dist, n, f, on_device=True)
     out = torch.cat([kern.trimmed_mean(v, 2 * f, row_index=sel) for v in slices])
     got = (torch.from_numpy(dist.numpy()), out.cpu(), sel.numpy().tolist(), idx)
-    check_against_unsharded(torch, want, got, 'columns W=%d' % world, g)
+    check_against_unsharded(torch, want, got, 'columns W=%d' % world, g, f=f if n >= 8000 else None)
 
 
 @pytest.mark.parametrize('n,d,world,panel_cols', [(1200, 24640, 3, 8192), (3000, 2 * 16400, 2, 16400), (520, 6000, 8, 2048),
