@@ -399,6 +399,50 @@ class AttackOnly(Workload):
                 'clients': self.m, 'params': self.d}
 
 
+class NoDefense(Workload):
+    """the column mean (defences.py:13-14) -- the same streaming kernel as the attack's statistics."""
+    name, defence = 'no_defense', 'NoDefense'
+
+    def __init__(self, torch, eng, n, d, device, seed):
+        self.eng, self.n, self.d = eng, n, d
+        self.g = make_matrix(torch, n, d, seed, device)
+
+    def step(self):
+        self.last = self.eng.no_defense(self.g, self.n, 0)
+
+    def dominant(self):
+        return {'kernel': 'column_stats', 'bound': 'hbm', 'work': 4.0 * self.n * self.d + 4.0 * self.d,
+                'peak': PEAK_HBM, 'unit': 'GB/s', 'scale': 1e9}
+
+    def config(self):
+        return {'workload': 'no_defense: column mean over N=%d clients, D=%d (defences.py:13-14)' % (self.n, self.d),
+                'clients': self.n, 'params': self.d}
+
+
+class ServerUpdate(Workload):
+    """velocity = momentum * velocity - lr * agg; weights += velocity (server.py:89-90), one fused
+    launch on device-resident vectors: 12 bytes read + 8 written per parameter."""
+    name, defence = 'server_update', 'momentum step'
+
+    def __init__(self, torch, eng, d, device, seed):
+        self.eng, self.d = eng, d
+        gen = torch.Generator(device=device).manual_seed(seed)
+        self.w = torch.randn(d, device=device, generator=gen)
+        self.v = torch.zeros(d, device=device)
+        self.agg = torch.randn(d, device=device, generator=gen)
+
+    def step(self):
+        self.eng.server_update(self.w, self.v, self.agg, 0.9, 0.1)
+        self.last = self.w
+
+    def dominant(self):
+        return {'kernel': 'misc', 'bound': 'hbm', 'work': 20.0 * self.d, 'peak': PEAK_HBM, 'unit': 'GB/s', 'scale': 1e9}
+
+    def config(self):
+        return {'workload': 'server update: fused momentum step on D=%d device-resident parameters (server.py:89-90)' % self.d,
+                'params': self.d}
+
+
 class BackdoorHook(Workload):
     """the two vector steps of BackdoorAttack._attack_grads (backdoor.py:54, 57-63)."""
     name, defence = 'backdoor', 'BackdoorAttack'
@@ -863,6 +907,8 @@ def main(argv=None):
                          lambda: KrumC2(torch, eng, 100, 79510, device, 1235),
                          lambda: KrumC2(torch, eng, 100, 21840, device, 1234),
                          lambda: AttackOnly(torch, eng, 2400, 1_000_000, device, 1238),
+                         lambda: NoDefense(torch, eng, 1000, 1_000_000, device, 1243),
+                         lambda: ServerUpdate(torch, eng, 10_000_000, device, 1244),
                          # the steps either side of the path; MnistNet's parameter shapes
                          lambda: BackdoorHook(torch, eng, 10_000_000, device, 1239),
                          lambda: Assembly(torch, eng, 100, [(100, 784), (100,), (10, 100), (10,)], device, 1240),
