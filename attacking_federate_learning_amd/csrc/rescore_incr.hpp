@@ -26,6 +26,11 @@
 #define BYZ_INCR_HD inline
 #endif
 
+// (development: a translation unit may define BYZ_INCR_PROBE(i) to count / time the sections of an update)
+#ifndef BYZ_INCR_PROBE
+#define BYZ_INCR_PROBE(i) do { } while (0)
+#endif
+
 namespace byz {
 namespace incr {
 
@@ -33,6 +38,7 @@ constexpr int kMaxEvents = 24;     // ties and crossings a record can hold behin
 constexpr int kMeetLimit = 16;     // literal steps a crossing region may take
 constexpr int kMaxFresh = 8;       // events a crossing region may leave
 constexpr uint32_t kGone = 0x80000000u;   // -0.0f: a removed entry (select.hip marks the table with it)
+constexpr uint32_t kNoValue = 0xffffffffu;   // what a table accessor returns for a position it cannot reach (the GPU's prefetched windows)
 
 enum Kind : int { kPlain = 0, kTie = 1, kCross = 2 };
 
@@ -51,13 +57,49 @@ struct Record {
     int32_t valid_pick;  // the pick `s` belongs to; -1: no record
     int32_t n_events;
     Event ev[kMaxEvents];
+
+    // (the algorithms below reach the events through these five only: the GPU keeps event i in lane i of the wave instead)
+    BYZ_INCR_HD Event get(int i) const { return ev[i]; }
+    BYZ_INCR_HD void set(int i, const Event& e) { ev[i] = e; }
+    BYZ_INCR_HD void erase(int i) {
+        for (int j = i; j + 1 < n_events; ++j) ev[j] = ev[j + 1];
+        --n_events;
+    }
+    BYZ_INCR_HD bool insert(int i, const Event& e) {
+        if (n_events >= kMaxEvents) return false;
+        for (int j = n_events; j > i; --j) ev[j] = ev[j - 1];
+        ev[i] = e;
+        ++n_events;
+        return true;
+    }
+    BYZ_INCR_HD int find(int pos) const {   // the event at physical position pos, or -1
+        for (int j = 0; j < n_events; ++j)
+            if (ev[j].pos == pos) return j;
+        return -1;
+    }
+    BYZ_INCR_HD int first_after(int pos) const {   // the first event behind physical position pos (n_events: none)
+        int j = 0;
+        while (j < n_events && ev[j].pos <= pos) ++j;
+        return j;
+    }
+    BYZ_INCR_HD int last_cross_before(int pos) const {   // the last crossing in front of physical position pos, or -1
+        int hit = -1;
+        for (int j = 0; j < n_events && ev[j].pos < pos; ++j)
+            if ((ev[j].kind_t >> 31) != 0u) hit = j;
+        return hit;
+    }
+    BYZ_INCR_HD int next_relevant(int i, bool ties_too) const {   // the first event >= i that is a crossing (or, ties_too, any)
+        while (i < n_events && !ties_too && (ev[i].kind_t >> 31) == 0u) ++i;
+        return i;
+    }
 };
 
 BYZ_INCR_HD bool adds_nothing(uint32_t xb) { return (xb & 0x7fffffffu) == 0u; }   // +0.0 (a live twin) or the -0.0 mark
 
 BYZ_INCR_HD uint32_t fadd_bits(uint32_t a, uint32_t b) {
 #if defined(__HIP_DEVICE_COMPILE__)
-    return __float_as_uint(__fadd_rn(__uint_as_float(a), __uint_as_float(b)));
+    // (wave-uniform in, wave-uniform out: saying so keeps the integer arithmetic around it on the scalar unit)
+    return static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(__float_as_uint(__fadd_rn(__uint_as_float(a), __uint_as_float(b))))));
 #else
     union { uint32_t u; float f; } x, y, z;
     x.u = a;
@@ -127,34 +169,21 @@ BYZ_INCR_HD uint32_t step(uint32_t s, uint32_t xb, int& kind, uint32_t& t) {
 
 BYZ_INCR_HD bool is_cross(const Event& e) { return (e.kind_t >> 31) != 0u; }
 
-BYZ_INCR_HD void erase_event(Record& r, int i) {
-    for (int j = i; j + 1 < r.n_events; ++j) r.ev[j] = r.ev[j + 1];
-    --r.n_events;
-}
-
-BYZ_INCR_HD bool insert_event(Record& r, int i, const Event& e) {
-    if (r.n_events >= kMaxEvents) return false;
-    for (int j = r.n_events; j > i; --j) r.ev[j] = r.ev[j - 1];
-    r.ev[i] = e;
-    ++r.n_events;
-    return true;
-}
-
 // the unit of the running sum in front of position p >= head_end
-BYZ_INCR_HD int unit_at(const Record& r, int p) {
+template <class Rec>
+BYZ_INCR_HD int unit_at(const Rec& r, int p) {
     uint32_t I;
     int eq;
-    decompose(r.s_head, I, eq);
-    for (int i = 0; i < r.n_events && r.ev[i].pos < p; ++i)
-        if (is_cross(r.ev[i])) decompose(r.ev[i].after, I, eq);
+    const int c = r.last_cross_before(p);
+    decompose(c >= 0 ? r.get(c).after : r.s_head, I, eq);
     return eq;
 }
 
 // The literal chain over vals(0 .. end), noting its events behind head_end: what a full re-score leaves behind.  Returns
 // false when no record can be kept (a sign bit or a non-finite value inside the prefix, too many events); r.s is right
 // either way.
-template <class Vals>
-BYZ_INCR_HD bool full(const Vals& vals, int end, int head_end, Record& r) {
+template <class Vals, class Rec>
+BYZ_INCR_HD bool full(const Vals& vals, int end, int head_end, Rec& r) {
     uint32_t s = 0u;
     bool ok = true;
     r.n_events = 0;
@@ -170,16 +199,12 @@ BYZ_INCR_HD bool full(const Vals& vals, int end, int head_end, Record& r) {
         uint32_t t;
         const uint32_t nb = step(s, xb, kind, t);
         if (p >= r.head_end && kind != kPlain) {
-            if (r.n_events < kMaxEvents) {
-                Event e;
-                e.pos = p;
-                e.kind_t = kind == kCross ? 0x80000000u : t;
-                e.before = s;
-                e.after = nb;
-                r.ev[r.n_events++] = e;
-            } else {
-                ok = false;
-            }
+            Event e;
+            e.pos = p;
+            e.kind_t = kind == kCross ? 0x80000000u : t;
+            e.before = s;
+            e.after = nb;
+            if (!r.insert(r.n_events, e)) ok = false;
         }
         s = nb;
     }
@@ -191,8 +216,8 @@ BYZ_INCR_HD bool full(const Vals& vals, int end, int head_end, Record& r) {
 
 // Entry k < r.end (value xk, already marked in the table) leaves the prefix.  s_head_new: the literal sum of [0, head_end)
 // after the mark -- needed (and read) only when k < head_end.  0: r is the record of the new chain; -1: re-score in full.
-template <class Vals>
-BYZ_INCR_HD int mark(const Vals& vals, Record& r, int k, uint32_t xk, uint32_t s_head_new) {
+template <class Vals, class Rec>
+BYZ_INCR_HD int mark(const Vals& vals, Rec& r, int k, uint32_t xk, uint32_t s_head_new) {
     if (adds_nothing(xk)) return 0;   // a live +0.0 (a twin's distance): no partial sum moves
     uint32_t shift = 0u, s_new = 0u, s_old = 0u;
     int shift_eq = 0, at = 0, i = 0;
@@ -208,55 +233,61 @@ BYZ_INCR_HD int mark(const Vals& vals, Record& r, int k, uint32_t xk, uint32_t s
         at = r.head_end;
         literal = true;
     } else {
-        int hit = -1;
-        for (int j = 0; j < r.n_events; ++j)
-            if (r.ev[j].pos == k) hit = j;
-        if (hit >= 0 && is_cross(r.ev[hit])) return -1;
+        const int hit = r.find(k);
+        Event at_k;
+        at_k.kind_t = 0u;
+        if (hit >= 0) at_k = r.get(hit);
+        if (hit >= 0 && is_cross(at_k)) return -1;
         const int eq = unit_at(r, k);
         uint32_t a, above, tie;
         classify(xk, eq, a, above, tie);
         if (tie != 0u && hit < 0) return -1;   // (a tie the record does not know: it was not made from this table)
-        const uint32_t t = hit >= 0 ? (r.ev[hit].kind_t & 1u) : above;
-        if (hit >= 0) erase_event(r, hit);
+        const uint32_t t = hit >= 0 ? (at_k.kind_t & 1u) : above;
+        if (hit >= 0) r.erase(hit);
         shift = a + t;
         shift_eq = eq;
-        while (i < r.n_events && r.ev[i].pos <= k) ++i;
+        i = r.first_after(k);
     }
+    BYZ_INCR_PROBE(0);   // prologue done
     for (;;) {
         if (literal) {
-            // both chains explicitly, entry by entry, until they are in one binade again and past the old chain's crossing
-            Event fresh[kMaxFresh];
+            // both chains explicitly, entry by entry, until they are in one binade again and past the old chain's crossing;
+            // what the new chain does on the way goes on the record at once, the old chain's events on the way come off it
             int n_fresh = 0, steps = 0;
             for (;;) {
                 uint32_t In, Io;
                 int en, eo;
                 decompose(s_new, In, en);
                 decompose(s_old, Io, eo);
-                const bool at_cross = i < r.n_events && r.ev[i].pos == at && is_cross(r.ev[i]);
+                bool at_cross = false;
+                if (i < r.n_events) {
+                    const Event e = r.get(i);
+                    at_cross = e.pos == at && is_cross(e);
+                }
                 if (en == eo && !at_cross) break;
                 if (at >= r.end) break;
                 if (steps >= kMeetLimit) return -1;
+                BYZ_INCR_PROBE(1);   // a literal iteration
                 const uint32_t xb = vals(at);
-                int kind, kind_old;
-                uint32_t t, t_old;
+                if (xb == kNoValue) return -1;
+                int kind;
+                uint32_t t;
                 const uint32_t before = s_new;
                 s_new = step(s_new, xb, kind, t);
-                s_old = step(s_old, xb, kind_old, t_old);
-                if (kind != kPlain) {
-                    if (n_fresh >= kMaxFresh) return -1;
-                    fresh[n_fresh].pos = at;
-                    fresh[n_fresh].kind_t = kind == kCross ? 0x80000000u : t;
-                    fresh[n_fresh].before = before;
-                    fresh[n_fresh].after = s_new;
-                    ++n_fresh;
-                }
+                if (!adds_nothing(xb)) s_old = fadd_bits(s_old, xb);   // (of the old chain only the value is needed)
                 ++steps;
                 ++at;
-                while (i < r.n_events && r.ev[i].pos < at) erase_event(r, i);   // the old chain's events inside the region
+                while (i < r.n_events && r.get(i).pos < at) r.erase(i);   // the old chain's events up to this entry
+                if (kind != kPlain) {
+                    Event e;
+                    e.pos = at - 1;
+                    e.kind_t = kind == kCross ? 0x80000000u : t;
+                    e.before = before;
+                    e.after = s_new;
+                    if (++n_fresh > kMaxFresh || !r.insert(i, e)) return -1;
+                    ++i;
+                }
             }
-            for (int j = 0; j < n_fresh; ++j)
-                if (!insert_event(r, i + j, fresh[j])) return -1;
-            i += n_fresh;
             if (at >= r.end) {
                 r.s = s_new;
                 return 0;
@@ -270,14 +301,15 @@ BYZ_INCR_HD int mark(const Vals& vals, Record& r, int k, uint32_t xk, uint32_t s
             shift_eq = en;
             literal = false;
         }
+        i = r.next_relevant(i, (shift & 1u) != 0u);   // (an even shift leaves every tie as it was resolved)
         if (i >= r.n_events) break;
-        Event& ev = r.ev[i];
+        Event ev = r.get(i);
         if (!is_cross(ev)) {
             if ((shift & 1u) != 0u) {
                 const uint32_t old_t = ev.kind_t & 1u, new_t = old_t ^ 1u;
                 shift = shift + old_t - new_t;
                 ev.kind_t = new_t;
-                // (before / after of a tie are not used by the walk)
+                r.set(i, ev);   // (before / after of a tie are not used by the walk)
             }
             ++i;
             continue;
@@ -287,10 +319,67 @@ BYZ_INCR_HD int mark(const Vals& vals, Record& r, int k, uint32_t xk, uint32_t s
         decompose(ev.before, Ib, eb);
         if (eb != shift_eq || Ib < shift || Ib - shift < (1u << 23)) return -1;
         s_new = compose(Ib - shift, eb);
+        {
+            // the usual case: the new chain crosses at the very entry the old one did -- the two meet right behind it, the
+            // event stays where it is with the new chain's sums, and the shift is read off in the new unit
+            const uint32_t xb = vals(ev.pos);
+            if (xb == kNoValue) return -1;
+            const uint32_t after_new = fadd_bits(s_new, xb);
+            uint32_t In, Io;
+            int en, eo;
+            decompose(after_new, In, en);
+            decompose(ev.after, Io, eo);
+            if (en == eo && Io >= In) {
+                BYZ_INCR_PROBE(2);   // a crossing met at its own entry
+                ev.before = s_new;
+                ev.after = after_new;
+                r.set(i, ev);
+                shift = Io - In;
+                shift_eq = en;
+                ++i;
+                continue;
+            }
+        }
+        {
+            // the other usual case: the new chain, one entry's worth lower, takes the old crossing entry without leaving the
+            // binade and crosses at the NEXT entry -- where the two meet.  (Anything else -- a tie on the way, an entry that adds
+            // nothing, another event of the old chain right there -- is the literal region's business.)
+            const uint32_t x0 = vals(ev.pos), x1 = ev.pos + 1 < r.end ? vals(ev.pos + 1) : kNoValue;
+            bool next_is_event = false;
+            if (i + 1 < r.n_events) next_is_event = r.get(i + 1).pos == ev.pos + 1;
+            if (x0 != kNoValue && x1 != kNoValue && !adds_nothing(x1) && !next_is_event) {
+                uint32_t a0, above0, tie0, I1, I2, Io;
+                int e1, e2, eo;
+                classify(x0, eb, a0, above0, tie0);
+                const uint32_t mid = fadd_bits(s_new, x0);
+                decompose(mid, I1, e1);
+                if (tie0 == 0u && e1 == eb) {
+                    const uint32_t after_new = fadd_bits(mid, x1), after_old = fadd_bits(ev.after, x1);
+                    decompose(after_new, I2, e2);
+                    decompose(after_old, Io, eo);
+                    uint32_t Ia;
+                    int ea;
+                    decompose(ev.after, Ia, ea);
+                    if (e2 == eo && eo == ea && e2 != eb && Io >= I2) {
+                        BYZ_INCR_PROBE(5);   // a crossing that moved to the next entry
+                        ev.pos = ev.pos + 1;
+                        ev.before = mid;
+                        ev.after = after_new;
+                        r.set(i, ev);
+                        shift = Io - I2;
+                        shift_eq = e2;
+                        ++i;
+                        continue;
+                    }
+                }
+            }
+        }
+        BYZ_INCR_PROBE(3);   // a crossing that needs the literal region
         s_old = ev.before;
         at = ev.pos;
         literal = true;
     }
+    BYZ_INCR_PROBE(4);   // the walk is over
     uint32_t If;
     int ef;
     decompose(r.s, If, ef);
@@ -301,22 +390,25 @@ BYZ_INCR_HD int mark(const Vals& vals, Record& r, int k, uint32_t xk, uint32_t s
 }
 
 // The winner lay behind the prefix: the prefix loses its last live entry.  0 / -1 as above.
-template <class Vals>
-BYZ_INCR_HD int drop_last(const Vals& vals, Record& r) {
+template <class Vals, class Rec>
+BYZ_INCR_HD int drop_last(const Vals& vals, Rec& r) {
     int p = r.end - 1, looked = 0;
     while (p >= 0 && vals(p) == kGone) {
         --p;
-        if (++looked > kMeetLimit) return -1;
+        if (++looked >= kMeetLimit) return -1;
     }
     if (p < r.head_end) return -1;
     const uint32_t xb = vals(p);
+    if (xb == kNoValue) return -1;
     if (adds_nothing(xb)) {   // a live +0.0
         r.end = p;
         return 0;
     }
-    if (r.n_events > 0 && r.ev[r.n_events - 1].pos == p) {
-        const Event ev = r.ev[r.n_events - 1];
-        --r.n_events;
+    Event ev;
+    ev.pos = -1;
+    if (r.n_events > 0) ev = r.get(r.n_events - 1);
+    if (ev.pos == p) {
+        r.erase(r.n_events - 1);
         if (is_cross(ev)) {
             r.s = ev.before;
             r.end = p;
