@@ -835,7 +835,7 @@ __device__ __forceinline__ float integer_passes(uint32_t (&M)[8], const int (&ex
 }
 
 // development aid (BYZ_BULYAN_CLOCKS=1): re-scores, their batches, integer passes and cycles
-__device__ unsigned long long g_rescore_clock[10];
+__device__ unsigned long long g_rescore_clock[14];
 
 // One wave; wave-uniform result; `ok` = false when the row holds a negative value (the passes assume distances: the caller
 // then takes the literal chain).  `head`: 512 floats of LDS for the literal chain over the first entries.
@@ -1456,8 +1456,13 @@ __global__ __launch_bounds__(kGridThreads) void bulyan_grid_kernel(
                         }
                         wr.valid_pick = -1;
                         bool gave_up = false;
+                        const unsigned long long cb0 = rescore_mode >= 2 ? __builtin_readcyclecounter() : 0ull;
                         const bool finished = build_slice(sorted_val, n, row, take, lane, rescore_stage[wave], wr, st,
                                                           (contends || !tracking) ? 0x7fffffff : slice_batches, gave_up);
+                        if (rescore_mode >= 2 && lane == 0) {   // (development) a contender's build runs to the end: the pick waits for it
+                            atomicAdd(&g_rescore_clock[contends ? 10 : 11], 1ull);
+                            atomicAdd(&g_rescore_clock[contends ? 12 : 13], __builtin_readcyclecounter() - cb0);
+                        }
                         if (finished) {
                             s32 = __uint_as_float(wr.s);
                             done = true;
@@ -1651,7 +1656,7 @@ int launch_bulyan_loop(byz_ctx* ctx, const float* dist, int64_t n, int64_t theta
     const bool clocks = rescore_mode != 0 && clocks_env != nullptr && std::atoi(clocks_env) != 0;
     if (clocks) {
         rescore_mode += 1;
-        const unsigned long long zero[10] = {0};
+        const unsigned long long zero[14] = {0};
         BYZ_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_rescore_clock), zero, sizeof(zero)));
         BYZ_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_incr_probe), zero, 8 * sizeof(unsigned long long)));
         const int on = 1;
@@ -1692,7 +1697,7 @@ int launch_bulyan_loop(byz_ctx* ctx, const float* dist, int64_t n, int64_t theta
         records, records != nullptr ? track_factor : 0.0f, slice_batches);
     BYZ_TRY(check_launch("bulyan_grid_kernel"));
     if (clocks) {
-        unsigned long long c[10];
+        unsigned long long c[14];
         BYZ_HIP(hipStreamSynchronize(stream));
         const int off = 0;
         BYZ_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_incr_probe_on), &off, sizeof(int)));
@@ -1704,6 +1709,8 @@ int launch_bulyan_loop(byz_ctx* ctx, const float* dist, int64_t n, int64_t theta
             const double q = static_cast<double>(c[5]);
             std::fprintf(stderr, "updates from records: %llu (%llu gave up); per update: head %.0f, windows %.0f, walk %.0f cycles\n",
                          c[5], c[9], c[6] / q, c[7] / q, c[8] / q);
+            std::fprintf(stderr, "  builds run to the end for a contender %llu (%.0f cycles each), slices of tracked rows %llu (%.0f cycles each)\n",
+                         c[10], c[10] ? (double)c[12] / c[10] : 0.0, c[11], c[11] ? (double)c[13] / c[11] : 0.0);
             unsigned long long pr[8];
             BYZ_HIP(hipMemcpyFromSymbol(pr, HIP_SYMBOL(g_incr_probe), sizeof(pr)));
             std::fprintf(stderr, "  walks past the prologue %llu, literal iterations %llu, crossings met at their entry %llu, at the next entry %llu, "
