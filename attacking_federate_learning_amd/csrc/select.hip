@@ -840,8 +840,10 @@ __device__ unsigned long long g_rescore_clock[14];
 // One wave; wave-uniform result; `ok` = false when the row holds a negative value (the passes assume distances: the caller
 // then takes the literal chain).  `head`: 512 floats of LDS for the literal chain over the first entries.
 // (The form that also leaves a record of its chain behind, for the incremental re-score, is build_slice below.)
+template <bool CLOCKS>
 __device__ __forceinline__ float reference_score_marked(const float* sorted_val, int n, int u, int take, int lane,
-                                                        float* __restrict__ head, int head_chunks, bool clocks, bool& ok) {
+                                                        float* __restrict__ head, int head_chunks, bool& ok) {
+    constexpr bool clocks = CLOCKS;   // (development: a compile-time switch -- what is compiled into this loop costs even when it never runs)
     typedef uint32_t u32x4u __attribute__((ext_vector_type(4), aligned(4)));
     typedef float f32x4 __attribute__((ext_vector_type(4)));
     const uint32_t* vals = reinterpret_cast<const uint32_t*>(sorted_val + static_cast<int64_t>(u) * n);
@@ -1021,8 +1023,10 @@ constexpr int kNoWindow = -(1 << 30);
 // One entry has left the prefix of `row` since its record was made: the winner's distance at position k (already marked in the
 // table; `beyond`: it lay behind the prefix, or is not finite -- then the prefix loses its last live entry instead).  True: wr
 // is the record of the new chain and wr.s its score; false: nothing can be said -- re-score in full.
+template <bool CLOCKS>
 __device__ __forceinline__ bool incremental_score(const float* sorted_val, int n, int row, int lane, float* __restrict__ stage,
-                                                  WaveRecord& wr, int k, uint32_t xk, bool beyond, bool clocks) {
+                                                  WaveRecord& wr, int k, uint32_t xk, bool beyond) {
+    constexpr bool clocks = CLOCKS;
     const uint32_t* vals = reinterpret_cast<const uint32_t*>(sorted_val + static_cast<int64_t>(row) * n);
     const unsigned long long c0 = clocks ? __builtin_readcyclecounter() : 0ull;
     const bool inside = !beyond && k < wr.end;
@@ -1214,7 +1218,7 @@ struct GridDecision {
 
 // INCR (BYZ_BULYAN_INCR=1): the incremental re-score and the tracked rows are compiled in; the plain instantiation is the
 // loop of rounds 2-4.
-template <bool INCR>
+template <bool INCR, bool DEV>
 __global__ __launch_bounds__(kGridThreads) void bulyan_grid_kernel(
     const float* __restrict__ dist, int n, int theta, int drop, int users_count, int corrupted,
     const uint16_t* __restrict__ sorted_idx, const uint16_t* __restrict__ rank_t, float* sorted_val,
@@ -1409,7 +1413,7 @@ __global__ __launch_bounds__(kGridThreads) void bulyan_grid_kernel(
                     }
                     const bool beyond = (xk & 0x7f800000u) == 0x7f800000u;
                     if (steady && wr.valid_pick == t - 1) {
-                        if (incremental_score(sorted_val, n, row, lane, rescore_stage[wave], wr, k_pos, xk, beyond, rescore_mode >= 2)) {
+                        if (incremental_score<DEV>(sorted_val, n, row, lane, rescore_stage[wave], wr, k_pos, xk, beyond)) {
                             s32 = __uint_as_float(wr.s);
                             done = true;
                             wr.valid_pick = t;
@@ -1437,7 +1441,7 @@ __global__ __launch_bounds__(kGridThreads) void bulyan_grid_kernel(
                                 // the previous pick's winner lies in the part that is already added: the partial chain moves
                                 wr.end = st.r0;
                                 wr.s = __float_as_uint(st.s);
-                                resumed = incremental_score(sorted_val, n, row, lane, rescore_stage[wave], wr, k_pos, xk, false, false);
+                                resumed = incremental_score<false>(sorted_val, n, row, lane, rescore_stage[wave], wr, k_pos, xk, false);
                                 st.s = __uint_as_float(wr.s);
                                 st.got -= 1;
                             }
@@ -1456,10 +1460,10 @@ __global__ __launch_bounds__(kGridThreads) void bulyan_grid_kernel(
                         }
                         wr.valid_pick = -1;
                         bool gave_up = false;
-                        const unsigned long long cb0 = rescore_mode >= 2 ? __builtin_readcyclecounter() : 0ull;
+                        const unsigned long long cb0 = DEV ? __builtin_readcyclecounter() : 0ull;
                         const bool finished = build_slice(sorted_val, n, row, take, lane, rescore_stage[wave], wr, st,
                                                           (contends || !tracking) ? 0x7fffffff : slice_batches, gave_up);
-                        if (rescore_mode >= 2 && lane == 0) {   // (development) a contender's build runs to the end: the pick waits for it
+                        if (DEV && lane == 0) {   // (development) a contender's build runs to the end: the pick waits for it
                             atomicAdd(&g_rescore_clock[contends ? 10 : 11], 1ull);
                             atomicAdd(&g_rescore_clock[contends ? 12 : 13], __builtin_readcyclecounter() - cb0);
                         }
@@ -1490,7 +1494,7 @@ __global__ __launch_bounds__(kGridThreads) void bulyan_grid_kernel(
                   }
                 }
                 if (!incremental && marked)
-                    s32 = reference_score_marked(sorted_val, n, row, take, lane, rescore_stage[wave], head_chunks, rescore_mode >= 2, done);
+                    s32 = reference_score_marked<DEV>(sorted_val, n, row, take, lane, rescore_stage[wave], head_chunks, done);
                 if (!contends) continue;
                 if (!done) s32 = reference_score_plain(sorted_val, sorted_idx, removed, n, row, take, lane, rescore_stage[wave]);
                 if (s32 < kKrumInit) {
@@ -1689,7 +1693,8 @@ int launch_bulyan_loop(byz_ctx* ctx, const float* dist, int64_t n, int64_t theta
     twin_class_fix_kernel<<<static_cast<unsigned>(ceil_div(n, 256)), 256, 0, stream>>>(cls_tmp, (int)n, cls);
     BYZ_TRY(check_launch("twin_class_fix_kernel"));
     const unsigned n_wgs = static_cast<unsigned>(ceil_div(n, kGridThreads));   // <= 64: all resident, they wait for each other
-    auto* kernel = records != nullptr ? &bulyan_grid_kernel<true> : &bulyan_grid_kernel<false>;
+    auto* kernel = records != nullptr ? (clocks ? &bulyan_grid_kernel<true, true> : &bulyan_grid_kernel<true, false>)
+                                      : (clocks ? &bulyan_grid_kernel<false, true> : &bulyan_grid_kernel<false, false>);
     kernel<<<n_wgs, kGridThreads, 0, stream>>>(
         dist, (int)n, (int)theta, (int)drop_count, (int)users_count, (int)corrupted, ctx->sorted_idx.as<uint16_t>(),
         ctx->rank_t.as<uint16_t>(), ctx->sorted_val.as<float>(), ctx->row_total.as<double>(), ctx->row_top.as<double>(), cls,
