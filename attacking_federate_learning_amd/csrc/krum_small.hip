@@ -411,7 +411,6 @@ __device__ double pair_sq_distance(const float* __restrict__ a, const float* __r
 
 // development aid (BYZ_KRUM_SMALL_TIMING=1): s_memtime stamps of K2's phases, taken by thread 0 of every workgroup
 constexpr int kRowStamps = 8;
-__device__ int g_rows_timing;
 __device__ unsigned long long g_rows_stamps[kMaxRows * kRowStamps];
 #define BYZ_STAMP(k)                                                                              \
     do {                                                                                          \
@@ -422,6 +421,9 @@ constexpr uint32_t kScoreSentinel = 0xffc0dead;   // "no score yet": K1 writes i
 constexpr int kGroups = 16;                       // thread groups of the slab sums (32 threads x 4 columns each)
 constexpr int kMaxPerGroup = 256 / kGroups;       // K1 launches at most 256 workgroups
 
+// TIMING (BYZ_KRUM_SMALL_TIMING): the phase stamps.  A template parameter: as a flag in device memory it was a dependent scalar
+// load at the head of a 10 us kernel.
+template <bool TIMING>
 __global__ __launch_bounds__(kThreads, 1) void small_rows_kernel(RowsArgs p) {
     __shared__ double part[2][kGroups][kMaxRows];   // [row entries | diagonal][group][column]
     __shared__ double red[kThreads];
@@ -432,7 +434,7 @@ __global__ __launch_bounds__(kThreads, 1) void small_rows_kernel(RowsArgs p) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i = blockIdx.x;
     const int n = p.n;
-    const bool timing = g_rows_timing != 0;
+    constexpr bool timing = TIMING;
     BYZ_STAMP(0);
 
     // ---- 1. the row of the Gram and the diagonal
@@ -818,18 +820,13 @@ static int small_round(byz_ctx* ctx, const float* G, int64_t n_rows, int64_t n_c
         p.out_row = out_row;
         p.status = device_status_word(ctx);
         const bool stamps = env_int("BYZ_KRUM_SMALL_TIMING", 0) != 0;
-        if (stamps) {
-            const int on = 1;
-            BYZ_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_rows_timing), &on, sizeof(int)));
-        }
-        small_rows_kernel<<<static_cast<unsigned>(n), kThreads, 0, stream>>>(p);
+        if (stamps) small_rows_kernel<true><<<static_cast<unsigned>(n), kThreads, 0, stream>>>(p);
+        else small_rows_kernel<false><<<static_cast<unsigned>(n), kThreads, 0, stream>>>(p);
         BYZ_TRY(check_launch("small_rows_kernel"));
         if (stamps) {
             static unsigned long long host[kMaxRows * kRowStamps];
             BYZ_HIP(hipStreamSynchronize(stream));
             BYZ_HIP(hipMemcpyFromSymbol(host, HIP_SYMBOL(g_rows_stamps), sizeof(host)));
-            const int off = 0;
-            BYZ_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_rows_timing), &off, sizeof(int)));
             const char* names[7] = {"", "slab sums", "distances", "sort + score + ticket", "wait for all", "argmin", "row copy"};
             for (int k = 1; k <= 6; ++k) {
                 if (k == 4 && prefix_len < 0) break;
