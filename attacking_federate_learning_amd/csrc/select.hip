@@ -877,6 +877,12 @@ __device__ __forceinline__ float reference_score_marked(const float* sorted_val,
         negative = negative || top > kGoneBits;   // a sign bit on a live entry
         const uint32_t incl = wave_scan_u32(cnt);
         const int total = __builtin_amdgcn_readlane(static_cast<int>(incl), 63);
+        if (total == 0) {
+            // nothing live in these 512 entries: the winners of the picks so far are every row's NEAREST neighbours, so late in the
+            // loop the front of the table is one run of marks -- up to ten such batches at N = 10,000 -- and there is nothing to add
+            ++n_batches;
+            return r0 + 512 >= n;
+        }
         if (got + total > take) {   // uniform: the prefix ends inside this batch
             int room = take - got - static_cast<int>(incl - cnt);   // live entries of this lane that still belong to it
 #pragma unroll
@@ -1121,6 +1127,12 @@ __device__ __forceinline__ bool build_slice(const float* sorted_val, int n, int 
         }
         const uint32_t incl = wave_scan_u32(cnt);
         const int total = __builtin_amdgcn_readlane(static_cast<int>(incl), 63);
+        if (total == 0) {   // nothing live in this batch (a run of marks): nothing to add, and it does not count as work done
+            st.r0 = r0 + 512;
+            finished = st.r0 >= n;
+            --batches;
+            continue;
+        }
         int kept_j = -1;
         if (st.got + total > take) {   // uniform: the prefix ends inside this batch
             int room = take - st.got - static_cast<int>(incl - cnt);
