@@ -389,6 +389,71 @@ BYZ_INCR_HD int mark(const Vals& vals, Rec& r, int k, uint32_t xk, uint32_t s_he
     return 0;
 }
 
+// The same update for the case that nearly every pick is: the marked entry lies behind the literal head, is no
+// event and no tie itself; every later crossing is met at its own entry or at the next live one, with no tie and no other event in
+// between.  Straight-line work per event -- the sums inside one binade are moved as integers on their bit patterns.  1: r is the
+// record of the new chain; 0: not this case -- r may be half-way changed, the caller restores its copy and runs `mark`.
+// vals.next_live(pos, at): the first entry behind pos that adds something (its position to `at`), kNoValue if out of reach.
+template <class Vals, class Rec>
+BYZ_INCR_HD int mark_fast(const Vals& vals, Rec& r, int k, uint32_t xk) {
+    if (adds_nothing(xk)) return 1;
+    if (k < r.head_end || r.find(k) >= 0) return 0;
+    uint32_t a, above, tie;
+    classify(xk, unit_at(r, k), a, above, tie);
+    if (tie != 0u) return 0;
+    uint32_t shift = a + above;
+    int i = r.first_after(k);
+    for (;;) {
+        i = r.next_relevant(i, (shift & 1u) != 0u);
+        if (i >= r.n_events) break;
+        Event ev = r.get(i);
+        if (!is_cross(ev)) {   // (only an odd shift gets here)
+            const uint32_t old_t = ev.kind_t & 1u, new_t = old_t ^ 1u;
+            shift = shift + old_t - new_t;
+            ev.kind_t = new_t;
+            r.set(i, ev);
+            ++i;
+            continue;
+        }
+        const uint32_t eb = ev.before >> 23, ea = ev.after >> 23;
+        if ((ev.before & 0x7fffffu) < shift && eb != 0u) return 0;   // the new chain would start this stretch a binade lower
+        if (eb == 0u) return 0;                                      // (subnormal sums: the general walk)
+        const uint32_t s_new = ev.before - shift;
+        const uint32_t x0 = vals(ev.pos);
+        if (x0 == kNoValue) return 0;
+        const uint32_t after0 = fadd_bits(s_new, x0);
+        if ((after0 >> 23) == ea) {   // crossed at the same entry: the two chains meet right behind it
+            if (ev.after < after0) return 0;
+            shift = ev.after - after0;
+            ev.before = s_new;
+            ev.after = after0;
+            r.set(i, ev);
+            ++i;
+            continue;
+        }
+        if ((after0 >> 23) != eb) return 0;
+        uint32_t a0, above0, tie0;
+        classify(x0, static_cast<int>(eb) - 150, a0, above0, tie0);
+        if (tie0 != 0u) return 0;   // (the entry is a plain step of the new chain now; a tie would have to go on the record)
+        int at1 = 0;
+        const uint32_t x1 = vals.next_live(ev.pos, at1);
+        if (x1 == kNoValue || at1 >= r.end) return 0;
+        if (i + 1 < r.n_events && r.get(i + 1).pos <= at1) return 0;
+        const uint32_t after_new = fadd_bits(after0, x1), after_old = fadd_bits(ev.after, x1);
+        if ((after_new >> 23) != ea || (after_old >> 23) != ea || after_old < after_new) return 0;
+        shift = after_old - after_new;
+        ev.pos = at1;
+        ev.before = after0;
+        ev.after = after_new;
+        r.set(i, ev);
+        ++i;
+    }
+    if ((r.s >> 23) == 0u || (r.s & 0x7fffffu) < shift) return 0;
+    // (the stretch behind the last crossing is the final binade: its unit is the shift's)
+    r.s = r.s - shift;
+    return 1;
+}
+
 // The winner lay behind the prefix: the prefix loses its last live entry.  0 / -1 as above.
 template <class Vals, class Rec>
 BYZ_INCR_HD int drop_last(const Vals& vals, Rec& r) {

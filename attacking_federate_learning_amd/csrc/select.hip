@@ -1016,6 +1016,20 @@ __device__ __forceinline__ uint32_t literal_head_sum(const uint32_t* vals, int n
 struct WindowVals {
     const float* stage;   // window w: stage[16 w .. 16 w + 15]
     int win_pos;          // lane w: where window w starts in the row (kNoWindow: it does not exist)
+    int lane;
+    // the first entry behind pos that adds something (the 16 lanes of a window look at it at once)
+    __device__ __forceinline__ uint32_t next_live(int pos, int& at) const {
+        const unsigned long long m = __ballot(static_cast<unsigned>(pos - win_pos) < 16u);
+        if (m == 0ull) return incr::kNoValue;
+        const int w = __builtin_ctzll(m);
+        const int base = __builtin_amdgcn_readlane(win_pos, w);
+        const uint32_t v = __float_as_uint(stage[16 * w + (lane & 15)]);
+        const unsigned long long live = __ballot(lane < 16 && lane > pos - base && v != incr::kNoValue && !incr::adds_nothing(v));
+        if (live == 0ull) return incr::kNoValue;
+        const int j = __builtin_ctzll(live);
+        at = base + j;
+        return static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(v), j));
+    }
     __device__ __forceinline__ uint32_t operator()(int p) const {
         const unsigned long long m = __ballot(static_cast<unsigned>(p - win_pos) < 16u);
         if (m == 0ull) return incr::kNoValue;
@@ -1057,9 +1071,22 @@ __device__ __forceinline__ bool incremental_score(const float* sorted_val, int n
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-    const WindowVals wv{stage, win_pos};
+    const WindowVals wv{stage, win_pos, lane};
     const unsigned long long c2 = clocks ? __builtin_readcyclecounter() : 0ull;
-    const int rc = inside ? incr::mark(wv, wr, k, xk, s_head_new) : incr::drop_last(wv, wr);
+    int rc;
+    if (inside) {
+        // the straight-line walk for the usual case first; what it declines goes to the general one on the record as it was
+        const WaveRecord saved = wr;
+        if (incr::mark_fast(wv, wr, k, xk) == 1) {
+            rc = 0;
+            if (clocks && lane == 0) atomicAdd(&g_incr_probe[6], 1ull);
+        } else {
+            wr = saved;
+            rc = incr::mark(wv, wr, k, xk, s_head_new);
+        }
+    } else {
+        rc = incr::drop_last(wv, wr);
+    }
     if (clocks && lane == 0) {
         const unsigned long long c3 = __builtin_readcyclecounter();
         atomicAdd(&g_rescore_clock[5], 1ull);
@@ -1731,7 +1758,7 @@ int launch_bulyan_loop(byz_ctx* ctx, const float* dist, int64_t n, int64_t theta
             unsigned long long pr[8];
             BYZ_HIP(hipMemcpyFromSymbol(pr, HIP_SYMBOL(g_incr_probe), sizeof(pr)));
             std::fprintf(stderr, "  walks past the prologue %llu, literal iterations %llu, crossings met at their entry %llu, at the next entry %llu, "
-                                 "through the literal region %llu, walks to the end %llu\n", pr[0], pr[1], pr[2], pr[5], pr[3], pr[4]);
+                                 "through the literal region %llu, walks to the end %llu; straight-line walks %llu\n", pr[0], pr[1], pr[2], pr[5], pr[3], pr[4], pr[6]);
         }
     }
     return BYZ_OK;

@@ -6,8 +6,18 @@ using namespace byz::incr;
 namespace {
 struct Table {
     const uint32_t* v;
+    int n;
     uint32_t operator()(int p) const { return v[p]; }
+    uint32_t next_live(int pos, int& at) const {
+        for (int p = pos + 1; p < n && p < pos + 16; ++p)
+            if (!adds_nothing(v[p])) {
+                at = p;
+                return v[p];
+            }
+        return kNoValue;
+    }
 };
+int g_fast_taken = 0, g_fast_declined = 0;
 uint32_t head_sum(const uint32_t* vals, int head_end) {
     uint32_t s = 0u;
     for (int p = 0; p < head_end; ++p) {
@@ -21,12 +31,15 @@ uint32_t head_sum(const uint32_t* vals, int head_end) {
 
 extern "C" {
 
+int incr_fast_taken() { return g_fast_taken; }
+int incr_fast_declined() { return g_fast_declined; }
+
 int incr_record_bytes() { return static_cast<int>(sizeof(Record)); }
 
 uint32_t incr_literal(const uint32_t* vals, int end) { return head_sum(vals, end); }
 
 int incr_full(const uint32_t* vals, int end, int head_end, Record* r) {
-    const bool ok = full(Table{vals}, end, head_end, *r);
+    const bool ok = full(Table{vals, 1 << 30}, end, head_end, *r);
     r->valid_pick = ok ? 0 : -1;
     return ok ? 1 : 0;
 }
@@ -39,11 +52,19 @@ int incr_update(uint32_t* vals, Record* r, int k) {
         const uint32_t xk = vals[k];
         vals[k] = kGone;
         if (r->valid_pick >= 0) {
-            const uint32_t s_head_new = k < r->head_end ? head_sum(vals, r->head_end) : 0u;
-            rc = mark(Table{vals}, *r, k, xk, s_head_new);
+            const Record saved = *r;
+            if (mark_fast(Table{vals, r->end}, *r, k, xk) == 1) {
+                ++g_fast_taken;
+                rc = 0;
+            } else {
+                ++g_fast_declined;
+                *r = saved;
+                const uint32_t s_head_new = k < r->head_end ? head_sum(vals, r->head_end) : 0u;
+                rc = mark(Table{vals, 1 << 30}, *r, k, xk, s_head_new);
+            }
         }
     } else if (r->valid_pick >= 0) {
-        rc = drop_last(Table{vals}, *r);
+        rc = drop_last(Table{vals, 1 << 30}, *r);
     }
     if (rc == 0) return 1;
     int end = r->end;
@@ -53,7 +74,7 @@ int incr_update(uint32_t* vals, Record* r, int k) {
         end = p < 0 ? 0 : p;
     }
     const int head_end = r->head_end;
-    const bool ok = full(Table{vals}, end, head_end > 0 ? head_end : 512, *r);
+    const bool ok = full(Table{vals, 1 << 30}, end, head_end > 0 ? head_end : 512, *r);
     r->valid_pick = ok ? 0 : -1;
     return 0;
 }
