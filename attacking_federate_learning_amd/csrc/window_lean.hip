@@ -126,7 +126,6 @@ __device__ __forceinline__ int wave_sum_i(int x) {
 __device__ unsigned int g_lean_reasons[16];
 // development aid (BYZ_TM_LEAN_TIMING=1): s_memtime stamps of the phases of the first 256 tiles, taken by thread 0
 constexpr int kStampTiles = 256, kStamps = 12;
-__device__ int g_lean_timing;
 __device__ unsigned long long g_lean_stamps[kStampTiles * kStamps];
 
 // Register rows are loaded (and then swept) in this order: the three sampled ones first, so that the range phase can start
@@ -165,7 +164,7 @@ template <int W, int RPW, int B, int SR, int LS, bool EXACT, bool PIPE>
 __global__ __launch_bounds__(64 * W, 4) void window_lean_kernel(const float* __restrict__ G, int n_rows, int64_t n_cols,
                                                                 int64_t ld, const int32_t* __restrict__ row_index, int keep,
                                                                 float* __restrict__ out, int32_t* __restrict__ redo,
-                                                                int by_xcd) {
+                                                                int by_xcd, int stamp_from) {
     constexpr int T = 64 * W;
     constexpr int NCW = kTileCols / W;          // columns an owner wave resolves: 4, 2 or 1
     constexpr int CAP = 64 * SR;
@@ -201,8 +200,10 @@ __global__ __launch_bounds__(64 * W, 4) void window_lean_kernel(const float* __r
     }
     const int64_t c_base = tile * kTileCols;
     const float pinf = __builtin_inff();
-    const int64_t stamp_tile = tile - (g_lean_timing - 1);   // g_lean_timing = 1 + first stamped tile (0: off)
-    const bool stamping = g_lean_timing != 0 && stamp_tile >= 0 && stamp_tile < kStampTiles && tid == 0;
+    // stamp_from = 1 + first stamped tile (0: off).  A kernel argument: as a flag in device memory it was a dependent scalar load
+    // that every workgroup waited for before its first instruction of substance.
+    const int64_t stamp_tile = tile - (stamp_from - 1);
+    const bool stamping = stamp_from != 0 && stamp_tile >= 0 && stamp_tile < kStampTiles && tid == 0;
 #define BYZ_STAMP(i) do { if (stamping) g_lean_stamps[stamp_tile * kStamps + (i)] = __builtin_readcyclecounter(); } while (0)
     BYZ_STAMP(0);
 
@@ -706,7 +707,6 @@ int launch_lean_shape(const float* G, int64_t n_rows, int64_t n_cols, int64_t ld
     const char* timing_env = std::getenv("BYZ_TM_LEAN_TIMING");
     // (tiles from the middle of the launch: the chip is in its steady state there)
     const int timing = timing_env != nullptr && std::atoi(timing_env) != 0 ? 1 + static_cast<int>(n_tiles > 2 * kStampTiles ? n_tiles / 2 : 0) : 0;
-    if (timing) BYZ_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_lean_timing), &timing, sizeof(int)));
     const char* xcd_env = std::getenv("BYZ_TM_LEAN_XCD");   // 0: tile = blockIdx.x (the comparison)
     const int by_xcd = xcd_env != nullptr ? std::atoi(xcd_env) : 1;
     // PIPE: request the tile's rows under the range phase and the histogram instead of all at once.  Same box, tiles ordered by
@@ -720,7 +720,7 @@ int launch_lean_shape(const float* G, int64_t n_rows, int64_t n_cols, int64_t ld
         BYZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&window_lean_kernel<W, RPW, B, SR, LS, E, P>),     \
                                     hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));            \
         window_lean_kernel<W, RPW, B, SR, LS, E, P><<<static_cast<unsigned>(n_tiles), 64 * W, lds, stream>>>(        \
-            G, static_cast<int>(n_rows), n_cols, ld, row_index, static_cast<int>(keep), out, redo, by_xcd);         \
+            G, static_cast<int>(n_rows), n_cols, ld, row_index, static_cast<int>(keep), out, redo, by_xcd, timing); \
     } while (0)
     if (exact) BYZ_LEAN(true, false);
     else if (pipe) BYZ_LEAN(false, true);
@@ -742,8 +742,6 @@ int launch_lean_shape(const float* G, int64_t n_rows, int64_t n_cols, int64_t ld
         }
         std::fprintf(stderr, "lean W=%d RPW=%d phases (s_memtime ticks, mean of %d tiles): issue %.0f | load wait + range %.0f | sweep A %.0f | scan %.0f | search %.0f | sweep B %.0f | owners %.0f\n",
                      W, RPW, tiles, sum[1] / tiles, sum[2] / tiles, sum[3] / tiles, sum[4] / tiles, sum[5] / tiles, sum[6] / tiles, sum[7] / tiles);
-        const int off = 0;
-        BYZ_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_lean_timing), &off, sizeof(int)));
     }
     if (const char* dbg = std::getenv("BYZ_TM_LEAN_DEBUG"); dbg != nullptr && std::atoi(dbg) != 0) {
         unsigned int host[16] = {0};
