@@ -54,12 +54,16 @@ def parse_args(argv=None):
     p.add_argument('--params', type=int, default=None, help='override total D')
     p.add_argument('--no-cpu-baseline', action='store_true')
     p.add_argument('--no-extras', action='store_true')
-    p.add_argument('--cpu-seconds', type=float, default=20.0, help='budget of the cpu_baseline leg')
+    p.add_argument('--cpu-seconds', type=float, default=12.0, help='budget of the cpu_baseline leg')
     p.add_argument('--layout', default='columns', choices=['columns', 'clients', 'both'],
                    help='multi-GPU layout of the gradient matrix (sharded.py); "both" times the other one as well')
     p.add_argument('--no-sharded-w1', action='store_true',
                    help='skip the leg that times the W > 1 code path (collectives forced) on this one GPU')
     p.add_argument('--no-north-star', action='store_true', help='skip the c5s / c5u legs of the default run')
+    p.add_argument('--detail-file', default='bench_detail.json',
+                   help='where the full record goes (every leg, every kernel table); stdout carries only the compact line')
+    p.add_argument('--extras-steps', type=int, default=10, help='timed rounds of each small side workload')
+    p.add_argument('--north-star-steps', type=int, default=2, help='timed rounds of the c5s / c5u legs')
     return p.parse_args(argv)
 
 
@@ -783,6 +787,148 @@ def cpu_baseline(wl, budget_s):
     return out
 
 
+# ---- the line the driver parses: compact, bounded, tested ----------------------------------------------------------------
+LINE_BUDGET = 4000         # bytes; the driver keeps an 8 KB tail of stdout + stderr (a 20 KB line was cut, parsed: null)
+
+
+def sig(x, digits=5):
+    """A float with `digits` significant digits (the record's numbers are measurements: 5 digits lose nothing)."""
+    if isinstance(x, bool) or x is None or isinstance(x, (int, str)):
+        return x
+    try:
+        return float('%.*g' % (digits, float(x)))
+    except (TypeError, ValueError):
+        return x
+
+
+def clip(text, limit):
+    text = str(text)
+    return text if len(text) <= limit else text[:limit - 3] + '...'
+
+
+def compact_roofline(r):
+    if not r:
+        return None
+    out = {k: sig(r.get(k)) for k in ('kernel', 'bound', 'achieved', 'peak', 'unit', 'frac', 'traffic', 'avg_launch_ms',
+                                       'launches_per_step', 'arithmetic') if k in r}
+    if r.get('mfma_issued'):
+        out['mfma_pipe_frac'] = sig(r['mfma_issued']['frac'])
+    if r.get('with_plane_split'):
+        out['plane_split_ms'] = sig(r['with_plane_split']['plane_split_ms_per_step'])
+    return out
+
+
+def compact_cpu_baseline(c):
+    if not c:
+        return None
+    out = {'value': sig(c.get('value')), 'unit': c.get('unit'), 'cores': c.get('cores'), 'kind': c.get('kind'),
+           'sample': clip(c.get('sample', ''), 260), 'host_cores': c.get('host_cores_available')}
+    also = c.get('also') or {}
+    for key, short in (('port_all_cores', 'all_cores'), ('as_shipped', 'as_shipped')):
+        if key in also:
+            out[short] = {'value': sig(also[key].get('value')), 'cores': also[key].get('cores')}
+    return out
+
+
+def compact_leg(rec):
+    """One side leg as a handful of numbers: rate, time, the dominant kernel's roofline fraction."""
+    if not rec:
+        return None
+    out = {'value': sig(rec.get('value')), 'ms': sig(rec.get('ms_per_step'))}
+    r = rec.get('roofline')
+    if r:
+        out['kernel'], out['bound'], out['frac'] = r.get('kernel'), r.get('bound'), sig(r.get('frac'), 4)
+    return out
+
+
+def compact_line(detail, budget=LINE_BUDGET):
+    """The ONE line of stdout: the contract's keys, the roofline and cpu_baseline objects, a flat kernel table, the
+    north-star legs and one number per side workload.  Everything else lives in the detail file.  Optional sections are
+    dropped, least important first, until the line fits the budget; the contract's own keys never are."""
+    line = {k: detail.get(k) for k in ('metric', 'value', 'unit', 'n_gpus', 'ranks_seen', 'steps', 'warmup', 'ms_per_step',
+                                       'higher_is_better', 'scaling', 'vs_baseline', 'dtype', 'data')}
+    line['value'], line['ms_per_step'] = sig(line['value'], 6), sig(line['ms_per_step'], 6)
+    line['dtype'] = clip(line['dtype'], 120)
+    cfg = detail.get('config') or {}
+    line['config'] = {k: (clip(v, 220) if isinstance(v, str) else v) for k, v in cfg.items()
+                      if k in ('workload', 'clients', 'params', 'corrupted', 'layout', 'params_per_gpu')}
+    line['roofline'] = compact_roofline(detail.get('roofline'))
+    line['cpu_baseline'] = compact_cpu_baseline(detail.get('cpu_baseline'))
+    if detail.get('kernels'):
+        line['kernels_ms'] = {k: sig(v['ms_per_step'], 4) for k, v in detail['kernels'].items()}
+    others = detail.get('other_workloads') or {}
+    star = {}
+    for name in ('c5s', 'c5u'):
+        rec = others.get(name)
+        if rec:
+            leg = compact_leg(rec)
+            p8 = (rec.get('projected') or {}).get('gpus_8')
+            if p8:
+                leg['projected_8'] = sig(p8['rounds_per_s'], 4)
+            leg['loop_ms'] = sig((rec.get('kernels') or {}).get('bulyan_loop', {}).get('ms_per_step'), 4)
+            star[name] = leg
+    if star:
+        if 'c5u' in star:
+            # north_star: >= 1 round/s at N = 10,000 x D = 25M on eight GPUs; said plainly (projection: one GPU is all there is)
+            star['c5u_target_met'] = bool((star['c5u'].get('projected_8') or 0.0) >= 1.0)
+        if 'c5s' in star:
+            star['c5s_target_met'] = bool((star['c5s'].get('projected_8') or 0.0) >= 1.0)
+        star['note'] = 'one GPU slice of configs[4] (D = 25M / 8); projected_8 = measured kernels + xGMI model, NOT measured on 8 GPUs'
+        line['north_star'] = star
+    side = {k: {kk: vv for kk, vv in compact_leg(v).items() if kk != 'kernel'} for k, v in others.items()
+            if k not in ('c5s', 'c5u')}
+    if side:
+        line['others'] = side
+    proj = detail.get('projected')
+    if proj:
+        line['projected'] = {k[5:]: sig(v['rounds_per_s'], 4) for k, v in proj.items() if k.startswith('gpus_')}
+        line['projected']['note'] = 'PROJECTED (kernels measured here + xGMI link model), not measured'
+    w1 = detail.get('sharded_path_w1') or {}
+    if w1:
+        line['sharded_path_w1_ms'] = {k: sig(v.get('ms_per_step'), 5) for k, v in w1.items() if isinstance(v, dict)}
+    if detail.get('other_layout'):
+        line['other_layout'] = dict(compact_leg(detail['other_layout']), layout=detail['other_layout'].get('layout'))
+    if detail.get('collectives'):
+        line['collectives_ms'] = {k: sig(v['ms_per_step'], 4) for k, v in detail['collectives'].items()}
+    if detail.get('verified_after_timing'):
+        line['verified_after_timing'] = detail['verified_after_timing']
+    if detail.get('detail_file'):
+        line['detail_file'] = detail['detail_file']
+    for victim in ('collectives_ms', 'sharded_path_w1_ms', 'others', 'projected', 'other_layout', 'kernels_ms',
+                   'verified_after_timing', 'north_star'):
+        if len(json.dumps(line)) <= budget:
+            break
+        line.pop(victim, None)
+    text = json.dumps(line)
+    if len(text) > budget:      # the contract's keys alone overflow: shorten the free-text fields, never drop a key
+        line['config'] = {'workload': clip(cfg.get('workload', ''), 100)}
+        if line.get('cpu_baseline'):
+            line['cpu_baseline']['sample'] = clip(line['cpu_baseline']['sample'], 80)
+        line['dtype'] = clip(line['dtype'], 40)
+        text = json.dumps(line)
+    assert len(text) <= budget and '\n' not in text, 'bench: the stdout line is %d bytes' % len(text)
+    return text
+
+
+def emit(detail, path):
+    """Full record -> the detail file (best effort: a read-only tree must not cost the run its line); compact line -> the
+    last line of stdout.  Nothing of the record goes to stderr: the driver's tail is stdout + stderr together."""
+    if path:
+        try:
+            with open(path, 'w') as fh:
+                json.dump(detail, fh, indent=1)
+            detail['detail_file'] = path
+        except OSError as exc:
+            sys.stderr.write('bench: detail file not written (%s)\n' % exc)
+    try:
+        import ctypes
+        ctypes.CDLL(None).fflush(None)     # RCCL's banner goes through C stdio: out first, the JSON line stays last
+    except OSError:
+        pass
+    sys.stderr.flush()
+    print(compact_line(detail), flush=True)
+
+
 # ---- main -----------------------------------------------------------------------------------------
 def collectives_table(agg, steps):
     """The timed steps' collectives: bytes THIS rank received and the time its compute stream spent in (or, for the overlapped
@@ -915,7 +1061,7 @@ def main(argv=None):
                          lambda: Assembly(torch, eng, 100, [(100, 784), (100,), (10, 100), (10,)], device, 1241, batched=True),
                          lambda: ClientStep(torch, eng, 100, 83, device, 1242)):
                 w2 = make()
-                k2 = 20
+                k2 = max(args.extras_steps, 1)
                 # these rounds are tens of microseconds long, where the per-launch HIP events are a visible share of
                 # the time: the throughput comes from a pass without them, the per-kernel table from a pass with them
                 e2, _ = timed_steps(torch, dist, w2, eng, k2, 3, 1, events=False)
@@ -933,25 +1079,21 @@ def main(argv=None):
                 # identical-row shortcut: c5s = the attack as the reference runs it (its m rows are ONE vector, the Gram runs
                 # over the N - m + 1 unique rows); c5u = 10,000 DISTINCT rows (an attacker who adds per-row noise: nothing to
                 # fold), the full N^2 D Gram.  Both with the 8-GPU projection.
-                for name in ('c5s', 'c5u'):
+                shared = None      # c5u leaves the matrix as generated (no write-back), so c5s can run on the same 125 GB after it
+                for name in ('c5u', 'c5s'):
                     w5 = BulyanSharded(torch, agg, eng, 10000, 3_125_000, device, 1237, with_attack=True, layout='columns',
-                                       distinct=name == 'c5u')
-                    rec = bulyan_record(torch, dist, w5, eng, agg, 5, 1, 1, traffic)
+                                       distinct=name == 'c5u', g=shared)
+                    shared = w5.g
+                    rec = bulyan_record(torch, dist, w5, eng, agg, max(args.north_star_steps, 1), 1, 1, traffic)
                     rec['projected'] = projected_scaling(w5, rec['kernels'], rec['ms_per_step'])
                     extras[name] = rec
                     w5.g = None
                     del w5
-                    torch.cuda.empty_cache()
+                del shared
+                torch.cuda.empty_cache()
             line['other_workloads'] = extras
     if rank == 0:
-        # RCCL writes its NCCL_DEBUG=VERSION banner through C stdio, which a pipe buffers until exit: push it out
-        # first so that the JSON line is the last thing on stdout
-        try:
-            import ctypes
-            ctypes.CDLL(None).fflush(None)
-        except OSError:
-            pass
-        print(json.dumps(line), flush=True)
+        emit(line, args.detail_file)
     if dist.is_initialized():
         dist.destroy_process_group()
 

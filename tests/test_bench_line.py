@@ -1,0 +1,122 @@
+"""The ONE stdout line of bench.py is what the driver parses.  Round 4's line had grown to 20 KB, the driver's 8 KB tail cut it
+and the round's record came back `parsed: null` (missing 1).  The line is now assembled by bench.compact_line under a
+byte budget; these tests build it from the largest record a run can produce -- through the same code -- and parse it."""
+import copy
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+
+CONTRACT_KEYS = ('metric', 'value', 'unit', 'n_gpus', 'ranks_seen', 'steps', 'warmup', 'ms_per_step', 'higher_is_better',
+                 'scaling', 'vs_baseline', 'dtype', 'data', 'config', 'roofline', 'cpu_baseline')
+
+
+def full_record():
+    """A complete detail record as a default run builds it: every leg present (headline, both sharded legs, the CPU baseline with
+    its two extra figures, ten side workloads, c5s and c5u with projections).  Recorded from a real run (profiles/, round 4)."""
+    with open(os.path.join(ROOT, 'tests', 'golden', 'bench_detail_sample.json')) as fh:
+        return json.load(fh)
+
+
+def inflate(rec):
+    """Worst case: every free-text field ten times as long, three times as many kernels and side workloads, collectives booked."""
+    rec = copy.deepcopy(rec)
+    rec['dtype'] = rec['dtype'] * 10
+    rec['config']['workload'] = rec['config']['workload'] * 10
+    rec['cpu_baseline']['sample'] = rec['cpu_baseline']['sample'] * 10
+    rec['roofline']['peak_note'] = rec['roofline']['peak_note'] * 10
+    for i in range(30):
+        rec['kernels']['kernel_with_a_long_name_%02d' % i] = {'ms_per_step': 1.0 / 3.0, 'launches_per_step': 7.0}
+        rec['other_workloads']['side_workload_number_%02d' % i] = copy.deepcopy(rec['other_workloads']['c3_D1000000'])
+    rec['collectives'] = {'all_reduce_gram_%d' % i: {'calls_per_step': 1.0, 'MB_per_step': 128.0, 'ms_per_step': 1.0 / 7.0}
+                          for i in range(12)}
+    rec['other_layout'] = copy.deepcopy(rec['other_workloads']['c5s'])
+    rec['other_layout']['layout'] = 'clients'
+    rec['detail_file'] = 'some/long/path/' * 8 + 'bench_detail.json'
+    return rec
+
+
+def check_line(text, want_all=True):
+    assert len(text) < 4096 and '\n' not in text
+    line = json.loads(text)
+    for key in CONTRACT_KEYS:
+        assert key in line, key
+    roof, cpu = line['roofline'], line['cpu_baseline']
+    for key in ('bound', 'achieved', 'peak', 'unit', 'frac', 'traffic'):
+        assert key in roof, key
+    assert abs(roof['frac'] - roof['achieved'] / roof['peak']) < 1e-3 * roof['frac']
+    for key in ('value', 'unit', 'cores', 'kind', 'sample'):
+        assert key in cpu, key
+    assert 'workload' in line['config'] and 'model' not in line['config']
+    assert abs(line['value'] * line['ms_per_step'] - 1e3) < 1e-3 * 1e3
+    return line
+
+
+def test_default_run_record_fits_with_every_section():
+    text = bench.compact_line(full_record())
+    line = check_line(text)
+    # a realistic record keeps all of its sections: nothing had to be dropped
+    for key in ('kernels_ms', 'north_star', 'others', 'projected', 'sharded_path_w1_ms', 'verified_after_timing'):
+        assert key in line, key
+    star = line['north_star']
+    assert star['c5u_target_met'] is False and star['c5s_target_met'] is True     # what round 4 measured
+    assert star['c5u']['projected_8'] < 1.0 < star['c5s']['projected_8']
+    assert len(text) < 3600          # headroom below the budget
+
+
+def test_worst_case_record_still_fits_and_keeps_the_contract():
+    text = bench.compact_line(inflate(full_record()))
+    line = check_line(text)
+    assert line['roofline']['kernel'] == 'gram_tile' and line['cpu_baseline']['kind'] == 'port'
+
+
+def test_minimal_record_no_cpu_baseline_no_extras():
+    rec = full_record()
+    for key in ('cpu_baseline', 'other_workloads', 'sharded_path_w1', 'projected'):
+        rec.pop(key, None)
+    line = json.loads(bench.compact_line(rec))
+    assert line['cpu_baseline'] is None and 'north_star' not in line and 'others' not in line
+    assert line['roofline']['frac'] > 0
+
+
+def test_emit_writes_the_detail_file_and_one_stdout_line(tmp_path, capfd):
+    rec = full_record()
+    path = str(tmp_path / 'detail.json')
+    bench.emit(rec, path)
+    out, err = capfd.readouterr()
+    lines = [ln for ln in out.splitlines() if ln.strip()]
+    assert len(lines) == 1 and err == ''
+    line = check_line(lines[0])
+    assert line['detail_file'] == path
+    with open(path) as fh:
+        stored = json.load(fh)
+    assert 'other_workloads' in stored and 'sharded_path_w1' in stored     # the long sections live here
+    # a tree that cannot be written to costs the detail file, never the line
+    bench.emit(full_record(), str(tmp_path / 'no_such_dir' / 'detail.json'))
+    out, err = capfd.readouterr()
+    check_line([ln for ln in out.splitlines() if ln.strip()][-1])
+    assert 'detail file not written' in err
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(600)
+def test_gpu_bench_prints_one_parsable_line(tmp_path):
+    """The bench as the driver runs it (short): the LAST line of stdout parses, fits the budget and carries the contract's keys;
+    stdout + stderr together stay inside the driver's 8 KB tail."""
+    path = str(tmp_path / 'detail.json')
+    proc = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '1', '--steps', '1', '--warmup', '1',
+                           '--clients', '1024', '--params', '262144', '--cpu-seconds', '6', '--no-north-star', '--extras-steps', '2',
+                           '--detail-file', path], capture_output=True, text=True, timeout=580)
+    assert proc.returncode == 0, proc.stderr[-3000:]
+    out_lines = [ln for ln in proc.stdout.splitlines() if ln.strip()]
+    line = check_line(out_lines[-1])
+    assert line['n_gpus'] == 1 and line['steps'] == 1 and line['roofline']['kernel'] == 'gram_tile'
+    assert line['cpu_baseline']['value'] > 0 and line['others']
+    assert len(proc.stdout) + len(proc.stderr) < 8000, (len(proc.stdout), len(proc.stderr))
+    assert os.path.isfile(path)
