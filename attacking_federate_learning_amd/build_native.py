@@ -33,7 +33,8 @@ EXTRA_FLAGS = {'trimmed_mean.hip': ['-fno-honor-nans'],
                'window_lean.hip': ['-mllvm', '-pragma-unroll-threshold=1000000'],
                'krum_small.hip': ['-mllvm', '-pragma-unroll-threshold=1000000'],
                # numpy arithmetic, operation by operation: no FMA contraction
-               'round_edges.hip': ['-ffp-contract=off']}
+               'round_edges.hip': ['-ffp-contract=off'],
+               'column_stats.hip': ['-ffp-contract=off']}
 COMMON_FLAGS = ['--offload-arch=' + ARCH, '-O3', '-std=c++17', '-fPIC', '-Wall', '-Wno-unused-function',
                 '-Wno-nan-infinity-disabled']
 
@@ -53,7 +54,8 @@ def _stale(target, deps):
 
 
 def _headers():
-    return [os.path.join(CSRC, 'common.hpp'), os.path.join(CSRC, 'lane_exchange.hpp'), os.path.join(HERE, '..', 'include', 'byzagg.h'), __file__]
+    import glob
+    return sorted(glob.glob(os.path.join(CSRC, '*.hpp'))) + [os.path.join(HERE, '..', 'include', 'byzagg.h'), __file__]
 
 
 # The host side under AddressSanitizer + UndefinedBehaviorSanitizer: same sources, kernels untouched

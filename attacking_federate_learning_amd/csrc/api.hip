@@ -201,7 +201,6 @@ void byz_ctx_destroy(byz_ctx* ctx) {
     ctx->gram_rep.release();
     ctx->near_sq.release();
     ctx->near_partial.release();
-    ctx->colstat_partials.release();
     ctx->sorted_idx.release();
     ctx->rank_t.release();
     ctx->sorted_val.release();

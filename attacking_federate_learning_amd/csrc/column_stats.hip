@@ -6,9 +6,10 @@
 //   Server.defend update  reference server.py:89-90     v = mu*v - lr*agg ; w += v
 //
 // Layout: G is row-major, so a wave reading 64 (or 256, with dwordx4) consecutive columns of one row is
-// a single coalesced request; each thread walks down the rows of its own column(s).  Sums are carried in
-// fp64 (free: the kernel moves 4 bytes per fp64 add) and the variance is taken about the first row's
-// value, so the fp32 reference result (two-pass) is reproduced to ~1 ulp without a second pass over HBM.
+// a single coalesced request; each thread walks down the rows of its own column(s) and adds them in row order in fp32:
+// the reference's numpy arithmetic operation by operation, so mean, std and the drifted vector are the reference's BITS
+// (the fp64 one-pass statistics of rounds 1-4 were 1 ulp off in a few columns, which moved median-window
+// decisions downstream).  The variance needs the mean first: the rows are walked twice.
 // Algorithmic traffic: 4*rows*cols bytes read + 4*cols written.
 #include "common.hpp"
 
@@ -26,81 +27,106 @@ int env_int(const char* name, int fallback) {
 constexpr int kThreads = 256;
 typedef float float4u __attribute__((ext_vector_type(4), aligned(4)));
 
-// partial layout: [split][2][n_cols] doubles (plane 0: sum of (x - x0), plane 1: sum of squares)
-template <int VEC, bool STATS>
-__global__ __launch_bounds__(kThreads) void column_partial_kernel(
-    const float* __restrict__ G, int64_t n_rows, int64_t n_cols, int64_t ld, int64_t rows_per_split,
-    double* __restrict__ partial) {
-    const int64_t c0 = (static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x) * VEC;
-    if (c0 >= n_cols) return;
-    const int64_t r_begin = static_cast<int64_t>(blockIdx.y) * rows_per_split;
-    const int64_t r_end = r_begin + rows_per_split < n_rows ? r_begin + rows_per_split : n_rows;
-    double s1[VEC], s2[VEC];
-    float x0[VEC];
-#pragma unroll
-    for (int v = 0; v < VEC; ++v) {
-        s1[v] = 0.0;
-        s2[v] = 0.0;
-        x0[v] = (STATS && c0 + v < n_cols) ? G[c0 + v] : 0.0f;
-    }
-    const float* p = G + r_begin * ld + c0;
-    const bool full = c0 + VEC <= n_cols;
-#pragma unroll 4
-    for (int64_t r = r_begin; r < r_end; ++r, p += ld) {
-        float x[VEC];
-        if constexpr (VEC == 4) {
-            if (full) {
-                const float4u q = *reinterpret_cast<const float4u*>(p);
-                x[0] = q.x; x[1] = q.y; x[2] = q.z; x[3] = q.w;
-            } else {
-#pragma unroll
-                for (int v = 0; v < VEC; ++v) x[v] = (c0 + v < n_cols) ? p[v] : 0.0f;
-            }
+// numpy's arithmetic for np.mean(rows, axis=0) and np.var(rows, axis=0) ** 0.5 on an (m, D) fp32 array, operation by operation
+// (tests/test_oracle_golden.py pins this model to numpy itself):
+//     s    = x[0] + x[1] + ... + x[m-1]          sequential fp32, in row order (a reduction over the OUTER axis is not pairwise)
+//     mean = s / float(m)
+//     s2   = sum over rows, sequential fp32, of  fl(fl(x[r] - mean) * fl(x[r] - mean))
+//     std  = sqrt(s2 / float(m))                 (`** 0.5` on an fp32 array is np.sqrt)
+//     drift = mean - fl(float(z) * std)
+// One thread owns VEC columns and walks the rows; the loads of a run of rows are issued together, the additions follow in row
+// order.  The chain starts from +0.0f, add.reduce's identity (a column of -0.0 sums to +0.0 in numpy, and here).
+// This file is compiled with -ffp-contract=off: no multiply may fuse with the addition that follows it.
+constexpr int kRowRun = 8;
+
+template <int VEC>
+__device__ __forceinline__ void load_columns(const float* __restrict__ p, bool full, int64_t c0, int64_t n_cols, float (&x)[VEC]) {
+    if constexpr (VEC == 4) {
+        if (full) {
+            const float4u q = *reinterpret_cast<const float4u*>(p);
+            x[0] = q.x; x[1] = q.y; x[2] = q.z; x[3] = q.w;
         } else {
-            x[0] = p[0];
-        }
 #pragma unroll
-        for (int v = 0; v < VEC; ++v) {
-            const double d = static_cast<double>(x[v]) - static_cast<double>(x0[v]);
-            s1[v] += d;
-            if (STATS) s2[v] += d * d;
+            for (int v = 0; v < VEC; ++v) x[v] = (c0 + v < n_cols) ? p[v] : 0.0f;
         }
-    }
-    double* out = partial + static_cast<int64_t>(blockIdx.y) * 2 * n_cols;
-#pragma unroll
-    for (int v = 0; v < VEC; ++v) {
-        if (c0 + v < n_cols) {
-            out[c0 + v] = s1[v];
-            if (STATS) out[n_cols + c0 + v] = s2[v];
-        }
+    } else {
+        x[0] = p[0];
     }
 }
 
-// Combines the row-split partials in a fixed order and writes mean / std / drift.
-template <bool STATS>
-__global__ __launch_bounds__(kThreads) void column_finalize_kernel(
-    const double* __restrict__ partial, const float* __restrict__ G, int64_t n_rows, int64_t n_cols,
-    int splits, float num_std, float* __restrict__ mean_out, float* __restrict__ std_out,
-    float* __restrict__ drift_out) {
-    const int64_t c = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x;
-    if (c >= n_cols) return;
-    double s1 = 0.0, s2 = 0.0;
-    for (int s = 0; s < splits; ++s) {
-        s1 += partial[static_cast<int64_t>(s) * 2 * n_cols + c];
-        if (STATS) s2 += partial[static_cast<int64_t>(s) * 2 * n_cols + n_cols + c];
+// MODE 0: mean only (no_defense).  MODE 1: mean, std, drift (the attack).
+// carry_in (optional, [VEC columns]): the chain continues a sum begun over earlier rows that live elsewhere (another rank's
+// clients); `total_rows` is the divisor (all rows of the chain, not only the local ones).
+template <int VEC, int MODE>
+__global__ __launch_bounds__(kThreads) void column_sequential_kernel(
+    const float* __restrict__ G, int64_t n_rows, int64_t n_cols, int64_t ld, float num_std,
+    float* __restrict__ mean_out, float* __restrict__ std_out, float* __restrict__ drift_out) {
+    const int64_t c0 = (static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x) * VEC;
+    if (c0 >= n_cols) return;
+    const bool full = c0 + VEC <= n_cols;
+    const float rows_f = static_cast<float>(n_rows);
+    float s[VEC];
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) s[v] = 0.0f;
+    const float* p = G + c0;
+    int64_t r = 0;
+    for (; r + kRowRun <= n_rows; r += kRowRun) {
+        float x[kRowRun][VEC];
+#pragma unroll
+        for (int u = 0; u < kRowRun; ++u) load_columns<VEC>(p + (r + u) * ld, full, c0, n_cols, x[u]);
+#pragma unroll
+        for (int u = 0; u < kRowRun; ++u)
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) s[v] = s[v] + x[u][v];
     }
-    const double inv = 1.0 / static_cast<double>(n_rows);
-    const double shift = STATS ? static_cast<double>(G[c]) : 0.0;
-    const double m1 = s1 * inv;
-    const float mean = static_cast<float>(shift + m1);
-    if (mean_out) mean_out[c] = mean;
-    if (STATS) {
-        double var = s2 * inv - m1 * m1;
-        var = var > 0.0 ? var : 0.0;
-        const float sd = static_cast<float>(sqrt(var));
-        if (std_out) std_out[c] = sd;
-        // malicious.py:35 evaluates mean - z*std on the fp32 values
-        if (drift_out) drift_out[c] = __fsub_rn(mean, __fmul_rn(num_std, sd));
+    for (; r < n_rows; ++r) {
+        float x[VEC];
+        load_columns<VEC>(p + r * ld, full, c0, n_cols, x);
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) s[v] = s[v] + x[v];
+    }
+    float mean[VEC];
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) {
+        mean[v] = s[v] / rows_f;
+        if (mean_out && c0 + v < n_cols) mean_out[c0 + v] = mean[v];
+    }
+    if constexpr (MODE == 1) {
+        float s2[VEC];
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) s2[v] = 0.0f;
+        r = 0;
+        for (; r + kRowRun <= n_rows; r += kRowRun) {
+            float x[kRowRun][VEC];
+#pragma unroll
+            for (int u = 0; u < kRowRun; ++u) load_columns<VEC>(p + (r + u) * ld, full, c0, n_cols, x[u]);
+#pragma unroll
+            for (int u = 0; u < kRowRun; ++u)
+#pragma unroll
+                for (int v = 0; v < VEC; ++v) {
+                    const float d = x[u][v] - mean[v];
+                    const float q = d * d;
+                    s2[v] = s2[v] + q;
+                }
+        }
+        for (; r < n_rows; ++r) {
+            float x[VEC];
+            load_columns<VEC>(p + r * ld, full, c0, n_cols, x);
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) {
+                const float d = x[v] - mean[v];
+                const float q = d * d;
+                s2[v] = s2[v] + q;
+            }
+        }
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) {
+            if (c0 + v >= n_cols) continue;
+            const float var = s2[v] / rows_f;
+            const float sd = __builtin_sqrtf(var);          // correctly rounded (hipcc's default for fp32 sqrt and divide)
+            if (std_out) std_out[c0 + v] = sd;
+            if (drift_out) drift_out[c0 + v] = mean[v] - num_std * sd;     // malicious.py:35 on the fp32 values
+        }
     }
 }
 
@@ -186,40 +212,21 @@ int column_pass(byz_ctx* ctx, const float* G, int64_t n_rows, int64_t n_cols, in
                 float num_std, float* mean, float* stdev, float* drift, hipStream_t stream) {
     BYZ_REQUIRE(G && n_rows > 0 && n_cols > 0 && ld >= n_cols, "column statistics: bad shape %lld x %lld ld %lld",
                 (long long)n_rows, (long long)n_cols, (long long)ld);
-    const bool vec4 = (ld % 4 == 0) && (reinterpret_cast<uintptr_t>(G) % 16 == 0) && n_cols >= 4 * kThreads;
-    const int vec = vec4 ? 4 : 1;
-    const int64_t col_blocks = ceil_div(n_cols, static_cast<int64_t>(kThreads) * vec);
-    // enough workgroups to cover the chip a few times over; rows are split when columns alone cannot
-    int64_t splits = ceil_div(static_cast<int64_t>(ctx->num_cus) * 8, col_blocks);
-    if (splits > ceil_div(n_rows, 8)) splits = ceil_div(n_rows, 8);
-    if (splits < 1) splits = 1;
-    const int64_t rows_per_split = ceil_div(n_rows, splits);
-    splits = ceil_div(n_rows, rows_per_split);
-    BYZ_TRY(ctx->colstat_partials.ensure(static_cast<size_t>(splits) * 2 * n_cols * sizeof(double)));
-    double* partial = ctx->colstat_partials.as<double>();
-    {
-        KernelTimer t(ctx, BYZ_K_COLUMN_STATS, stream);
-        dim3 grid(static_cast<unsigned>(col_blocks), static_cast<unsigned>(splits));
-        if (stats) {
-            if (vec4) column_partial_kernel<4, true><<<grid, kThreads, 0, stream>>>(G, n_rows, n_cols, ld, rows_per_split, partial);
-            else column_partial_kernel<1, true><<<grid, kThreads, 0, stream>>>(G, n_rows, n_cols, ld, rows_per_split, partial);
-        } else {
-            if (vec4) column_partial_kernel<4, false><<<grid, kThreads, 0, stream>>>(G, n_rows, n_cols, ld, rows_per_split, partial);
-            else column_partial_kernel<1, false><<<grid, kThreads, 0, stream>>>(G, n_rows, n_cols, ld, rows_per_split, partial);
-        }
-        BYZ_TRY(check_launch("column_partial_kernel"));
+    // 16-byte loads when every row starts 16-byte aligned and the columns alone fill the chip; one column per thread otherwise
+    // (few columns: four times the threads)
+    const bool vec4 = (ld % 4 == 0) && (reinterpret_cast<uintptr_t>(G) % 16 == 0) &&
+                      n_cols >= static_cast<int64_t>(4) * kThreads * ctx->num_cus * 2;
+    const int64_t col_blocks = ceil_div(n_cols, static_cast<int64_t>(kThreads) * (vec4 ? 4 : 1));
+    KernelTimer t(ctx, BYZ_K_COLUMN_STATS, stream);
+    const dim3 grid(static_cast<unsigned>(col_blocks));
+    if (stats) {
+        if (vec4) column_sequential_kernel<4, 1><<<grid, kThreads, 0, stream>>>(G, n_rows, n_cols, ld, num_std, mean, stdev, drift);
+        else column_sequential_kernel<1, 1><<<grid, kThreads, 0, stream>>>(G, n_rows, n_cols, ld, num_std, mean, stdev, drift);
+    } else {
+        if (vec4) column_sequential_kernel<4, 0><<<grid, kThreads, 0, stream>>>(G, n_rows, n_cols, ld, 0.0f, mean, nullptr, nullptr);
+        else column_sequential_kernel<1, 0><<<grid, kThreads, 0, stream>>>(G, n_rows, n_cols, ld, 0.0f, mean, nullptr, nullptr);
     }
-    {
-        KernelTimer t(ctx, BYZ_K_MISC, stream);
-        const unsigned blocks = static_cast<unsigned>(ceil_div(n_cols, kThreads));
-        if (stats)
-            column_finalize_kernel<true><<<blocks, kThreads, 0, stream>>>(partial, G, n_rows, n_cols, (int)splits, num_std, mean, stdev, drift);
-        else
-            column_finalize_kernel<false><<<blocks, kThreads, 0, stream>>>(partial, G, n_rows, n_cols, (int)splits, 0.0f, mean, nullptr, nullptr);
-        BYZ_TRY(check_launch("column_finalize_kernel"));
-    }
-    (void)vec;
-    return BYZ_OK;
+    return check_launch("column_sequential_kernel");
 }
 
 }  // namespace
@@ -239,7 +246,10 @@ int launch_broadcast_rows(byz_ctx* ctx, float* G, int64_t n_rows, int64_t n_cols
                           hipStream_t stream) {
     KernelTimer t(ctx, BYZ_K_MISC, stream);
     const bool wide = ld % 4 == 0 && (reinterpret_cast<uintptr_t>(G) & 15u) == 0 && (reinterpret_cast<uintptr_t>(vec) & 15u) == 0;
-    const int run = env_int("BYZ_BROADCAST_RUN", 16);      // 4 KiB pieces of a row a workgroup writes back to back (1, 2, 4, 8, 16)
+    // 4 KiB pieces of a row a workgroup writes back to back: one of the instantiated 1, 2, 4, 8, 16 (anything else is 16 --
+    // the grid below must be sized for the RUN that is launched)
+    int run = env_int("BYZ_BROADCAST_RUN", 16);
+    if (run != 1 && run != 2 && run != 4 && run != 8) run = 16;
     const int64_t per_wg = static_cast<int64_t>(kThreads) * (wide ? 4 : 1) * run;
     const unsigned blocks = static_cast<unsigned>(ceil_div(n_cols, per_wg));
     unsigned ysplit = static_cast<unsigned>(ceil_div(static_cast<int64_t>(ctx->num_cus) * 8, blocks));

@@ -122,7 +122,6 @@ struct byz_ctx {
     byz::Buffer near_partial;    // per (pair, column chunk) partial sums
     int64_t near_pair_capacity = 0;
     byz::Buffer dist;            // n x n fp32 distances (when the caller does not pass one)
-    byz::Buffer colstat_partials;  // row-split partial column sums
     byz::Buffer sorted_idx;      // n x n uint16: column index at every ascending rank
     byz::Buffer sorted_val;      // n x n fp32: every row's distances in ascending order (the reference-arithmetic re-score)
     byz::Buffer rank_t;          // n x n uint16: rank_t[w][u] = rank of column w in row u

@@ -164,6 +164,23 @@ def attack_statistics(rows):
     return mean, stdev
 
 
+def attack_statistics_sequential(rows):
+    """The same two lines as fp32 operations in the order numpy performs them (a reduction over the OUTER axis of a C-ordered
+    array is a plain loop over the rows, not a pairwise sum; `** 0.5` on an fp32 array is np.sqrt): the arithmetic
+    csrc/column_stats.hip implements.  tests/test_pipeline_golden.py holds it to `attack_statistics` bit for bit."""
+    a = np.asarray(rows, dtype=np.float32)
+    m = np.float32(a.shape[0])
+    s = np.zeros(a.shape[1], dtype=np.float32)        # add.reduce starts from its identity: a column of -0.0 sums to +0.0
+    for r in range(a.shape[0]):
+        s = s + a[r]
+    mean = s / m
+    s2 = np.zeros(a.shape[1], dtype=np.float32)
+    for r in range(a.shape[0]):
+        d = a[r] - mean
+        s2 = s2 + d * d
+    return mean, np.sqrt(s2 / m)
+
+
 def drift_vector(rows, num_std):
     """malicious.py:18-24,34-36: the vector every malicious client submits."""
     mean, stdev = attack_statistics(rows)

@@ -262,7 +262,7 @@ def test_config5_flow_n10000(eng):
     g = torch.from_numpy(g_host).cuda()
     drift, mean, std = eng.drift_attack(g[:f], 1.5, write_back=True)
     want_drift = faithful.drift_vector(g_host[:f].copy(), 1.5)
-    assert close(drift.cpu().numpy(), want_drift)
+    assert np.array_equal(drift.cpu().numpy(), want_drift)      # m = 2400 rows: the reference's bits
     g_host[:f] = drift.cpu().numpy()
     assert torch.equal(g[:f], drift[None, :].expand(f, d))
     dist = eng.pairwise_distances(g)
