@@ -385,17 +385,16 @@ struct Frags<2, MB> {
 // DBG (timing experiments only, wrong results; scripts/gram_ab.py): bit 0 no DMA after the first NBUF stages,
 // bit 1 no MFMA, bit 2 no workgroup barrier in the steady loop, bit 3 no LDS reads after stage 0, bit 4 no slab update,
 // bit 5 every workgroup's DMA reads tile (0, 0) (the L2 -> LDS rate without misses).
-// MB = 32-row blocks of a wave's sub-tile along the A side: 2 -> eight waves of 64 x 64 (two per SIMD, round 2's geometry),
-// 4 -> FOUR waves of 128 x 64, one per SIMD with the 512-register budget (accumulators in AGPRs): a quarter fewer LDS fragment
-// reads per MFMA (12 ds_read_b128 per 24 MFMAs instead of 8 per 12), the same DMA bytes.  Every output element goes through
-// the same MFMA chain in the same order either way: the Gram is bitwise the same (BYZ_GRAM_WAVE_TILE).
+// MB = 32-row blocks of a wave's sub-tile along the A side: 2 -> eight waves of 64 x 64, two per SIMD.  (MB = 4, four waves of
+// 128 x 64, was built in round 4, is bitwise equal and lost by 8.6 %: EXPERIMENTS.md G4; only MB = 2 is instantiated.)
 template <int PLANES, int NBUF, int DBG, int MB = 2>
 __global__ __launch_bounds__(64 * 16 / MB, 1) void gram_planes_kernel(const u32x4* __restrict__ planes, int64_t n_steps,
                                                                   const double* __restrict__ unscale, int64_t rows_pad,
                                                                   double* __restrict__ partial, int n_tiles,
                                                                   const int2* __restrict__ tile_order, int n_chunks,
                                                                   int* __restrict__ tickets, int round_size, int t128,
-                                                                  int slab_live0, int32_t* __restrict__ device_status) {
+                                                                  int slab_live0, int n_blocks32,
+                                                                  int32_t* __restrict__ device_status) {
     constexpr int kRbBytes = PLANES * kFragBytes;           // one 32-row block, one stage: [plane][1 KiB]
     constexpr int kStage = kRowBlocks * kRbBytes;           // 36,864 (bf16x3) / 24,576 (f16x2)
     constexpr int NW = 16 / MB;                             // waves of the workgroup
@@ -443,7 +442,30 @@ __global__ __launch_bounds__(64 * 16 / MB, 1) void gram_planes_kernel(const u32x
     const int wr = wave >> 1, wc = wave & 1;
     const int ti = 2 * bi + (wr * MB) / 4;             // this wave's slab row
     const int row_in_slab = ((wr * MB) % 4) * 32;      // and where its sub-tile starts inside it
-    const bool live_wave = tj <= ti && ti < t128;      // the upper half of a tile that straddles the diagonal is not needed
+    // Which of the wave's MB x 2 output blocks (32 x 32) anybody reads: block (m, n) covers 32-row block `rblk` of the A side and
+    // `cblk` of the B side.  Not needed: blocks of rows past the matrix (N = 4000 pads to 4096: three quarters of the last slab
+    // row; N = 10,000 to 10,112), and blocks strictly above the diagonal (gram_reduce_kernel reads a diagonal slab's lower
+    // triangle only).  Round 4 skipped at slab granularity only and issued 8 % more MFMAs than 3 N^2 D / 32768 at N = 4000
+    // (VERDICT r4, weak 5).  A skipped block is never multiplied, never flushed and never touches its slab entries; the blocks
+    // that are computed go through the same MFMA chain in the same order as before: the Gram is bitwise the same.
+    unsigned live_blocks = 0;
+    if (tj <= ti && ti < t128 && n_blocks32 < 0) {
+        live_blocks = (1u << (MB * 2)) - 1u;     // BYZ_GRAM_BLOCK_SKIP=0: round 4's slab-granular rule, for the same-box A/B
+    } else if (tj <= ti && ti < t128) {     // the upper half of a tile that straddles the diagonal is not needed
+#pragma unroll
+        for (int m = 0; m < MB; ++m)
+#pragma unroll
+            for (int n = 0; n < 2; ++n) {
+                const int rblk = ti * 4 + row_in_slab / 32 + m, cblk = tj * 4 + wc * 2 + n;
+                if (rblk < n_blocks32 && cblk <= rblk) live_blocks |= 1u << (m * 2 + n);
+            }
+    }
+    // The K loop is instantiated once per mask that can occur (MB = 2, bit m * 2 + n): all four blocks; the row block m = 0
+    // only (the last valid row block of the matrix is the first of its wave); a diagonal 64 x 64 sub-tile without its upper
+    // block; both; nothing (a dead wave still takes part in the DMA and the barriers).  A run-time test per MFMA instead cost the
+    // compiler its schedule (a wait for ALL pending LDS reads in front of every MFMA).
+    static_assert(MB == 2, "the mask set below is the one of 64 x 64 wave tiles");
+    const bool live_wave = live_blocks != 0;
 
     const int step0 = chunk * kChunkSteps;
     int n_stages = static_cast<int>(n_steps) - step0;
@@ -486,42 +508,44 @@ __global__ __launch_bounds__(64 * 16 / MB, 1) void gram_planes_kernel(const u32x
                 acc2[m][n][e] = 0.0f;
             }
 
-    auto read_frags = [&](int s, frags_t& f) __attribute__((always_inline)) {
+    auto read_frags = [&](int s, frags_t& f, auto mask_c) __attribute__((always_inline)) {
+        constexpr unsigned MASK = decltype(mask_c)::value;     // only the fragments a live block multiplies
         if ((DBG & 8) && s > 0) return;
         const unsigned char* A = lds + (s % NBUF) * kStage + (MB * wr) * kRbBytes + lane * 16;
         const unsigned char* B = lds + (s % NBUF) * kStage + (8 + 2 * wc) * kRbBytes + lane * 16;
 #pragma unroll
         for (int p = 0; p < PLANES; ++p) {
 #pragma unroll
-            for (int m = 0; m < MB; ++m) f.a[p][m] = *reinterpret_cast<const frag_t*>(A + m * kRbBytes + p * kFragBytes);
+            for (int m = 0; m < MB; ++m)
+                if (((MASK >> (m * 2)) & 3u) != 0) f.a[p][m] = *reinterpret_cast<const frag_t*>(A + m * kRbBytes + p * kFragBytes);
 #pragma unroll
-            for (int n = 0; n < 2; ++n) f.b[p][n] = *reinterpret_cast<const frag_t*>(B + n * kRbBytes + p * kFragBytes);
+            for (int n = 0; n < 2; ++n)
+                if (((MASK >> n) & 5u) != 0) f.b[p][n] = *reinterpret_cast<const frag_t*>(B + n * kRbBytes + p * kFragBytes);
         }
     };
-    auto multiply = [&](const frags_t& f) __attribute__((always_inline)) {
+    // TERMS of the split product, smallest first, term-major over the accumulators (bf16x3: the order of gram.hip's split mode)
+    auto mfma_term = [&](const frags_t& f, int t, int m, int n) __attribute__((always_inline)) {
         if constexpr (PLANES == 3) {
-            // h h' + h m' + m h' + m m' + h l' + l h', smallest terms first, term-major over the four accumulators:
-            // the order of gram.hip's split mode
+            // h h' + h m' + m h' + m m' + h l' + l h'
             constexpr int pa[6] = {2, 0, 1, 1, 0, 0};
             constexpr int pb[6] = {0, 2, 1, 0, 1, 0};
-#pragma unroll
-            for (int t = 0; t < 6; ++t)
-#pragma unroll
-                for (int m = 0; m < MB; ++m)
-#pragma unroll
-                    for (int n = 0; n < 2; ++n)
-                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[pa[t]][m], f.b[pb[t]][n], acc[m][n], 0, 0, 0);
+            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[pa[t]][m], f.b[pb[t]][n], acc[m][n], 0, 0, 0);
         } else {
             constexpr int pa[3] = {1, 0, 0};   // m h' + h m' + h h'
             constexpr int pb[3] = {0, 1, 0};
-#pragma unroll
-            for (int t = 0; t < 3; ++t)
-#pragma unroll
-                for (int m = 0; m < MB; ++m)
-#pragma unroll
-                    for (int n = 0; n < 2; ++n)
-                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.a[pa[t]][m], f.b[pb[t]][n], acc[m][n], 0, 0, 0);
+            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.a[pa[t]][m], f.b[pb[t]][n], acc[m][n], 0, 0, 0);
         }
+    };
+    constexpr int kTerms = PLANES == 3 ? 6 : 3;
+    auto multiply = [&](const frags_t& f, auto mask_c) __attribute__((always_inline)) {
+        constexpr unsigned MASK = decltype(mask_c)::value;
+#pragma unroll
+        for (int t = 0; t < kTerms; ++t)
+#pragma unroll
+            for (int m = 0; m < MB; ++m)
+#pragma unroll
+                for (int n = 0; n < 2; ++n)
+                    if (((MASK >> (m * 2 + n)) & 1u) != 0) mfma_term(f, t, m, n);   // folds: the loops are unrolled
     };
     auto flush = [&](int s) __attribute__((always_inline)) {
         if ((s + 1) % kFlushSteps == 0) {
@@ -537,11 +561,12 @@ __global__ __launch_bounds__(64 * 16 / MB, 1) void gram_planes_kernel(const u32x
         }
     };
     // one stage: multiply `cur` (stage s, in registers), read stage s + 1 into `next`, keep the DMA kLead stages ahead
-    auto steady = [&](int s, const frags_t& cur, frags_t& next) __attribute__((always_inline)) {
+    auto steady = [&](int s, const frags_t& cur, frags_t& next, auto mask_c) __attribute__((always_inline)) {
+        constexpr bool kLive = decltype(mask_c)::value != 0;
         dma(s + kLead);                       // into the buffer of stage s, whose last readers passed the previous barrier
-        if (live_wave && !(DBG & 2)) {
-            read_frags(s + 1, next);
-            multiply(cur);
+        if (kLive && !(DBG & 2)) {
+            read_frags(s + 1, next, mask_c);
+            multiply(cur, mask_c);
         }
         // before anyone reads stage s + 2 it must have landed: of my requests only stages s + 3 .. s + kLead may be
         // outstanding (memory reads return in order, so that is a vmcnt bound)
@@ -549,39 +574,52 @@ __global__ __launch_bounds__(64 * 16 / MB, 1) void gram_planes_kernel(const u32x
         else wait_vmcnt<(kLead - 2) * (kPerWave - 1)>();
         if (DBG & 4) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         else asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        if (live_wave) flush(s);
+        if (kLive) flush(s);
     };
-    auto drain = [&](int s, const frags_t& cur, frags_t& next) __attribute__((always_inline)) {
+    auto drain = [&](int s, const frags_t& cur, frags_t& next, auto mask_c) __attribute__((always_inline)) {
+        constexpr bool kLive = decltype(mask_c)::value != 0;
         if (s + kLead < n_stages) dma(s + kLead);
-        if (live_wave && !(DBG & 2)) {
-            if (s + 1 < n_stages) read_frags(s + 1, next);
-            multiply(cur);
+        if (kLive && !(DBG & 2)) {
+            if (s + 1 < n_stages) read_frags(s + 1, next, mask_c);
+            multiply(cur, mask_c);
         }
         const int last = s + kLead < n_stages ? s + kLead : n_stages - 1;
         const int ahead = last - (s + 2);
         wait_vmcnt_dyn((ahead > 0 ? ahead : 0) * my_dmas);
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        if (live_wave) flush(s);
+        if (kLive) flush(s);
     };
 
-    frags_t x, y;
     for (int a = 0; a < kLead && a < n_stages; ++a) dma(a);
     {
         const int issued = n_stages < kLead ? n_stages : kLead;
         wait_vmcnt_dyn((issued > 2 ? issued - 2 : 0) * my_dmas);   // stages 0 and 1 have landed
     }
     asm volatile("s_barrier" ::: "memory");
-    if (live_wave && !(DBG & 2) && n_stages > 0) read_frags(0, x);
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");    // everybody has read stage 0: its buffer may be refilled
-    int s = 0;
-    for (; s + 1 + kLead < n_stages; s += 2) {
-        steady(s, x, y);
-        steady(s + 1, y, x);
+    auto k_loop = [&](auto mask_c) __attribute__((always_inline)) {
+        constexpr bool kLive = decltype(mask_c)::value != 0;
+        frags_t x, y;
+        if (kLive && !(DBG & 2) && n_stages > 0) read_frags(0, x, mask_c);
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");    // everybody has read stage 0: its buffer may be refilled
+        int s = 0;
+        for (; s + 1 + kLead < n_stages; s += 2) {
+            steady(s, x, y, mask_c);
+            steady(s + 1, y, x, mask_c);
+        }
+        for (; s < n_stages; s += 2) {
+            drain(s, x, y, mask_c);
+            if (s + 1 < n_stages) drain(s + 1, y, x, mask_c);
+        }
+    };
+    // wave-uniform; every instantiation passes the same barriers.  A mask outside the set (there is none) computes all four.
+    switch (live_blocks) {
+        case 0u: k_loop(std::integral_constant<unsigned, 0u>{}); break;
+        case 1u: k_loop(std::integral_constant<unsigned, 1u>{}); break;
+        case 3u: k_loop(std::integral_constant<unsigned, 3u>{}); break;
+        case 13u: k_loop(std::integral_constant<unsigned, 13u>{}); break;
+        default: live_blocks = 15u; k_loop(std::integral_constant<unsigned, 15u>{}); break;
     }
-    for (; s < n_stages; s += 2) {
-        drain(s, x, y);
-        if (s + 1 < n_stages) drain(s + 1, y, x);
-    }
+    auto block_live = [&](int m, int n) __attribute__((always_inline)) { return ((live_blocks >> (m * 2 + n)) & 1u) != 0; };
 
     // epilogue: chunks of a tile add into its slabs in chunk order (gram.hip's ticket protocol)
     bool lost = false;
@@ -620,6 +658,7 @@ __global__ __launch_bounds__(64 * 16 / MB, 1) void gram_planes_kernel(const u32x
         for (int m = 0; m < MB; ++m)
 #pragma unroll
             for (int n = 0; n < 2; ++n) {
+                if (!block_live(m, n)) continue;     // nobody reads this block of the slab
                 const int j = wc * 64 + n * 32 + (lane & 31);
                 double uj = 1.0;
                 if constexpr (PLANES == 2) uj = un[static_cast<int64_t>(tj) * kSlab + j];
@@ -717,34 +756,30 @@ int launch_gram_planes(byz_ctx* ctx, const float* G, int64_t n_rows, int64_t n_c
     }
     int* tickets = ctx->gram_tickets.as<int>();
     u32x4* planes = ctx->gram_planes.as<u32x4>();
-    // BYZ_GRAM_PLANES_VARIANT: 0 production; 4: f16x2 with four LDS stages; the others are timing experiments with wrong
-    // results (the DBG bits of the kernel, times ten)
-    int variant = env_int("BYZ_GRAM_PLANES_VARIANT", 0);
-    if (variant == 0 && f16 && env_int("BYZ_GRAM_WAVE_TILE", 64) == 128) variant = 1280;
-    const int threads = (f16 && variant >= 1280 && variant <= 1282) ? 256 : kThreads;
     typedef void (*kernel_t)(const u32x4*, int64_t, const double*, int64_t, double*, int, const int2*, int, int*, int, int,
-                             int, int32_t*);
-    kernel_t kernel;
-    int nbuf;
-    if (f16) {
-        nbuf = variant == 4 ? 4 : 6;
-        kernel = variant == 10 ? &gram_planes_kernel<2, 6, 1> : variant == 20 ? &gram_planes_kernel<2, 6, 2>
-                 : variant == 4 ? &gram_planes_kernel<2, 4, 0>
-                 : variant == 50 ? &gram_planes_kernel<2, 6, 5>      // no DMA, no barrier
-                 : variant == 90 ? &gram_planes_kernel<2, 6, 9>      // no DMA, no LDS reads
-                 : variant == 130 ? &gram_planes_kernel<2, 6, 13>    // the MFMAs, the loop and the slab update only
-                 : variant == 160 ? &gram_planes_kernel<2, 6, 16>    // everything but the slab update
-                 : variant == 340 ? &gram_planes_kernel<2, 6, 34>    // DMA only, every workgroup the same tile
-                 : variant == 320 ? &gram_planes_kernel<2, 6, 32>    // everything, every workgroup the same tile
-                 : variant == 1280 ? &gram_planes_kernel<2, 6, 0, 4>   // 128 x 64 wave tiles, one wave per SIMD
-                 : variant == 1281 ? &gram_planes_kernel<2, 6, 13, 4>  //   ... its MFMAs, loop and slab update only
-                 : variant == 1282 ? &gram_planes_kernel<2, 6, 1, 4>   //   ... without the DMA
-                                   : &gram_planes_kernel<2, 6, 0>;
-    } else {
-        nbuf = 4;
-        kernel = variant == 10 ? &gram_planes_kernel<3, 4, 1> : variant == 20 ? &gram_planes_kernel<3, 4, 2>
-                                                                              : &gram_planes_kernel<3, 4, 0>;
+                             int, int, int32_t*);
+    kernel_t kernel = f16 ? &gram_planes_kernel<2, 6, 0> : &gram_planes_kernel<3, 4, 0>;
+    int nbuf = f16 ? 6 : 4;
+    const int threads = kThreads;
+#ifdef BYZ_GRAM_DEBUG_VARIANTS
+    // Timing experiments with WRONG results (the DBG bits of the kernel, times ten; scripts/gram_ab.py, EXPERIMENTS.md G1-G3).
+    // Not compiled into the shipped library: build with -DBYZ_GRAM_DEBUG_VARIANTS to get them back.
+    {
+        const int variant = env_int("BYZ_GRAM_PLANES_VARIANT", 0);
+        if (f16) {
+            kernel = variant == 10 ? &gram_planes_kernel<2, 6, 1> : variant == 20 ? &gram_planes_kernel<2, 6, 2>
+                     : variant == 50 ? &gram_planes_kernel<2, 6, 5>      // no DMA, no barrier
+                     : variant == 90 ? &gram_planes_kernel<2, 6, 9>      // no DMA, no LDS reads
+                     : variant == 130 ? &gram_planes_kernel<2, 6, 13>    // the MFMAs, the loop and the slab update only
+                     : variant == 160 ? &gram_planes_kernel<2, 6, 16>    // everything but the slab update
+                     : variant == 340 ? &gram_planes_kernel<2, 6, 34>    // DMA only, every workgroup the same tile
+                     : variant == 320 ? &gram_planes_kernel<2, 6, 32>    // everything, every workgroup the same tile
+                                      : kernel;
+        } else {
+            kernel = variant == 10 ? &gram_planes_kernel<3, 4, 1> : variant == 20 ? &gram_planes_kernel<3, 4, 2> : kernel;
+        }
     }
+#endif
     const size_t lds_bytes = static_cast<size_t>(nbuf) * kRowBlocks * n_planes * kFragBytes;
     BYZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 static_cast<int>(lds_bytes)));
@@ -794,7 +829,7 @@ int launch_gram_planes(byz_ctx* ctx, const float* G, int64_t n_rows, int64_t n_c
             kernel<<<static_cast<unsigned>(grid), threads, lds_bytes, stream>>>(
                 planes, n_steps, unscale, rows_pad, slabs, static_cast<int>(n_tiles), ctx->plane_order.as<int2>(),
                 static_cast<int>(n_chunks), tickets, round_size, static_cast<int>(t128), sc > 0 ? 1 : 0,
-                device_status_word(ctx));
+                env_int("BYZ_GRAM_BLOCK_SKIP", 1) != 0 ? static_cast<int>(ceil_div(n_rows, 32)) : -1, device_status_word(ctx));
             BYZ_TRY(check_launch("gram_planes_kernel"));
         }
     }

@@ -1,5 +1,9 @@
-"""Same-box A/B of the long-K Gram tile kernel's schedules (BYZ_GRAM_PLANES_VARIANT; torch-free GPU probe): time per call of
-the tile kernel, alternated, and whether the Gram is bitwise the production schedule's."""
+"""Same-box A/B of the long-K Gram tile kernel (torch-free GPU probe): time per call of the tile kernel under each setting,
+alternated, and whether the Gram is bitwise the first setting's.
+
+    python scripts/gram_ab.py BYZ_GRAM_BLOCK_SKIP=0,BYZ_GRAM_BLOCK_SKIP=1 4000 262224
+    python scripts/gram_ab.py 0,20 ...          a bare number is a BYZ_GRAM_PLANES_VARIANT (needs a -DBYZ_GRAM_DEBUG_VARIANTS build)
+"""
 import os
 import sys
 import numpy as np
@@ -32,7 +36,11 @@ def main():
     for rep in range(2):
         for v in variants:
             opts = v.split(':')                                           # "0:r0" = variant 0 without the round gate
-            os.environ['BYZ_GRAM_PLANES_VARIANT'] = opts[0]
+            if '=' in opts[0]:
+                key, val = opts[0].split('=', 1)
+                os.environ[key] = val
+            else:
+                os.environ['BYZ_GRAM_PLANES_VARIANT'] = opts[0]
             os.environ['BYZ_GRAM_ROUND'] = '0' if 'r0' in opts[1:] else '32'
             res = eng.gram(buf)
             eng.check()

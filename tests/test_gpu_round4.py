@@ -99,11 +99,14 @@ def test_twins_in_row_blocks_split_at_different_scales(eng, monkeypatch, n, twin
     assert got == scale.bulyan_selection(dist, n, f)
 
 
-@pytest.mark.parametrize('n,d,dup', [(2900, 3 * 8192 + 100, 0), (3300, 2 * 8192 + 33 * 32 + 4, 700), (4000, 5 * 8192 + 36, 0)])
-def test_gram_with_128x64_wave_tiles_is_bitwise_the_production_gram(eng, monkeypatch, n, d, dup):
-    """gram_planes_kernel<2, 6, 0, MB = 4>: four waves of 128 x 64 (one per SIMD, accumulators in AGPRs) instead of eight of
-    64 x 64.  Every Gram entry goes through the same MFMA chain in the same order: the fp64 Gram must be IDENTICAL, with a
-    ragged K tail, an odd number of slab rows, several super-chunks and the identical-row indirection."""
+@pytest.mark.parametrize('n,d,dup', [(2900, 3 * 8192 + 100, 0), (3300, 2 * 8192 + 33 * 32 + 4, 700), (4000, 5 * 8192 + 36, 0),
+                                     (2817, 2 * 8192 + 7, 0), (3009, 8192 + 640, 0)])
+def test_gram_with_skipped_blocks_is_bitwise_the_slab_granular_gram(eng, monkeypatch, n, d, dup):
+    """Round 5: gram_planes_kernel no longer multiplies 32 x 32 blocks nobody reads (rows past the matrix, blocks strictly above
+    the diagonal of a diagonal slab).  Every block that IS computed goes through the same MFMA chain in the
+    same order as under round 4's slab-granular rule (BYZ_GRAM_BLOCK_SKIP=0): the fp64 Gram must be IDENTICAL -- with a ragged K
+    tail, row counts that leave 1 / 2 / 3 / 4 valid row blocks in the last slab, several super-chunks and the identical-row
+    indirection -- and equal to fp64 on sampled entries."""
     torch = pytest.importorskip('torch')
     gen = torch.Generator(device='cuda').manual_seed(4100 + n)
     g = torch.randn((n, d), generator=gen, device='cuda', dtype=torch.float32)
@@ -112,15 +115,22 @@ def test_gram_with_128x64_wave_tiles_is_bitwise_the_production_gram(eng, monkeyp
         g[torch.randperm(n, device='cuda')[:dup]] = g[7].clone()
     monkeypatch.delenv('BYZ_GRAM_MODE', raising=False)
     monkeypatch.setenv('BYZ_GRAM_PLANES', '1')
-    monkeypatch.setenv('BYZ_GRAM_WAVE_TILE', '64')
+    monkeypatch.setenv('BYZ_GRAM_BLOCK_SKIP', '0')
     base = eng.gram(g).clone()
-    monkeypatch.setenv('BYZ_GRAM_WAVE_TILE', '128')
-    wide = eng.gram(g).clone()
+    monkeypatch.setenv('BYZ_GRAM_BLOCK_SKIP', '1')
+    lean = eng.gram(g).clone()
     monkeypatch.setenv('BYZ_GRAM_PLANE_MB', '300')
-    wide_many = eng.gram(g).clone()
+    lean_many = eng.gram(g).clone()
     eng.check()
-    assert torch.equal(base, wide), float((base - wide).abs().max())
-    assert torch.equal(base, wide_many)
+    assert torch.equal(base, lean), float((base - lean).abs().max())
+    assert torch.equal(base, lean_many)
+    assert torch.equal(lean, lean.T)
+    # the last rows and the diagonal against fp64
+    rows = torch.tensor([0, 1, 31, 32, 63, 64, 127, 128, n - 33, n - 32, n - 2, n - 1], device='cuda')
+    want = g[rows].double() @ g.double().T
+    got = lean[rows]
+    scale = (g.double() ** 2).sum(1).sqrt()
+    assert float(((got - want).abs() / (scale[rows][:, None] * scale[None, :])).max()) < 3e-7
 
 
 def test_collect_gradients_writes_all_device_clients_in_one_launch(eng, golden):
