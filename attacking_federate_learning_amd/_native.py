@@ -55,6 +55,7 @@ _PROTOTYPES = {
     'byz_backdoor_clip_dev': [c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_f32, c_f32, c_vp, c_vp],
     'byz_assemble_row_dev': [c_vp, c_vp, c_i64, c_i64, c_i64, c_i64, c_i64, c_vp, c_vp, c_vp],
     'byz_assemble_rows_dev': [c_vp, c_vp, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_vp, c_vp, c_vp],
+    'byz_assemble_rows_again_dev': [c_vp, c_vp, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_vp],
     'byz_assemble_columns_dev': [c_vp, c_vp, c_i64, c_i64, c_i64, c_i64, c_vp, c_vp, c_vp],
     'byz_assemble_row_host': [c_vp, c_vp, c_i64, c_i64, c_i64, c_i64, c_vp, c_vp],
     'byz_defend_host': [c_vp, c_int, c_vp, c_i64, c_i64, c_i64, c_i64, c_int, c_vp, c_vp],

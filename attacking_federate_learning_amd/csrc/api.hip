@@ -423,7 +423,16 @@ int byz_krum_dev(byz_ctx* ctx, const float* G, int64_t n_rows, int64_t n_cols, i
         // the reference's own sizes: two launches (krum_small.hip), the row copy is part of the second
         ctx->row_map_rows = 0;
         const int64_t prefix = python_prefix_len(n_rows - 1, users_count - corrupted_count);
-        BYZ_TRY(launch_small_krum(ctx, G, n_rows, n_cols, ld, ctx->dist.as<float>(), prefix, winner, out_row, s));
+        if (ctx->num_cus >= n_rows) {
+            BYZ_TRY(launch_small_krum(ctx, G, n_rows, n_cols, ld, ctx->dist.as<float>(), prefix, winner, out_row, s));
+        } else {
+            // the two-launch form has every row's workgroup wait for all the others' scores: they must all be resident at once
+            // (one workgroup per CU).  On a device or partition with fewer CUs than rows (a CPX partition has 32) the first wave
+            // of workgroups would spin to the limit and the call fail with the status word set: take the
+            // four-launch form, which has no wait across workgroups.
+            BYZ_TRY(launch_small_distances(ctx, G, n_rows, n_cols, ld, ctx->dist.as<float>(), s));
+            BYZ_TRY(launch_small_select(ctx, ctx->dist.as<float>(), n_rows, prefix, G, n_cols, ld, winner, out_row, s));
+        }
     } else {
         BYZ_TRY(launch_gram(ctx, G, n_rows, n_cols, ld, ctx->gram.as<double>(), s));
         BYZ_TRY(launch_distances_from_gram(ctx, ctx->gram.as<double>(), n_rows, ctx->dist.as<float>(), s, G, n_cols, ld));
@@ -574,6 +583,16 @@ int byz_assemble_rows_dev(byz_ctx* ctx, float* G, int64_t n_rows, int64_t n_cols
     BYZ_REQUIRE(n_segments > 0 && segments_dev && lengths, "assemble_rows: no segments");
     return launch_assemble_rows(ctx, G + first_row * ld, n_cols, ld, n_clients, n_segments, segments_dev, lengths,
                                 as_stream(stream));
+}
+
+int byz_assemble_rows_again_dev(byz_ctx* ctx, float* G, int64_t n_rows, int64_t n_cols, int64_t ld, int64_t first_row,
+                                int64_t n_clients, int64_t n_segments, void* stream) {
+    BYZ_TRY(enter(ctx));
+    BYZ_TRY(check_matrix(G, n_rows, n_cols, ld, "assemble_rows_again"));
+    BYZ_REQUIRE(first_row >= 0 && n_clients > 0 && first_row + n_clients <= n_rows,
+                "assemble_rows_again: rows %lld .. %lld outside 0..%lld", (long long)first_row,
+                (long long)(first_row + n_clients - 1), (long long)n_rows - 1);
+    return launch_assemble_rows_again(ctx, G + first_row * ld, n_cols, ld, n_clients, n_segments, as_stream(stream));
 }
 
 int byz_assemble_columns_dev(byz_ctx* ctx, float* G, int64_t n_rows, int64_t n_cols, int64_t ld, int64_t n_segments,

@@ -141,6 +141,7 @@ struct byz_ctx {
     byz::Buffer assemble_table;  // byz_assemble_rows_dev: segment starts + every client's tensor pointers
     std::vector<int64_t> assemble_host;   // its host image: owned by the context, because an async copy out of pageable memory
     hipEvent_t assemble_copied = nullptr; // may still be reading it when the call returns; recorded behind that copy
+    int64_t assemble_clients = 0, assemble_segments = 0, assemble_longest = 0, assemble_total = 0;   // what the device table holds
     byz::Buffer stage_in;        // device copy of a host matrix
     byz::Buffer stage_out;       // device result before download
     byz::PinnedBuffer pinned;    // host bounce buffer for small results
@@ -223,6 +224,8 @@ int launch_assemble_row(byz_ctx* ctx, float* row, int64_t n_cols, int64_t n_segm
                         const int64_t* lengths, hipStream_t stream);
 int launch_assemble_columns(byz_ctx* ctx, float* G, int64_t n_rows, int64_t n_cols, int64_t ld, int64_t n_segments,
                             const float* const* segments, const int64_t* lengths, hipStream_t stream);
+int launch_assemble_rows_again(byz_ctx* ctx, float* G, int64_t n_cols, int64_t ld, int64_t n_clients, int64_t n_segments,
+                               hipStream_t stream);
 int launch_assemble_rows(byz_ctx* ctx, float* G, int64_t n_cols, int64_t ld, int64_t n_clients, int64_t n_segments,
                          const float* const* segments, const int64_t* lengths, hipStream_t stream);
 

@@ -244,8 +244,23 @@ int launch_assemble_rows(byz_ctx* ctx, float* G, int64_t n_cols, int64_t ld, int
     BYZ_TRY(ctx->assemble_table.ensure(table.size() * sizeof(int64_t)));
     BYZ_HIP(hipMemcpyAsync(ctx->assemble_table.ptr, table.data(), table.size() * sizeof(int64_t), hipMemcpyHostToDevice, stream));
     BYZ_HIP(hipEventRecord(ctx->assemble_copied, stream));
+    ctx->assemble_clients = n_clients;
+    ctx->assemble_segments = n_segments;
+    ctx->assemble_longest = longest;
+    ctx->assemble_total = total;
+    return launch_assemble_rows_again(ctx, G, n_cols, ld, n_clients, n_segments, stream);
+}
+
+// The launch alone, from the table the last launch_assemble_rows left on the device.
+int launch_assemble_rows_again(byz_ctx* ctx, float* G, int64_t n_cols, int64_t ld, int64_t n_clients, int64_t n_segments,
+                               hipStream_t stream) {
+    BYZ_REQUIRE(ctx->assemble_clients > 0 && ctx->assemble_clients == n_clients && ctx->assemble_segments == n_segments &&
+                    ctx->assemble_total == n_cols,
+                "assemble_rows_again: the device table holds %lld clients x %lld tensors of %lld values, the call says %lld x %lld of %lld",
+                (long long)ctx->assemble_clients, (long long)ctx->assemble_segments, (long long)ctx->assemble_total,
+                (long long)n_clients, (long long)n_segments, (long long)n_cols);
     KernelTimer t(ctx, BYZ_K_MISC, stream);
-    int64_t blocks = ceil_div(longest, static_cast<int64_t>(kThreads) * 4);
+    int64_t blocks = ceil_div(ctx->assemble_longest, static_cast<int64_t>(kThreads) * 4);
     const int64_t cap = 64;     // n_clients x n_segments workgroup columns already fill the chip; the kernel strides
     if (blocks > cap) blocks = cap;
     const int64_t* starts = ctx->assemble_table.as<int64_t>();

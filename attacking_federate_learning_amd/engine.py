@@ -9,6 +9,7 @@ The engine accepts either
 There is no CPU implementation behind it: every method ends in a HIP kernel or raises.
 """
 import ctypes
+import itertools
 import os
 
 import numpy as np
@@ -127,6 +128,7 @@ class Engine:
         _check(self.lib.byz_ctx_create(int(device), ctypes.byref(ctx)))
         self.ctx = ctx
         self.device = int(device)
+        self._assemble_key = None     # what the context's device-side pointer table holds (assemble_rows)
 
     def close(self):
         if getattr(self, 'ctx', None):
@@ -251,9 +253,23 @@ class Engine:
         n_rows, idx_ptr, keep = m.rows, None, None
         if row_index is not None:
             idx_ptr, n_rows, keep = self._row_index(row_index, m, validate=False)
-        ptr = gram.data_ptr() if _is_torch(gram) else gram.ptr
         if tuple(gram.shape) != (n_rows, n_rows):
             raise ValueError('the accumulator must be %d x %d' % (n_rows, n_rows))
+        # the kernel read-modify-writes N * N doubles at this address: anything else than a contiguous fp64 buffer on the
+        # panel's device would corrupt memory silently
+        if _is_torch(gram):
+            import torch
+            if gram.dtype != torch.float64 or not gram.is_contiguous() or not gram.is_cuda:
+                raise ValueError('the accumulator must be a contiguous float64 CUDA tensor')
+            if m.torch_like is not None and gram.device != m.torch_like.device:
+                raise ValueError('the accumulator lives on %s, the panel on %s' % (gram.device, m.torch_like.device))
+            ptr = gram.data_ptr()
+        elif isinstance(gram, DeviceBuffer):
+            if gram.dtype != np.float64:
+                raise ValueError('the accumulator must be float64')
+            ptr = gram.ptr
+        else:
+            raise ValueError('the accumulator must be a torch CUDA tensor or a DeviceBuffer')
         _check(self.lib.byz_gram_share_add_dev(self.ctx, _vp(m.ptr), int(n_rows), m.cols, m.ld, _vp(idx_ptr),
                                                int(share_count), int(share_index), _vp(ptr), _vp(m.stream)))
         if keep is not None and not _is_torch(keep):
@@ -676,10 +692,30 @@ class Engine:
                                               host.ctypes.data_as(ctypes.c_void_p), _vp(m.stream)))
         self.synchronize(m.stream)   # `host` may be a temporary
 
+    def _order_after_torch(self, m, tensors):
+        """The launch goes to m.stream; torch tensors (and the .contiguous() temporaries made of them) belong to torch's
+        current stream.  Where the two differ -- a DeviceBuffer matrix filled from torch tensors under a side stream --
+        the producers are waited for before the launch and the launch before the temporaries can be freed.
+        Returns whether the caller must synchronise m.stream after the launch."""
+        for t in tensors:
+            if _is_torch(t):
+                import torch
+                current = torch.cuda.current_stream(t.device)
+                if int(current.cuda_stream) != int(m.stream or 0):
+                    current.synchronize()
+                    return True
+                return False
+        return False
+
     def assemble_rows(self, g, first_row, clients_grads):
         """Rows first_row .. of the device-resident matrix := the clients' gradients, ONE launch for all of them
         (server.py:81-83's loop).  `clients_grads[c]` is client c's sequence of device tensors, one per model parameter in
-        parameter order; every client has the same parameter sizes (one model)."""
+        parameter order; every client has the same parameter sizes (one model).
+
+        The table of the clients' tensor addresses is built and uploaded when an address changed since the last call; a round
+        in which no tensor moved (the normal case: a model's .grad buffers keep their addresses) costs one pass over
+        `data_ptr()` and the launch (the table of 400 tensors was rebuilt and uploaded every round, twelve
+        times the kernel's own time)."""
         m = self._device_matrix(g)
         if m is None:
             raise ValueError('assemble_rows() fills a device-resident matrix')
@@ -687,12 +723,25 @@ class Engine:
         if n_clients == 0:
             return
         n_seg = len(clients_grads[0])
-        ptrs, keep, lens = [], [], None
-        for tensors in clients_grads:
-            if len(tensors) != n_seg:
-                raise ValueError('every client must hand over the same number of tensors')
+        flat = list(itertools.chain.from_iterable(clients_grads))
+        if len(flat) != n_clients * n_seg:
+            raise ValueError('every client must hand over the same number of tensors')
+        key = None
+        if _is_torch(flat[0]):
+            import torch
+            try:     # C-level map: no Python frame per tensor
+                key = (n_clients, n_seg, m.cols, tuple(map(torch.Tensor.data_ptr, flat)))
+            except TypeError:
+                key = None      # DeviceBuffers among them: the general path below
+        if key is not None and key == self._assemble_key:
+            _check(self.lib.byz_assemble_rows_again_dev(self.ctx, _vp(m.ptr), m.rows, m.cols, m.ld, int(first_row), n_clients,
+                                                        n_seg, _vp(m.stream)))
+            return
+        self._assemble_key = None
+        ptrs, keep, lens, temporaries = [], [], None, False
+        for c in range(n_clients):
             mine = []
-            for t in tensors:
+            for t in flat[c * n_seg:(c + 1) * n_seg]:
                 if isinstance(t, DeviceBuffer):
                     assert t.dtype == np.float32
                     ptrs.append(t.ptr)
@@ -701,7 +750,8 @@ class Engine:
                     import torch
                     if t.dtype != torch.float32:
                         raise ValueError('gradient tensors must be float32')
-                    t = t if t.is_contiguous() else t.contiguous()
+                    if not t.is_contiguous():
+                        t, temporaries = t.contiguous(), True
                     ptrs.append(t.data_ptr())
                     mine.append(t.numel())
                 else:
@@ -711,10 +761,15 @@ class Engine:
                 lens = mine
             elif mine != lens:
                 raise ValueError('clients disagree on the parameter sizes: %r and %r' % (lens, mine))
+        sync_after = self._order_after_torch(m, keep)
         table = (ctypes.c_void_p * len(ptrs))(*ptrs)
         lengths = (ctypes.c_int64 * n_seg)(*lens)
         _check(self.lib.byz_assemble_rows_dev(self.ctx, _vp(m.ptr), m.rows, m.cols, m.ld, int(first_row), n_clients, n_seg,
                                               table, lengths, _vp(m.stream)))
+        if sync_after:
+            self.synchronize(m.stream)
+        if key is not None and not temporaries:
+            self._assemble_key = key      # what the device table now holds
 
     def assemble_columns(self, g, batched_grads):
         """Every client at once: `batched_grads[s]` is the device tensor (n_clients, *shape_s) holding parameter

@@ -215,6 +215,13 @@ int byz_assemble_row_dev(byz_ctx* ctx, float* G_dev, int64_t n_rows, int64_t n_c
 int byz_assemble_rows_dev(byz_ctx* ctx, float* G_dev, int64_t n_rows, int64_t n_cols, int64_t ld,
                           int64_t first_row, int64_t n_clients, int64_t n_segments,
                           const float* const* segments_dev, const int64_t* lengths, void* stream);
+/* The same launch again with the pointer table of the LAST byz_assemble_rows_dev call on this */
+/* context (it stays on the device): for rounds in which no client's gradient tensor moved,    */
+/* which is the normal case -- a model's .grad buffers keep their addresses.  The caller       */
+/* vouches that the tensors are the ones of that call; n_clients and n_segments must match it  */
+/* (BYZ_E_INVALID otherwise, or when there has been no such call).  No host-to-device copy.    */
+int byz_assemble_rows_again_dev(byz_ctx* ctx, float* G_dev, int64_t n_rows, int64_t n_cols, int64_t ld,
+                                int64_t first_row, int64_t n_clients, int64_t n_segments, void* stream);
 /* Every client at once (what a batched client step produces): segment s is the row-major    */
 /* (n_rows x lengths[s]) gradient of parameter s for all clients; G[:, start_s:start_s+len_s] */
 /* := that block.  One launch per 32 parameters.                                             */
