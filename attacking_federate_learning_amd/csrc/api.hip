@@ -59,6 +59,11 @@ int read_small(byz_ctx* ctx, int32_t (&words)[32], hipStream_t stream) {
                       "process?); the result of this call is invalid");
             return BYZ_E_HIP;
         }
+        if (sticky & 16) {
+            set_error("column statistics: a wave of the register-resident kernel never got its turn; the statistics of this "
+                      "call are invalid (please report the shape)");
+            return BYZ_E_HIP;
+        }
         if (sticky & 4) {
             set_error("distances: two rows have bitwise equal Gram entries but differ; their near-duplicate pairs were not "
                       "re-evaluated (please report the input)");
@@ -708,8 +713,8 @@ int byz_drift_attack_host(byz_ctx* ctx, const float* rows_host, int64_t n_rows, 
     if (drift_host) BYZ_HIP(hipMemcpyAsync(drift_host, out, vec, hipMemcpyDeviceToHost, s));
     if (mean_host) BYZ_HIP(hipMemcpyAsync(mean_host, out + n_cols, vec, hipMemcpyDeviceToHost, s));
     if (std_host) BYZ_HIP(hipMemcpyAsync(std_host, out + 2 * n_cols, vec, hipMemcpyDeviceToHost, s));
-    BYZ_HIP(hipStreamSynchronize(s));
-    return BYZ_OK;
+    int32_t words[32];
+    return read_small(ctx, words, s);     // synchronises; a kernel that flagged a failure makes this call fail
 }
 
 // ---- timing --------------------------------------------------------------------------------------

@@ -13,6 +13,7 @@
 // Algorithmic traffic: 4*rows*cols bytes read + 4*cols written.
 #include "common.hpp"
 
+#include <algorithm>
 #include <cstdlib>
 
 namespace byz {
@@ -130,6 +131,165 @@ __global__ __launch_bounds__(kThreads) void column_sequential_kernel(
     }
 }
 
+// ---- the attack's statistics with the rows RESIDENT IN REGISTERS between the two walks -----------------------------------
+//
+// The variance needs the mean first, so the rows are walked twice, and a matrix of m = 2400 rows x 3.125e6 columns (30 GB)
+// does not come out of any cache the second time: column_sequential_kernel above moves 60 GB for 30 GB of input (10.3 ms,
+// 0.37 of HBM; profiles/r05a_attack_sequential_*).  Here a workgroup keeps a tile of 32 columns x m rows in its REGISTERS
+// (m = 2400: 300 KiB of the CU's 512 KiB) and both walks read registers; HBM is read once.
+//
+//   tile      32 columns (one 128-byte line per row) x all m rows.  NW waves; lanes 0-31 and 32-63 of a wave are two SEGMENTS
+//             of consecutive rows (segment g = 2 wave + half holds rows g R .. g R + R - 1, R = ceil(m / (2 NW)) <= S = 8 RB); lane
+//             (half, c) holds its segment's values of column c in x[0..R).  Rows past m hold +0.0.
+//   chain     numpy adds in row order, so per column the additions are ONE chain through all segments: wave w takes its turn when
+//             the workgroup's token says so, continues the running sum from `carry` (LDS), adds its lower segment (all lanes run
+//             the adds; lanes 0-31 are the ones that count), hands the sum to lanes 32-63, adds the upper segment, leaves the
+//             sum in `carry` and passes the token on.  Adding a padded +0.0 leaves a sum unchanged (the chain starts at +0.0 and
+//             can never be -0.0), so every segment runs the same R additions.  The second walk is the same chain over
+//             q = fl(fl(x - mean)^2), zero for padded rows.
+//   pipeline  a wave that has finished its part of the second walk loads its rows of the NEXT tile while the token is with the
+//             other waves: the loads hide behind the chain (2 x 2 NW R dependent additions per tile).
+// The arithmetic is column_sequential_kernel's, operation for operation (the GPU tests hold both to numpy bit for bit).
+constexpr int kTileCols = 32;
+
+// The token is polled through a VOLATILE asm read: the compiler may not move it across the other volatile statements, in
+// particular not in front of the register-only work that has to be finished before a wave starts waiting for its turn (an
+// ordinary acquire load was hoisted above the squared deviations, which put them on the chain).
+__device__ __forceinline__ int lds_peek(const int* p) {
+    int v;
+    const unsigned addr = static_cast<unsigned>(reinterpret_cast<uintptr_t>((const __attribute__((address_space(3))) int*)p));
+    asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(addr) : "memory");
+    return v;
+}
+// Bounded: a token that never arrives (it cannot, short of a bug) must not hang the device; the status word says so.
+constexpr int kStatusNoTurn = 16;
+__device__ __forceinline__ void wait_token(const int* token, int want, int32_t* status) {
+    unsigned spins = 0;
+    while (lds_peek(token) < want) {
+        __builtin_amdgcn_s_sleep(1);
+        if (++spins > (1u << 23)) {
+            atomicOr(status, kStatusNoTurn);
+            break;
+        }
+    }
+}
+
+template <int NW, int RB>
+__global__ __launch_bounds__(NW * 64) void column_resident_kernel(
+    const float* __restrict__ G, int n_rows, int64_t n_cols, int64_t ld, float num_std, float* __restrict__ mean_out,
+    float* __restrict__ std_out, float* __restrict__ drift_out, int n_tiles, int32_t* __restrict__ status) {
+    __shared__ float carry[kTileCols];
+    __shared__ float mean_s[kTileCols];
+    __shared__ int token;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int half = lane >> 5, c = lane & 31;
+    constexpr int S = RB * 8;                              // register slots of a lane: the kernel is instantiated per RB, so
+                                                           // that the chain is straight-line code (no test between additions)
+    const int R = (n_rows + 2 * NW - 1) / (2 * NW);      // rows per segment, S - 8 < R <= S (the launcher's business)
+    const int row0 = (2 * wave + half) * R;
+    int mine = n_rows - row0;                              // rows of my segment
+    mine = mine < 0 ? 0 : (mine > R ? R : mine);
+    const float rows_f = static_cast<float>(n_rows);
+    if (threadIdx.x == 0) token = 0;
+    __syncthreads();
+
+    // tiles: XCD x (workgroups x, x + 8, ...) owns a contiguous range; its workgroups take neighbouring tiles at the same time,
+    // so the 128-byte lines that a row shares between two tiles (rows are not line-aligned unless ld is a multiple of 32) are
+    // asked for by the same L2 at about the same time
+    // (a grid that is not a multiple of eight -- fewer tiles than CUs -- strides plainly)
+    const bool grouped = (gridDim.x & 7) == 0;
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int per_xcd = gridDim.x >> 3;                    // workgroups of an XCD
+    const int tiles_x = (n_tiles + 7) >> 3;
+    auto tile_of = [&](int it) {
+        if (!grouped) {
+            const int64_t t = static_cast<int64_t>(it) * gridDim.x + blockIdx.x;
+            return t < n_tiles ? static_cast<int>(t) : n_tiles;
+        }
+        const int local = it * per_xcd + slot;
+        const int t = xcd * tiles_x + local;
+        return local < tiles_x && t < n_tiles ? t : n_tiles;
+    };
+
+    float x[S];
+    auto load_tile = [&](int tile) __attribute__((always_inline)) {
+        const int64_t col = static_cast<int64_t>(tile) * kTileCols + c;
+        const bool col_ok = col < n_cols;
+        const float* p = G + static_cast<int64_t>(row0) * ld + col;
+#pragma unroll
+        for (int s = 0; s < S; ++s) {
+            x[s] = 0.0f;
+            if (col_ok && s < mine) x[s] = p[0];
+            p += ld;
+        }
+    };
+    // one walk's share of the chain: S dependent additions, straight-line (the slots past R hold +0.0)
+    auto add_segment = [&](float acc) __attribute__((always_inline)) {
+#pragma unroll
+        for (int s = 0; s < S; ++s) acc = acc + x[s];
+        return acc;
+    };
+    auto my_turn = [&](int turn) __attribute__((always_inline)) {
+        wait_token(&token, turn, status);
+        float acc = wave == 0 ? 0.0f : carry[c];
+        acc = add_segment(acc);                            // lanes 0-31: the sum after the lower segment
+        acc = __shfl(acc, c, 64);                          // ... handed to the lanes of the upper segment (and kept by the lower)
+        acc = add_segment(acc);                            // lanes 32-63: the sum after the upper segment
+        return acc;
+    };
+    auto pass_on = [&](int turn) __attribute__((always_inline)) {
+        if (lane == 0) __hip_atomic_store(&token, turn + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+    };
+
+    int it = 0, base = 0;
+    int tile = tile_of(0);
+    if (tile < n_tiles) load_tile(tile);
+    while (tile < n_tiles) {
+        const int64_t col = static_cast<int64_t>(tile) * kTileCols + c;
+        const bool writer = half == 1 && col < n_cols;     // the lanes that hold a finished chain
+        // ---- first walk: the sum, the mean
+        float acc = my_turn(base + wave);
+        if (wave == NW - 1) {
+            const float mean = acc / rows_f;
+            if (half == 1) mean_s[c] = mean;
+            if (writer && mean_out) mean_out[col] = mean;
+        } else if (half == 1) {
+            carry[c] = acc;
+        }
+        pass_on(base + wave);
+        // ---- the squared deviations, in place (off the chain: every wave does its own as soon as the mean is known)
+        wait_token(&token, base + NW, status);
+        const float mean = mean_s[c];
+#pragma unroll
+        for (int s = 0; s < S; ++s) {
+            const float d = x[s] - mean;
+            const float q = d * d;
+            x[s] = s < mine ? q : 0.0f;
+        }
+#pragma unroll
+        for (int s = 0; s < S; ++s) asm volatile("" : "+v"(x[s]));     // ... and they ARE done before the wait below
+        // ---- second walk: the sum of squares, std, drift
+        acc = my_turn(base + NW + wave);
+        if (wave == NW - 1) {
+            if (writer) {
+                const float var = acc / rows_f;
+                const float sd = __builtin_sqrtf(var);
+                if (std_out) std_out[col] = sd;
+                if (drift_out) drift_out[col] = mean - num_std * sd;
+            }
+        } else if (half == 1) {
+            carry[c] = acc;
+        }
+        // my registers are free: fetch my rows of the next tile before passing the token on (the loads are in flight while the
+        // other waves finish this tile and start the next)
+        ++it;
+        tile = tile_of(it);
+        if (tile < n_tiles) load_tile(tile);
+        pass_on(base + NW + wave);
+        base += 2 * NW;
+    }
+}
+
 // vec -> every row of G (malicious.py:26-27: all malicious clients get ONE array).  VEC = 4: 16-byte stores (rows and the
 // vector 16-byte aligned), a workgroup owns RUN x 4 KiB CONSECUTIVE bytes of every row it visits -- with one 4 KiB piece per
 // row visit (round 3) every wave's next store lay a whole row further on and HBM saw 1 KiB writes scattered over thousands of
@@ -218,14 +378,35 @@ int column_pass(byz_ctx* ctx, const float* G, int64_t n_rows, int64_t n_cols, in
                       n_cols >= static_cast<int64_t>(4) * kThreads * ctx->num_cus * 2;
     const int64_t col_blocks = ceil_div(n_cols, static_cast<int64_t>(kThreads) * (vec4 ? 4 : 1));
     KernelTimer t(ctx, BYZ_K_COLUMN_STATS, stream);
-    const dim3 grid(static_cast<unsigned>(col_blocks));
-    if (stats) {
-        if (vec4) column_sequential_kernel<4, 1><<<grid, kThreads, 0, stream>>>(G, n_rows, n_cols, ld, num_std, mean, stdev, drift);
-        else column_sequential_kernel<1, 1><<<grid, kThreads, 0, stream>>>(G, n_rows, n_cols, ld, num_std, mean, stdev, drift);
-    } else {
-        if (vec4) column_sequential_kernel<4, 0><<<grid, kThreads, 0, stream>>>(G, n_rows, n_cols, ld, 0.0f, mean, nullptr, nullptr);
-        else column_sequential_kernel<1, 0><<<grid, kThreads, 0, stream>>>(G, n_rows, n_cols, ld, 0.0f, mean, nullptr, nullptr);
+    // the attack over many rows: one pass over HBM with the tile resident in registers (BYZ_ATTACK_RESIDENT=0: the two-pass
+    // kernel for everything -- the same bits, the A/B)
+    constexpr int kMaxRb = 10;                   // 80 register slots per lane: 16 waves x 2 segments x 80 = 2560 rows
+    if (stats && n_rows > 64 && n_rows <= 2 * 16 * 8 * kMaxRb && n_cols >= kTileCols && env_int("BYZ_ATTACK_RESIDENT", 1) != 0) {
+        const int64_t n_tiles = ceil_div(n_cols, static_cast<int64_t>(kTileCols));
+        BYZ_REQUIRE(n_tiles < (1 << 30), "column statistics: too many columns");
+        // up to 640 rows four waves hold a tile and several workgroups share a CU; up to 2560 rows sixteen waves, one per CU
+        const int nw = n_rows <= 2 * 4 * 8 * kMaxRb ? 4 : 16;
+        const int rb = static_cast<int>(ceil_div(ceil_div(n_rows, 2 * nw), 8));
+        // (a lane's registers: 20 + 8 rb; a CU runs 32 waves at most)
+        const int64_t wgs = std::min<int64_t>(n_tiles, static_cast<int64_t>(ctx->num_cus) * (nw == 16 ? 1 : rb <= 5 ? 8 : 4));
+#define BYZ_RESIDENT(NW, RB)                                                                                         \
+    case RB:                                                                                                         \
+        column_resident_kernel<NW, RB><<<static_cast<unsigned>(wgs), NW * 64, 0, stream>>>(                          \
+            G, static_cast<int>(n_rows), n_cols, ld, num_std, mean, stdev, drift, static_cast<int>(n_tiles),         \
+            device_status_word(ctx));                                                                                \
+        break
+#define BYZ_RESIDENT_ALL(NW)                                                                                         \
+    switch (rb) {                                                                                                    \
+        BYZ_RESIDENT(NW, 1); BYZ_RESIDENT(NW, 2); BYZ_RESIDENT(NW, 3); BYZ_RESIDENT(NW, 4); BYZ_RESIDENT(NW, 5);       \
+        BYZ_RESIDENT(NW, 6); BYZ_RESIDENT(NW, 7); BYZ_RESIDENT(NW, 8); BYZ_RESIDENT(NW, 9); BYZ_RESIDENT(NW, 10);      \
+        default: set_error("column statistics: %d row blocks per segment", rb); return BYZ_E_INVALID;                \
     }
+        if (nw == 4) { BYZ_RESIDENT_ALL(4) } else { BYZ_RESIDENT_ALL(16) }
+#undef BYZ_RESIDENT_ALL
+#undef BYZ_RESIDENT
+        return check_launch("column_resident_kernel");
+    }
+    const dim3 grid(static_cast<unsigned>(col_blocks));
     return check_launch("column_sequential_kernel");
 }
 

@@ -158,7 +158,8 @@ inline hipStream_t as_stream(void* s) { return static_cast<hipStream_t>(s); }
 //   [0] Krum winner   [8] Bulyan loop status   [9] rows the Bulyan loop re-scored
 //   [16] sticky device status (bit 0: a Gram chunk lost its ticket, bit 1: near-duplicate pair list overflowed,
 //        bit 2: two rows with bitwise equal Gram entries turned out to differ, bit 3: the row workgroups of the small-N
-//        path did not all report their scores in time)
+//        path did not all report their scores in time, bit 4: a wave of the register-resident column statistics never got
+//        its turn)
 //   [17] number of near-duplicate pairs listed by the last distance kernel
 inline int32_t* device_status_word(byz_ctx* ctx) { return ctx->small.as<int32_t>() + 16; }
 inline int32_t* near_pair_count_word(byz_ctx* ctx) { return ctx->small.as<int32_t>() + 17; }

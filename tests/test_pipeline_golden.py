@@ -187,8 +187,12 @@ def test_gpu_pipeline_attack_then_trimmed_mean(eng, pipeline):
 @pytest.mark.gpu
 @pytest.mark.parametrize('m,d,z', [(1, 10, 1.5), (24, 79510, 1.5), (240, 5000, 0.7), (5, 1 << 20, 1.5), (2400, 3000, 1.5),
                                    (24, 1 << 21, 1.1), (77, 524288 + 5, 2.0), (2560, 640, 1.5), (2561, 100, 1.5),
-                                   (33, 2048, 1.5), (1281, 96, 0.3)])
-def test_gpu_attack_statistics_bit_for_bit_at_sizes(eng, m, d, z):
+                                   (33, 2048, 1.5), (1281, 96, 0.3), (65, 33, 1.5), (641, 4099, 1.5), (640, 2048 + 31, 1.5),
+                                   (2400, 8192 * 3 + 17, 1.5), (1999, 12345, 0.9), (320, 100000, 1.5), (81, 70000, 1.5)])
+def test_gpu_attack_statistics_bit_for_bit_at_sizes(eng, m, d, z, monkeypatch):
+    """Every shape class of csrc/column_stats.hip: the two-pass kernel (m <= 64, m > 2560, fewer than 32 columns), the
+    register-resident kernel with four waves (m <= 640) and with sixteen (m <= 2560), every count of row blocks per segment,
+    ragged last tiles -- and the two kernels against each other (BYZ_ATTACK_RESIDENT=0)."""
     rng = np.random.default_rng(9000 + m)
     g = (rng.standard_normal((m, d)) * 2 + 0.5).astype(np.float32)
     g[:, 0] = 0.25
@@ -199,18 +203,41 @@ def test_gpu_attack_statistics_bit_for_bit_at_sizes(eng, m, d, z):
     want_mean, want_std = faithful.attack_statistics(g)
     assert same_bits(mean, want_mean) and same_bits(std, want_std)
     assert same_bits(drift, faithful.drift_vector(g, z))
+    monkeypatch.setenv('BYZ_ATTACK_RESIDENT', '0')
+    drift2, mean2, std2 = eng.drift_attack(g, z)
+    assert same_bits(mean2, mean) and same_bits(std2, std) and same_bits(drift2, drift)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('m', [66, 130, 200, 260, 330, 400, 450, 520, 580, 640, 700, 1000, 1300, 1600, 1900, 2200, 2500, 2560])
+def test_gpu_resident_attack_every_row_block_count(eng, m):
+    """RB = 1 .. 10 for both wave counts, device-resident with a leading dimension that is not a multiple of 32 (row segments
+    straddle cache lines) and a ragged last tile."""
+    torch = pytest.importorskip('torch')
+    d = 1000 + m % 37
+    rng = np.random.default_rng(9300 + m)
+    wide = (rng.standard_normal((m, d + 5)) * 3 - 1).astype(np.float32)
+    dev = torch.from_numpy(wide).cuda()
+    drift, mean, std = eng.drift_attack(dev[:, 2:d + 2], 1.5)
+    eng.check()
+    rows = wide[:, 2:d + 2]
+    want_mean, want_std = faithful.attack_statistics(rows)
+    assert same_bits(mean.cpu().numpy(), want_mean) and same_bits(std.cpu().numpy(), want_std)
+    assert same_bits(drift.cpu().numpy(), faithful.drift_vector(rows, 1.5))
 
 
 @pytest.mark.gpu
 def test_gpu_attack_statistics_with_non_finite_rows(eng):
     rng = np.random.default_rng(9200)
-    g = rng.standard_normal((40, 300)).astype(np.float32)
-    g[3, 5], g[7, 6], g[0, 7], g[39, 8] = np.inf, -np.inf, np.nan, np.nan
-    g[:, 9] = np.float32(3e38)        # the sum overflows
-    with np.errstate(all='ignore'):
-        want_mean, want_std = faithful.attack_statistics(g)
-    _, mean, std = eng.drift_attack(g, 1.5)
-    assert same_bits(mean, want_mean) and same_bits(std, want_std)
+    for m in (40, 300, 900):          # the two-pass kernel, the resident one with four waves, with sixteen
+        g = rng.standard_normal((m, 300)).astype(np.float32)
+        g[3, 5], g[7, 6], g[0, 7], g[m - 1, 8] = np.inf, -np.inf, np.nan, np.nan
+        g[:, 9] = np.float32(3e38)        # the sum overflows
+        g[:, 10] = -0.0
+        with np.errstate(all='ignore'):
+            want_mean, want_std = faithful.attack_statistics(g)
+        _, mean, std = eng.drift_attack(g, 1.5)
+        assert same_bits(mean, want_mean) and same_bits(std, want_std)
 
 
 @pytest.mark.gpu
