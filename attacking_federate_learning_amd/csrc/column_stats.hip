@@ -152,35 +152,32 @@ __global__ __launch_bounds__(kThreads) void column_sequential_kernel(
 // The arithmetic is column_sequential_kernel's, operation for operation (the GPU tests hold both to numpy bit for bit).
 constexpr int kTileCols = 32;
 
-// The token is polled through a VOLATILE asm read: the compiler may not move it across the other volatile statements, in
-// particular not in front of the register-only work that has to be finished before a wave starts waiting for its turn (an
+// The hand-off word of a column: (turn << 32) | bits of the running sum, ONE 8-byte LDS word written with one ds_write_b64 by
+// the lane that finished a turn and polled with ds_read_b64 by the lane that takes the next -- the value arrives with its tag,
+// no second read, no wait between a payload and a flag (a separate token word cost two dependent LDS round trips per hand-off:
+// 7.7 ms instead of ... at m = 2400 x 3.125e6).  Volatile asm: the compiler may not move the poll across the other volatile
+// statements, in particular not in front of register-only work that has to be finished before a wave starts waiting (an
 // ordinary acquire load was hoisted above the squared deviations, which put them on the chain).
-__device__ __forceinline__ int lds_peek(const int* p) {
-    int v;
-    const unsigned addr = static_cast<unsigned>(reinterpret_cast<uintptr_t>((const __attribute__((address_space(3))) int*)p));
-    asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(addr) : "memory");
+__device__ __forceinline__ unsigned lds_address(const void* p) {
+    return static_cast<unsigned>(reinterpret_cast<uintptr_t>((const __attribute__((address_space(3))) void*)p));
+}
+__device__ __forceinline__ unsigned long long lds_peek64(unsigned addr) {
+    unsigned long long v;
+    asm volatile("ds_read_b64 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(addr) : "memory");
     return v;
 }
-// Bounded: a token that never arrives (it cannot, short of a bug) must not hang the device; the status word says so.
-constexpr int kStatusNoTurn = 16;
-__device__ __forceinline__ void wait_token(const int* token, int want, int32_t* status) {
-    unsigned spins = 0;
-    while (lds_peek(token) < want) {
-        __builtin_amdgcn_s_sleep(1);
-        if (++spins > (1u << 23)) {
-            atomicOr(status, kStatusNoTurn);
-            break;
-        }
-    }
+__device__ __forceinline__ void lds_poke64(unsigned addr, unsigned long long v) {
+    asm volatile("ds_write_b64 %0, %1" ::"v"(addr), "v"(v) : "memory");
 }
+// Bounded: a turn that never comes (it cannot, short of a bug) must not hang the device; the status word says so.
+constexpr int kStatusNoTurn = 16;
 
 template <int NW, int RB>
 __global__ __launch_bounds__(NW * 64) void column_resident_kernel(
     const float* __restrict__ G, int n_rows, int64_t n_cols, int64_t ld, float num_std, float* __restrict__ mean_out,
     float* __restrict__ std_out, float* __restrict__ drift_out, int n_tiles, int32_t* __restrict__ status) {
-    __shared__ float carry[kTileCols];
+    __shared__ __attribute__((aligned(8))) unsigned long long handoff[kTileCols];
     __shared__ float mean_s[kTileCols];
-    __shared__ int token;
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int half = lane >> 5, c = lane & 31;
     constexpr int S = RB * 8;                              // register slots of a lane: the kernel is instantiated per RB, so
@@ -190,8 +187,9 @@ __global__ __launch_bounds__(NW * 64) void column_resident_kernel(
     int mine = n_rows - row0;                              // rows of my segment
     mine = mine < 0 ? 0 : (mine > R ? R : mine);
     const float rows_f = static_cast<float>(n_rows);
-    if (threadIdx.x == 0) token = 0;
+    if (threadIdx.x < kTileCols) handoff[threadIdx.x] = 0ull;      // turn 0 may start
     __syncthreads();
+    const unsigned my_word = lds_address(&handoff[c]);
 
     // tiles: XCD x (workgroups x, x + 8, ...) owns a contiguous range; its workgroups take neighbouring tiles at the same time,
     // so the 128-byte lines that a row shares between two tiles (rows are not line-aligned unless ld is a multiple of 32) are
@@ -229,16 +227,33 @@ __global__ __launch_bounds__(NW * 64) void column_resident_kernel(
         for (int s = 0; s < S; ++s) acc = acc + x[s];
         return acc;
     };
-    auto my_turn = [&](int turn) __attribute__((always_inline)) {
-        wait_token(&token, turn, status);
-        float acc = wave == 0 ? 0.0f : carry[c];
+    // wait until turn `turn` may start (the previous turn's owner has written its word); returns the value that came with it
+    auto wait_turn = [&](int turn) __attribute__((always_inline)) -> float {
+        unsigned spins = 0;
+        for (;;) {
+            const unsigned long long w = lds_peek64(my_word);
+            const int tag = static_cast<int>(w >> 32);
+            if (__all(tag >= turn)) return __uint_as_float(static_cast<uint32_t>(w));
+            // the wave whose turn is next polls without a pause; the others can afford one
+            if (turn - __builtin_amdgcn_readfirstlane(tag) > 1) __builtin_amdgcn_s_sleep(2);
+            if (++spins > (1u << 23)) {
+                atomicOr(status, kStatusNoTurn);
+                return 0.0f;
+            }
+        }
+    };
+    // my turn of a walk: continue the running sum through my two segments
+    auto my_turn = [&](int turn) __attribute__((always_inline)) -> float {
+        float acc = wait_turn(turn);
+        if (wave == 0) acc = 0.0f;                         // a walk starts at add.reduce's identity
         acc = add_segment(acc);                            // lanes 0-31: the sum after the lower segment
-        acc = __shfl(acc, c, 64);                          // ... handed to the lanes of the upper segment (and kept by the lower)
+        // ... handed to the lanes of the upper segment: lanes 32-63 take lanes 0-31's value (v_permlane32_swap_b32)
+        acc = __uint_as_float(__builtin_amdgcn_permlane32_swap(__float_as_uint(acc), __float_as_uint(acc), false, false)[0]);
         acc = add_segment(acc);                            // lanes 32-63: the sum after the upper segment
         return acc;
     };
-    auto pass_on = [&](int turn) __attribute__((always_inline)) {
-        if (lane == 0) __hip_atomic_store(&token, turn + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+    auto pass_on = [&](int turn, float value) __attribute__((always_inline)) {
+        if (half == 1) lds_poke64(my_word, (static_cast<unsigned long long>(static_cast<uint32_t>(turn + 1)) << 32) | __float_as_uint(value));
     };
 
     int it = 0, base = 0;
@@ -250,15 +265,13 @@ __global__ __launch_bounds__(NW * 64) void column_resident_kernel(
         // ---- first walk: the sum, the mean
         float acc = my_turn(base + wave);
         if (wave == NW - 1) {
-            const float mean = acc / rows_f;
-            if (half == 1) mean_s[c] = mean;
-            if (writer && mean_out) mean_out[col] = mean;
-        } else if (half == 1) {
-            carry[c] = acc;
+            const float m = acc / rows_f;
+            if (half == 1) mean_s[c] = m;                  // (LDS is in order per wave: in place before the word below)
+            if (writer && mean_out) mean_out[col] = m;
         }
-        pass_on(base + wave);
+        pass_on(base + wave, acc);
         // ---- the squared deviations, in place (off the chain: every wave does its own as soon as the mean is known)
-        wait_token(&token, base + NW, status);
+        (void)wait_turn(base + NW);
         const float mean = mean_s[c];
 #pragma unroll
         for (int s = 0; s < S; ++s) {
@@ -270,22 +283,19 @@ __global__ __launch_bounds__(NW * 64) void column_resident_kernel(
         for (int s = 0; s < S; ++s) asm volatile("" : "+v"(x[s]));     // ... and they ARE done before the wait below
         // ---- second walk: the sum of squares, std, drift
         acc = my_turn(base + NW + wave);
-        if (wave == NW - 1) {
-            if (writer) {
-                const float var = acc / rows_f;
-                const float sd = __builtin_sqrtf(var);
-                if (std_out) std_out[col] = sd;
-                if (drift_out) drift_out[col] = mean - num_std * sd;
-            }
-        } else if (half == 1) {
-            carry[c] = acc;
+        // the word goes on FIRST (issuing 8 RB loads takes thousands of cycles -- address arithmetic, the 63-deep request
+        // counter -- and must not sit on the chain: with the loads in front of the hand-off a tile took 65 us instead of 14);
+        // then, my registers being free, I fetch my rows of the next tile while the other waves finish this one
+        pass_on(base + NW + wave, acc);
+        if (wave == NW - 1 && writer) {
+            const float var = acc / rows_f;
+            const float sd = __builtin_sqrtf(var);
+            if (std_out) std_out[col] = sd;
+            if (drift_out) drift_out[col] = mean - num_std * sd;
         }
-        // my registers are free: fetch my rows of the next tile before passing the token on (the loads are in flight while the
-        // other waves finish this tile and start the next)
         ++it;
         tile = tile_of(it);
         if (tile < n_tiles) load_tile(tile);
-        pass_on(base + NW + wave);
         base += 2 * NW;
     }
 }
@@ -384,11 +394,13 @@ int column_pass(byz_ctx* ctx, const float* G, int64_t n_rows, int64_t n_cols, in
     if (stats && n_rows > 64 && n_rows <= 2 * 16 * 8 * kMaxRb && n_cols >= kTileCols && env_int("BYZ_ATTACK_RESIDENT", 1) != 0) {
         const int64_t n_tiles = ceil_div(n_cols, static_cast<int64_t>(kTileCols));
         BYZ_REQUIRE(n_tiles < (1 << 30), "column statistics: too many columns");
-        // up to 640 rows four waves hold a tile and several workgroups share a CU; up to 2560 rows sixteen waves, one per CU
-        const int nw = n_rows <= 2 * 4 * 8 * kMaxRb ? 4 : 16;
+        // up to 640 rows four waves hold a tile, up to 1280 eight, up to 2560 sixteen (one workgroup per CU): the fewest waves
+        // that hold the rows -- a hand-off between waves costs as much as thirty additions
+        const int nw = n_rows <= 2 * 4 * 8 * kMaxRb ? 4 : n_rows <= 2 * 8 * 8 * kMaxRb ? 8 : 16;
         const int rb = static_cast<int>(ceil_div(ceil_div(n_rows, 2 * nw), 8));
         // (a lane's registers: 20 + 8 rb; a CU runs 32 waves at most)
-        const int64_t wgs = std::min<int64_t>(n_tiles, static_cast<int64_t>(ctx->num_cus) * (nw == 16 ? 1 : rb <= 5 ? 8 : 4));
+        const int per_cu = (rb <= 5 ? 32 : 16) / nw;
+        const int64_t wgs = std::min<int64_t>(n_tiles, static_cast<int64_t>(ctx->num_cus) * per_cu);
 #define BYZ_RESIDENT(NW, RB)                                                                                         \
     case RB:                                                                                                         \
         column_resident_kernel<NW, RB><<<static_cast<unsigned>(wgs), NW * 64, 0, stream>>>(                          \
@@ -401,12 +413,19 @@ int column_pass(byz_ctx* ctx, const float* G, int64_t n_rows, int64_t n_cols, in
         BYZ_RESIDENT(NW, 6); BYZ_RESIDENT(NW, 7); BYZ_RESIDENT(NW, 8); BYZ_RESIDENT(NW, 9); BYZ_RESIDENT(NW, 10);      \
         default: set_error("column statistics: %d row blocks per segment", rb); return BYZ_E_INVALID;                \
     }
-        if (nw == 4) { BYZ_RESIDENT_ALL(4) } else { BYZ_RESIDENT_ALL(16) }
+        if (nw == 4) { BYZ_RESIDENT_ALL(4) } else if (nw == 8) { BYZ_RESIDENT_ALL(8) } else { BYZ_RESIDENT_ALL(16) }
 #undef BYZ_RESIDENT_ALL
 #undef BYZ_RESIDENT
         return check_launch("column_resident_kernel");
     }
     const dim3 grid(static_cast<unsigned>(col_blocks));
+    if (stats) {
+        if (vec4) column_sequential_kernel<4, 1><<<grid, kThreads, 0, stream>>>(G, n_rows, n_cols, ld, num_std, mean, stdev, drift);
+        else column_sequential_kernel<1, 1><<<grid, kThreads, 0, stream>>>(G, n_rows, n_cols, ld, num_std, mean, stdev, drift);
+    } else {
+        if (vec4) column_sequential_kernel<4, 0><<<grid, kThreads, 0, stream>>>(G, n_rows, n_cols, ld, 0.0f, mean, nullptr, nullptr);
+        else column_sequential_kernel<1, 0><<<grid, kThreads, 0, stream>>>(G, n_rows, n_cols, ld, 0.0f, mean, nullptr, nullptr);
+    }
     return check_launch("column_sequential_kernel");
 }
 
