@@ -40,7 +40,6 @@ _PROTOTYPES = {
     'byz_near_pairs_apply_dev': [c_vp, c_vp, c_i64, c_vp, c_vp],
     'byz_ctx_check': [c_vp, c_vp],
     'byz_bulyan_rescored': [c_vp, _P(c_i64)],
-    'byz_bulyan_from_records': [c_vp, _P(c_i64)],
     'byz_krum_select_dev': [c_vp, c_vp, c_i64, c_i64, c_i64, _P(c_i32), c_vp, c_vp],
     'byz_krum_dev': [c_vp, c_vp, c_i64, c_i64, c_i64, c_i64, c_i64, c_int, c_vp, _P(c_i32), c_vp],
     'byz_trimmed_mean_dev': [c_vp, c_vp, c_i64, c_i64, c_i64, c_vp, c_i64, c_vp, c_vp],

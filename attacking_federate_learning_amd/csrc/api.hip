@@ -126,7 +126,6 @@ int bulyan_select(byz_ctx* ctx, const float* dist, int64_t n, int64_t users_coun
     BYZ_TRY(read_small(ctx, words, stream));
     const int32_t status[2] = {words[8], words[9]};
     ctx->bulyan_rescored = status[1];
-    ctx->bulyan_from_records = words[10];
     if (status[0] == 2) {
         set_error("bulyan: the selection loop's workgroups lost contact with each other (exchange timed out)");
         return BYZ_E_HIP;
@@ -216,7 +215,6 @@ void byz_ctx_destroy(byz_ctx* ctx) {
     ctx->twin_class.release();
     ctx->redo_tiles.release();
     ctx->xchg.release();
-    ctx->rescore_records.release();
     ctx->small.release();
     ctx->stage_in.release();
     ctx->stage_out.release();
@@ -361,15 +359,6 @@ int byz_ctx_check(byz_ctx* ctx, void* stream) {
     BYZ_TRY(enter(ctx));
     int32_t words[32];
     return read_small(ctx, words, as_stream(stream));
-}
-
-int byz_bulyan_from_records(const byz_ctx* ctx, int64_t* rows_host) {
-    if (!ctx || !rows_host) {
-        set_error("bulyan_from_records: null argument");
-        return BYZ_E_INVALID;
-    }
-    *rows_host = ctx->bulyan_from_records;
-    return BYZ_OK;
 }
 
 int byz_bulyan_rescored(const byz_ctx* ctx, int64_t* rows_host) {

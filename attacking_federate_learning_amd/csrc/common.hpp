@@ -133,8 +133,6 @@ struct byz_ctx {
     byz::Buffer twin_class;      // 2n int32: twin class of every row (scratch, then final)
     byz::Buffer xchg;            // Bulyan grid loop: tagged 8-byte granules the workgroups exchange
     int64_t bulyan_rescored = 0; // rows the last Bulyan loop re-scored in the reference's fp32 arithmetic
-    int64_t bulyan_from_records = 0;   // ... of them from the record of the previous pick's chain (rescore_incr.hpp)
-    byz::Buffer rescore_records;       // one incr::Record per row
     byz::Buffer selection;       // theta int32
     byz::Buffer small;           // misc device scalars (winner index, status words)
     bool small_configured = false;   // krum_small.hip: dynamic-LDS attributes set for this context's device

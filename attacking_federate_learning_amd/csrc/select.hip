@@ -25,14 +25,6 @@
 // matrix the selection is the reference's, pick for pick -- not a more accurate one.
 #include "common.hpp"
 
-// (development, BYZ_BULYAN_CLOCKS=1: how often an update's walk passes through each of its sections)
-namespace byz { namespace { __device__ unsigned long long g_incr_probe[8]; __device__ int g_incr_probe_on; } }
-#define BYZ_INCR_PROBE(i)                                                                                          \
-    do {                                                                                                           \
-        if (::byz::g_incr_probe_on != 0 && (threadIdx.x & 63) == 0) atomicAdd(&::byz::g_incr_probe[(i)], 1ull);    \
-    } while (0)
-#include "rescore_incr.hpp"
-
 #include <cstdlib>
 #include <cstring>
 
@@ -52,119 +44,8 @@ __device__ __forceinline__ float from_ordered_bits(uint32_t o) {
 __device__ __forceinline__ int visit_position(int u) { return u == 0 ? 1 : (u == 1 ? 0 : u); }
 
 // (defined with the Bulyan re-score below; row_sort_kernel's Krum score uses it too)
-// ---- the incremental re-score (rescore_incr.hpp): a record of a row's chain -- its sum, the sum behind the literal head, the
-// physical end of the prefix and the chain's events (ties, binade crossings) -- kept per row in global memory between picks.
-// In the wave, event i lives in lane i; everything else is wave-uniform.
-struct WaveRecord {
-    uint32_t s, s_head;
-    int32_t head_end, end, valid_pick, n_events;
-    incr::Event mine;
-    int lane;
-    bool overflow;   // (while recording) more events than a record holds: it will not be kept
+__device__ __forceinline__ float integer_passes(uint32_t (&M)[8], const int (&ex)[8], float s, int lane, unsigned long long& n_passes);
 
-    __device__ __forceinline__ incr::Event get(int i) const {
-        const int l = __builtin_amdgcn_readfirstlane(i);
-        incr::Event e;
-        e.pos = __builtin_amdgcn_readlane(mine.pos, l);
-        e.kind_t = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(mine.kind_t), l));
-        e.before = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(mine.before), l));
-        e.after = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(mine.after), l));
-        return e;
-    }
-    __device__ __forceinline__ void set(int i, const incr::Event& e) {
-        if (lane == i) mine = e;
-    }
-    // (the events sit in lanes 0 .. 23: a shift by one lane inside the 32-lane half is two DPP row shifts and a row_bcast fix-up
-    //  cheaper as one ds_swizzle-free pair: lane l reads l + 1 / l - 1 through a DPP wave shift, one instruction per word)
-    __device__ __forceinline__ void erase(int i) {
-        incr::Event up;
-        up.pos = __builtin_amdgcn_update_dpp(0, mine.pos, 0x130, 0xF, 0xF, false);                                   // wave_shl:1
-        up.kind_t = static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(mine.kind_t), 0x130, 0xF, 0xF, false));
-        up.before = static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(mine.before), 0x130, 0xF, 0xF, false));
-        up.after = static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(mine.after), 0x130, 0xF, 0xF, false));
-        if (lane >= i) mine = up;
-        --n_events;
-    }
-    __device__ __forceinline__ bool insert(int i, const incr::Event& e) {
-        if (n_events >= incr::kMaxEvents) return false;
-        incr::Event dn;
-        dn.pos = __builtin_amdgcn_update_dpp(0, mine.pos, 0x138, 0xF, 0xF, false);                                   // wave_shr:1
-        dn.kind_t = static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(mine.kind_t), 0x138, 0xF, 0xF, false));
-        dn.before = static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(mine.before), 0x138, 0xF, 0xF, false));
-        dn.after = static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(mine.after), 0x138, 0xF, 0xF, false));
-        if (lane > i) mine = dn;
-        if (lane == i) mine = e;
-        ++n_events;
-        return true;
-    }
-    __device__ __forceinline__ int find(int pos) const {
-        const unsigned long long m = __ballot(lane < n_events && mine.pos == pos);
-        return m != 0ull ? __builtin_ctzll(m) : -1;
-    }
-    __device__ __forceinline__ int first_after(int pos) const {
-        const unsigned long long m = __ballot(lane < n_events && mine.pos > pos);
-        return m != 0ull ? __builtin_ctzll(m) : n_events;
-    }
-    __device__ __forceinline__ int last_cross_before(int pos) const {
-        const unsigned long long m = __ballot(lane < n_events && mine.pos < pos && (mine.kind_t >> 31) != 0u);
-        return m != 0ull ? 63 - __builtin_clzll(m) : -1;
-    }
-    __device__ __forceinline__ int next_relevant(int i, bool ties_too) const {
-        const unsigned long long m = __ballot(lane >= i && lane < n_events && (ties_too || (mine.kind_t >> 31) != 0u));
-        return m != 0ull ? __builtin_ctzll(m) : n_events;
-    }
-    __device__ __forceinline__ void append(int pos, uint32_t kind_t, uint32_t before, uint32_t after) {   // recording
-        if (n_events >= incr::kMaxEvents) {
-            overflow = true;
-            return;
-        }
-        if (lane == n_events) {
-            mine.pos = pos;
-            mine.kind_t = kind_t;
-            mine.before = before;
-            mine.after = after;
-        }
-        ++n_events;
-    }
-};
-
-__device__ __forceinline__ void record_load(const incr::Record* g, int lane, WaveRecord& r) {
-    const int32_t* h = reinterpret_cast<const int32_t*>(g);
-    r.s = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(h[0]));
-    r.s_head = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(h[1]));
-    r.head_end = __builtin_amdgcn_readfirstlane(h[2]);
-    r.end = __builtin_amdgcn_readfirstlane(h[3]);
-    r.valid_pick = __builtin_amdgcn_readfirstlane(h[4]);
-    int ne = __builtin_amdgcn_readfirstlane(h[5]);
-    r.n_events = ne < 0 ? 0 : (ne > incr::kMaxEvents ? incr::kMaxEvents : ne);
-    r.lane = lane;
-    r.overflow = false;
-    const uint4 e = *reinterpret_cast<const uint4*>(&g->ev[lane < incr::kMaxEvents ? lane : incr::kMaxEvents - 1]);
-    r.mine.pos = static_cast<int32_t>(e.x);
-    r.mine.kind_t = e.y;
-    r.mine.before = e.z;
-    r.mine.after = e.w;
-}
-
-__device__ __forceinline__ void record_store(incr::Record* g, int lane, const WaveRecord& r) {
-    if (lane == 0) {
-        int32_t* h = reinterpret_cast<int32_t*>(g);
-        h[0] = static_cast<int32_t>(r.s);
-        h[1] = static_cast<int32_t>(r.s_head);
-        h[2] = r.head_end;
-        h[3] = r.end;
-        h[4] = r.valid_pick;
-        h[5] = r.n_events;
-    }
-    if (lane < r.n_events && lane < incr::kMaxEvents)
-        *reinterpret_cast<uint4*>(&g->ev[lane]) = make_uint4(static_cast<uint32_t>(r.mine.pos), r.mine.kind_t, r.mine.before, r.mine.after);
-}
-
-template <bool REC>
-__device__ __forceinline__ float integer_passes(uint32_t (&M)[8], const int (&ex)[8], float s, int lane, unsigned long long& n_passes,
-                                                WaveRecord& rec, int r0);
-
-// ---------------------------------------------------------------------------------------------------
 template <bool TABLES>
 __global__ void row_sort_kernel(const float* __restrict__ dist, int n, int n_pad, int prefix_len, int drop,
                                 float* __restrict__ scores, uint16_t* __restrict__ sorted_idx,
@@ -247,8 +128,7 @@ __global__ void row_sort_kernel(const float* __restrict__ dist, int n, int n_pad
                 M[j] = e != 0u ? ((xb & 0x7fffffu) | 0x800000u) : (xb & 0x7fffffu);
             }
             if (__ballot(odd) == 0ull) {
-                WaveRecord none;
-                s = integer_passes<false>(M, ex, s, lane, n_passes, none, 0);
+                s = integer_passes(M, ex, s, lane, n_passes);
             }
         }
         if (__ballot(odd) != 0ull || !(__builtin_fabsf(s) <= 3.4028234663852886e38f)) {
@@ -700,12 +580,7 @@ __device__ __forceinline__ uint32_t wave_scan_u32(uint32_t v) {   // inclusive, 
 // a = floor(x / q) in the high word and the remainder, left-aligned, in the low word -- above half a unit iff it exceeds
 // 0x80000000, a tie iff it equals it.  Lanes without a tie (nearly all) have their increment at once, and its parity is
 // their "xor"; only lanes that hold a tie walk their eight entries under both incoming parities.
-// REC: the pass appends what the chain did to `rec` -- every tie it consumed (position, how it was resolved) and the crossing
-// that ended it -- for the incremental re-score of the picks to come; r0 = the batch's position in the row.  (A compile-time
-// switch: the plain instantiation is the code of rounds 3-4 to the instruction -- a runtime flag cost the default loop 2-5%.)
-template <bool REC>
-__device__ __forceinline__ float integer_passes(uint32_t (&M)[8], const int (&ex)[8], float s, int lane, unsigned long long& n_passes,
-                                                WaveRecord& rec, int r0) {
+__device__ __forceinline__ float integer_passes(uint32_t (&M)[8], const int (&ex)[8], float s, int lane, unsigned long long& n_passes) {
     const unsigned long long lt = (1ull << lane) - 1ull;
     for (;;) {
         // (s is the same in every lane; saying so keeps the pass's bookkeeping on the scalar unit and its branches uniform)
@@ -761,32 +636,7 @@ __device__ __forceinline__ float integer_passes(uint32_t (&M)[8], const int (&ex
         const uint32_t incl = wave_scan_u32(mine);
         const uint32_t limit = (1u << 24) - I;                  // I + increments reaching 2^24: the binade ends
         const unsigned long long crossm = __ballot(incl >= limit);
-        // the ties this pass consumes (all of them, or those in front of the crossing) go on the record, in position order
-        auto note_ties = [&](int lc, uint32_t hit) __attribute__((always_inline)) {
-            if (!REC || tie_lanes == 0ull) return;
-            uint32_t tm = 0u, tt = 0u, par = pin;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const uint32_t alpha = a[j] & 1u, ab = y[j] > 0x80000000u ? 1u : 0u, ti = y[j] == 0x80000000u ? 1u : 0u;
-                const bool consumed = lane < lc || (lane == lc && static_cast<uint32_t>(j) < hit);
-                if (ti != 0u && consumed) {
-                    tm |= 1u << j;
-                    tt |= (par ^ alpha) << j;
-                }
-                par = ti ? 0u : (par ^ alpha ^ ab);
-            }
-            unsigned long long left = __ballot(tm != 0u);
-            while (left != 0ull) {   // uniform
-                const int L = __builtin_ctzll(left);
-                left &= left - 1ull;
-                const uint32_t m8 = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(tm), L));
-                const uint32_t t8 = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(tt), L));
-                for (int j = 0; j < 8; ++j)
-                    if ((m8 >> j) & 1u) rec.append(r0 + 8 * L + j, (t8 >> j) & 1u, 0u, 0u);
-            }
-        };
         if (crossm == 0ull) {
-            if constexpr (REC) note_ties(64, 8u);
             const uint32_t In = I + static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(incl), 63));   // < 2^24
             s = __uint_as_float((e0 == 0 && In < (1u << 23)) ? In : ((static_cast<uint32_t>(es) << 23) | (In & 0x7fffffu)));
             break;
@@ -821,10 +671,6 @@ __device__ __forceinline__ float integer_passes(uint32_t (&M)[8], const int (&ex
         const float x_u = __uint_as_float(xm_u >= (1u << 23) ? ((xe_u << 23) | (xm_u & 0x7fffffu)) : xm_u);
         const float before = __uint_as_float((e0 == 0 && run_u < (1u << 23)) ? run_u : ((static_cast<uint32_t>(es) << 23) | (run_u & 0x7fffffu)));
         s = __fadd_rn(before, x_u);
-        if constexpr (REC) {
-            note_ties(lc, hit_u);
-            rec.append(r0 + 8 * lc + static_cast<int>(hit_u), 0x80000000u, __float_as_uint(before), __float_as_uint(s));
-        }
         if (lane <= lc) {
 #pragma unroll
             for (int j = 0; j < 8; ++j)
@@ -839,7 +685,6 @@ __device__ unsigned long long g_rescore_clock[14];
 
 // One wave; wave-uniform result; `ok` = false when the row holds a negative value (the passes assume distances: the caller
 // then takes the literal chain).  `head`: 512 floats of LDS for the literal chain over the first entries.
-// (The form that also leaves a record of its chain behind, for the incremental re-score, is build_slice below.)
 template <bool CLOCKS>
 __device__ __forceinline__ float reference_score_marked(const float* sorted_val, int n, int u, int take, int lane,
                                                         float* __restrict__ head, int head_chunks, bool& ok) {
@@ -941,8 +786,7 @@ __device__ __forceinline__ float reference_score_marked(const float* sorted_val,
                 if (8 * lane + j < start) M[j] = 0u;
             }
             const unsigned long long c0 = clocks ? __builtin_readcyclecounter() : 0ull;
-            WaveRecord none;
-            s = integer_passes<false>(M, ex, s, lane, n_passes, none, 0);
+            s = integer_passes(M, ex, s, lane, n_passes);
             if (clocks) c_passes += __builtin_readcyclecounter() - c0;
         }
         ++n_batches;
@@ -971,300 +815,21 @@ __device__ __forceinline__ float reference_score_marked(const float* sorted_val,
     return s;
 }
 
-// The literal chain over the live entries of physical positions [0, head_end): the sum behind the head after a mark inside it
-// (rescore_incr.hpp).  One wave; 512 entries at a time through LDS, 64-entry chunks, empty chunks skipped.
-__device__ __forceinline__ uint32_t literal_head_sum(const uint32_t* vals, int n, int head_end, int lane, float* __restrict__ stage) {
-    typedef uint32_t u32x4u __attribute__((ext_vector_type(4), aligned(4)));
-    typedef float f32x4 __attribute__((ext_vector_type(4)));
-    float s = 0.0f;
-    for (int r0 = 0; r0 < head_end; r0 += 512) {   // uniform
-        int p = r0 + 8 * lane;
-        p = p < n ? p : n;
-        const u32x4u lo = *reinterpret_cast<const u32x4u*>(vals + p), hi = *reinterpret_cast<const u32x4u*>(vals + p + 4);
-        uint32_t xb[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
-        uint32_t any = 0u;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const bool live = r0 + 8 * lane + j < head_end && xb[j] != kGoneBits;
-            xb[j] = live ? xb[j] : 0u;
-            any |= xb[j];
-        }
-        const unsigned long long holds = __ballot(any != 0u);   // lanes 8 k .. 8 k + 7 hold chunk k
-        if (holds == 0ull) continue;
-        *reinterpret_cast<f32x4*>(stage + 8 * lane) = f32x4{__uint_as_float(xb[0]), __uint_as_float(xb[1]), __uint_as_float(xb[2]), __uint_as_float(xb[3])};
-        *reinterpret_cast<f32x4*>(stage + 8 * lane + 4) = f32x4{__uint_as_float(xb[4]), __uint_as_float(xb[5]), __uint_as_float(xb[6]), __uint_as_float(xb[7])};
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-        const f32x4* src = reinterpret_cast<const f32x4*>(stage);
-        for (int k = 0; k < 8; ++k) {
-            if (((holds >> (8 * k)) & 0xffull) == 0ull) continue;
-            f32x4 e[16];
-#pragma unroll
-            for (int i = 0; i < 16; ++i) e[i] = src[16 * k + i];
-#pragma unroll
-            for (int i = 0; i < 16; ++i) s = __fadd_rn(__fadd_rn(__fadd_rn(__fadd_rn(s, e[i].x), e[i].y), e[i].z), e[i].w);
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // read before the next batch overwrites it
-        __builtin_amdgcn_wave_barrier();
-    }
-    return __float_as_uint(s);
-}
-
-// What an update reads of the row besides its head: 16 entries behind every crossing of the record (window w = event w), behind
-// the head (window 24) and in front of the prefix's end (window 25), fetched at once into LDS before the walk starts.
-struct WindowVals {
-    const float* stage;   // window w: stage[16 w .. 16 w + 15]
-    int win_pos;          // lane w: where window w starts in the row (kNoWindow: it does not exist)
-    int lane;
-    // the first entry behind pos that adds something (the 16 lanes of a window look at it at once)
-    __device__ __forceinline__ uint32_t next_live(int pos, int& at) const {
-        const unsigned long long m = __ballot(static_cast<unsigned>(pos - win_pos) < 16u);
-        if (m == 0ull) return incr::kNoValue;
-        const int w = __builtin_ctzll(m);
-        const int base = __builtin_amdgcn_readlane(win_pos, w);
-        const uint32_t v = __float_as_uint(stage[16 * w + (lane & 15)]);
-        const unsigned long long live = __ballot(lane < 16 && lane > pos - base && v != incr::kNoValue && !incr::adds_nothing(v));
-        if (live == 0ull) return incr::kNoValue;
-        const int j = __builtin_ctzll(live);
-        at = base + j;
-        return static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(v), j));
-    }
-    __device__ __forceinline__ uint32_t operator()(int p) const {
-        const unsigned long long m = __ballot(static_cast<unsigned>(p - win_pos) < 16u);
-        if (m == 0ull) return incr::kNoValue;
-        const int w = __builtin_ctzll(m);
-        return static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(
-            static_cast<int>(__float_as_uint(stage[16 * w + (p - __builtin_amdgcn_readlane(win_pos, w))]))));
-    }
-};
-constexpr int kNoWindow = -(1 << 30);
-
-// One entry has left the prefix of `row` since its record was made: the winner's distance at position k (already marked in the
-// table; `beyond`: it lay behind the prefix, or is not finite -- then the prefix loses its last live entry instead).  True: wr
-// is the record of the new chain and wr.s its score; false: nothing can be said -- re-score in full.
-template <bool CLOCKS>
-__device__ __forceinline__ bool incremental_score(const float* sorted_val, int n, int row, int lane, float* __restrict__ stage,
-                                                  WaveRecord& wr, int k, uint32_t xk, bool beyond) {
-    constexpr bool clocks = CLOCKS;
-    const uint32_t* vals = reinterpret_cast<const uint32_t*>(sorted_val + static_cast<int64_t>(row) * n);
-    const unsigned long long c0 = clocks ? __builtin_readcyclecounter() : 0ull;
-    const bool inside = !beyond && k < wr.end;
-    if ((xk & 0x80000000u) != 0u && inside) return false;
-    uint32_t s_head_new = 0u;
-    if (inside && k < wr.head_end && !incr::adds_nothing(xk)) s_head_new = literal_head_sum(vals, n, wr.head_end, lane, stage);
-    const unsigned long long c1 = clocks ? __builtin_readcyclecounter() : 0ull;
-    int win_pos = kNoWindow;
-    if (lane < wr.n_events && incr::is_cross(wr.mine)) win_pos = wr.mine.pos;
-    if (lane == 24) win_pos = wr.head_end;
-    if (lane == 25) win_pos = wr.end - 16;
-    uint32_t* stage_u = reinterpret_cast<uint32_t*>(stage);
-#pragma unroll
-    for (int i = 0; i < 7; ++i) {
-        const int e = lane + 64 * i, w = e >> 4, j = e & 15;
-        const int wp = __shfl(win_pos, w, 64);
-        const int pos = wp + j;
-        uint32_t v = incr::kNoValue;
-        if (wp != kNoWindow && pos >= 0 && pos < n) v = vals[pos];
-        stage_u[e] = v;
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-    const WindowVals wv{stage, win_pos, lane};
-    const unsigned long long c2 = clocks ? __builtin_readcyclecounter() : 0ull;
-    int rc;
-    if (inside) {
-        // the straight-line walk for the usual case first; what it declines goes to the general one on the record as it was
-        const WaveRecord saved = wr;
-        if (incr::mark_fast(wv, wr, k, xk) == 1) {
-            rc = 0;
-            if (clocks && lane == 0) atomicAdd(&g_incr_probe[6], 1ull);
-        } else {
-            wr = saved;
-            rc = incr::mark(wv, wr, k, xk, s_head_new);
-        }
-    } else {
-        rc = incr::drop_last(wv, wr);
-    }
-    if (clocks && lane == 0) {
-        const unsigned long long c3 = __builtin_readcyclecounter();
-        atomicAdd(&g_rescore_clock[5], 1ull);
-        atomicAdd(&g_rescore_clock[6], c1 - c0);   // the head
-        atomicAdd(&g_rescore_clock[7], c2 - c1);   // the windows
-        atomicAdd(&g_rescore_clock[8], c3 - c2);   // the walk
-        if (rc != 0) atomicAdd(&g_rescore_clock[9], 1ull);
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // read before the stage is used again
-    __builtin_amdgcn_wave_barrier();
-    const uint32_t e8 = (wr.s >> 23) & 0xffu;
-    return rc == 0 && e8 != 0xffu;
-}
-
-// A row's record in global memory, and behind it the state of a record that is still being BUILT: a full re-score cut into
-// slices of a few 512-entry batches, one slice per pick (round 4: the rows NEAR the band are kept scored -- an entrant's first
-// score is ready before it becomes a contender, and no pick waits for a whole chain any more; scripts/proto/band_dynamics.py).
-struct RowRecord {
-    incr::Record rec;
-    int32_t build_r0;        // next batch of the row to process; < 0: nothing is being built
-    int32_t build_got;       // live entries of the processed part
-    int32_t build_literal;   // chunks the literal head still has to take
-    int32_t build_last_kept;
-    int32_t build_flags;     // bit 0: the head's end is on the record; bit 1: more events than a record holds
-    uint32_t build_s;        // the sum so far
-    int32_t pad[2];
-};
-
-struct BuildState {   // wave-uniform
-    float s;
-    int r0, got, literal_left, last_kept;
-    bool head_noted;
-};
-
-// Up to max_batches more batches of the chain of `u` (never stopping inside the literal head).  True: the prefix is complete --
-// rec.{end, head_end, s_head, s} are final and rec.valid_pick says whether the record can be kept (the caller writes the pick).
-// `gave_up`: a live entry with a sign bit -- the passes refuse, the caller takes the plain chain.
-__device__ __forceinline__ bool build_slice(const float* sorted_val, int n, int u, int take, int lane, float* __restrict__ head,
-                                            WaveRecord& rec, BuildState& st, int max_batches, bool& gave_up) {
-    typedef uint32_t u32x4u __attribute__((ext_vector_type(4), aligned(4)));
-    typedef float f32x4 __attribute__((ext_vector_type(4)));
-    const uint32_t* vals = reinterpret_cast<const uint32_t*>(sorted_val + static_cast<int64_t>(u) * n);
-    unsigned long long n_passes = 0;
-    gave_up = false;
-    bool finished = false;
-    for (int batches = 0; !finished && (batches < max_batches || !st.head_noted); ++batches) {
-        const int r0 = st.r0;
-        int p = r0 + 8 * lane;
-        p = p < n ? p : n;
-        const u32x4u lo = *reinterpret_cast<const u32x4u*>(vals + p), hi = *reinterpret_cast<const u32x4u*>(vals + p + 4);
-        const uint32_t bx[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
-        uint32_t xb[8];
-        uint32_t cnt = 0, top = 0;
-        const int inside = n - r0 - 8 * lane;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const bool live = j < inside && bx[j] != kGoneBits;
-            xb[j] = live ? bx[j] : 0u;
-            cnt += live ? 1u : 0u;
-            top = xb[j] > top ? xb[j] : top;
-        }
-        if (__ballot(top > kGoneBits) != 0ull) {
-            gave_up = true;
-            return false;
-        }
-        const uint32_t incl = wave_scan_u32(cnt);
-        const int total = __builtin_amdgcn_readlane(static_cast<int>(incl), 63);
-        if (total == 0) {   // nothing live in this batch (a run of marks): nothing to add, and it does not count as work done
-            st.r0 = r0 + 512;
-            finished = st.r0 >= n;
-            --batches;
-            continue;
-        }
-        int kept_j = -1;
-        if (st.got + total > take) {   // uniform: the prefix ends inside this batch
-            int room = take - st.got - static_cast<int>(incl - cnt);
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                if (xb[j] != 0u || (j < inside && bx[j] == 0u)) {
-                    if (room <= 0) xb[j] = 0u;
-                    else kept_j = j;
-                    --room;
-                }
-            }
-        } else {
-#pragma unroll
-            for (int j = 0; j < 8; ++j)
-                if (j < inside && bx[j] != kGoneBits) kept_j = j;
-        }
-        {
-            const int here = wave_max_int(kept_j >= 0 ? r0 + 8 * lane + kept_j : -1);
-            st.last_kept = here > st.last_kept ? here : st.last_kept;
-        }
-        st.got += total;
-        int start = 0;
-        if (st.literal_left > 0) {
-            uint32_t any = 0;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) any |= xb[j];
-            const unsigned long long holds = __ballot(any != 0u);
-            if (holds != 0ull) {
-                *reinterpret_cast<f32x4*>(head + 8 * lane) = f32x4{__uint_as_float(xb[0]), __uint_as_float(xb[1]), __uint_as_float(xb[2]), __uint_as_float(xb[3])};
-                *reinterpret_cast<f32x4*>(head + 8 * lane + 4) = f32x4{__uint_as_float(xb[4]), __uint_as_float(xb[5]), __uint_as_float(xb[6]), __uint_as_float(xb[7])};
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-                __builtin_amdgcn_wave_barrier();
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-                const f32x4* src = reinterpret_cast<const f32x4*>(head);
-                for (int k = 0; k < 8 && st.literal_left > 0; ++k) {
-                    if (((holds >> (8 * k)) & 0xffull) == 0ull) {
-                        start = 64 * (k + 1);
-                        continue;
-                    }
-                    f32x4 e[16];
-#pragma unroll
-                    for (int i = 0; i < 16; ++i) e[i] = src[16 * k + i];
-#pragma unroll
-                    for (int i = 0; i < 16; ++i) st.s = __fadd_rn(__fadd_rn(__fadd_rn(__fadd_rn(st.s, e[i].x), e[i].y), e[i].z), e[i].w);
-                    --st.literal_left;
-                    start = 64 * (k + 1);
-                }
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-                __builtin_amdgcn_wave_barrier();
-            } else {
-                start = 512;
-            }
-        }
-        if (!st.head_noted && st.literal_left <= 0) {
-            st.head_noted = true;
-            rec.head_end = r0 + start;
-            rec.s_head = __float_as_uint(st.s);
-        }
-        {
-            uint32_t M[8];
-            int ex[8];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const uint32_t e = xb[j] >> 23;
-                ex[j] = e != 0u ? static_cast<int>(e) : 1;
-                M[j] = e != 0u ? ((xb[j] & 0x7fffffu) | 0x800000u) : xb[j];
-                if (8 * lane + j < start) M[j] = 0u;
-            }
-            st.s = st.head_noted ? integer_passes<true>(M, ex, st.s, lane, n_passes, rec, r0)
-                                 : integer_passes<false>(M, ex, st.s, lane, n_passes, rec, r0);
-        }
-        st.r0 = r0 + 512;
-        finished = st.got >= take || st.r0 >= n;
-    }
-    if (finished) {
-        rec.end = st.last_kept + 1;
-        if (!st.head_noted) {
-            rec.head_end = rec.end;
-            rec.s_head = __float_as_uint(st.s);
-        }
-        if (rec.head_end > rec.end) rec.head_end = rec.end;
-        rec.s = __float_as_uint(st.s);
-        const uint32_t e8 = (rec.s >> 23) & 0xffu;
-        rec.valid_pick = (!rec.overflow && e8 != 0xffu && take >= 1) ? 0 : -1;
-    }
-    return finished;
-}
-
 struct GridDecision {
     int mode;        // 0 winner known, 1 round 2, 2 no candidate, 3 exchange timed out
     int winner;
     double threshold;
-    double track;    // (tracking) rows with an exact score up to here are kept scored from pick to pick
 };
 
-// INCR (BYZ_BULYAN_INCR=1): the incremental re-score and the tracked rows are compiled in; the plain instantiation is the
-// loop of rounds 2-4.
-template <bool INCR, bool DEV>
+// (Round 4's exact incremental re-score -- a contender re-scored from a record of its previous chain, rows near the band kept
+// scored -- was built, measured and REMOVED in round 5: EXPERIMENTS.md S2.)
+template <bool DEV>
 __global__ __launch_bounds__(kGridThreads) void bulyan_grid_kernel(
     const float* __restrict__ dist, int n, int theta, int drop, int users_count, int corrupted,
     const uint16_t* __restrict__ sorted_idx, const uint16_t* __restrict__ rank_t, float* sorted_val,
     const double* __restrict__ row_total, const double* __restrict__ row_top, const int32_t* __restrict__ cls,
     unsigned long long* __restrict__ xchg, float band_scale, int32_t* __restrict__ selection,
-    int32_t* __restrict__ status, int32_t* __restrict__ rescored, int rescore_mode, int head_chunks,
-    RowRecord* __restrict__ records, float track_factor, int slice_batches) {
+    int32_t* __restrict__ status, int32_t* __restrict__ rescored, int rescore_mode, int head_chunks) {
     __shared__ __attribute__((aligned(16))) float rescore_stage[kGridThreads / 64][512];
     __shared__ Candidate slots[kGridThreads / 64];
     __shared__ double second_slots[kGridThreads / 64];
@@ -1273,7 +838,6 @@ __global__ __launch_bounds__(kGridThreads) void bulyan_grid_kernel(
     __shared__ unsigned long long class_leader[256];
     __shared__ int leaders[kGridThreads];
     __shared__ int n_leaders;
-    __shared__ int n_leaders_contending;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n_wgs = gridDim.x, wg = blockIdx.x;
     const int u = wg * kGridThreads + tid;
@@ -1290,18 +854,6 @@ __global__ __launch_bounds__(kGridThreads) void bulyan_grid_kernel(
     // rescore_mode >= 1: the table of ascending values carries the removals (-0.0); first of all the row's own diagonal
     const bool marked = rescore_mode >= 1;
     if (marked && alive) sorted_val[static_cast<int64_t>(u) * n + rank_t[static_cast<int64_t>(u) * n + u]] = __uint_as_float(kGoneBits);
-    // records != nullptr: a contender that was scored at the previous pick is re-scored from the record of that chain
-    // (rescore_incr.hpp); no row has a record yet
-    const bool incremental = INCR && marked && records != nullptr;
-    if (incremental && alive) {
-        records[u].rec.valid_pick = -1;
-        records[u].build_r0 = -1;
-    }
-    // track_factor > 0: not only the contenders of a pick but every row whose exact score lies within track_factor times the
-    // band is kept scored from pick to pick -- updated from its record, or its first record built a slice per pick
-    const bool tracking = INCR && incremental && track_factor > 0.0f;
-    __shared__ unsigned char leader_contends[INCR ? kGridThreads : 1];
-    int n_from_records = 0, last_winner = -1;
     auto take_at = [&](int t) __attribute__((always_inline)) -> int {
         // the prefix the reference sums at pick t: sorted(...)[: users_count - t - f] of the n - t - 1 live entries
         const int live_entries = n - t - 1;
@@ -1366,7 +918,7 @@ __global__ __launch_bounds__(kGridThreads) void bulyan_grid_kernel(
             const int a_row = static_cast<int>((ga >> 18) & 0x3fffu);
             const int a_cls = static_cast<int>((ga >> 4) & 0x3fffu);
             const float m1 = wave_min_f(a);
-            GridDecision d{0, -1, 0.0, 0.0};
+            GridDecision d{0, -1, 0.0};
             if (!ok) {
                 d.mode = 3;
             } else if (!(m1 < __builtin_inff())) {
@@ -1381,7 +933,6 @@ __global__ __launch_bounds__(kGridThreads) void bulyan_grid_kernel(
                 const double ub = double_above(m1);
                 const double thr = ub + fabs(ub) * (take <= 1 ? 1e-12 : band);
                 d.threshold = thr;
-                d.track = ub + fabs(ub) * (take <= 1 ? 1e-12 : band * static_cast<double>(track_factor));
                 const bool in_a = static_cast<double>(a) <= thr;
                 const bool in_b = static_cast<double>(b) <= thr;
                 const unsigned long long first = __ballot(a == m1);
@@ -1397,18 +948,14 @@ __global__ __launch_bounds__(kGridThreads) void bulyan_grid_kernel(
             if (lane == 0) decision = d;
         }
         if (tid < 256) class_leader[tid] = ~0ull;
-        if (tid == 0) {
-            n_leaders = 0;
-            n_leaders_contending = 0;
-        }
+        if (tid == 0) n_leaders = 0;
         __syncthreads();
         GridDecision d = decision;
-        const bool work_phase = d.mode == 1 || (tracking && d.mode == 0 && take >= 1 && take == take_at(t - 1) - 1);
         Candidate r{static_cast<double>(kKrumInit), 0x7fffffff, -1};
-        if (work_phase) {
-            // ---- 3. round 2: the contenders scored in the reference's own arithmetic (and, tracking, the rows near them kept scored)
-            const bool contender = candidate && d.mode == 1 && score <= d.threshold;
-            const bool tracked = contender || (tracking && candidate && score <= d.track);
+        if (d.mode == 1) {
+            // ---- 3. round 2: the contenders scored in the reference's own arithmetic
+            const bool contender = candidate && score <= d.threshold;
+            const bool tracked = contender;
             const unsigned long long key = (static_cast<unsigned long long>(my_pos) << 32) | static_cast<uint32_t>(my_class);
             if (tracked) atomicMin(&class_leader[my_class & 255], key);
             __syncthreads();
@@ -1422,130 +969,23 @@ __global__ __launch_bounds__(kGridThreads) void bulyan_grid_kernel(
             if (leader) {
                 const int at = atomicAdd(&n_leaders, 1);
                 leaders[at] = tid;
-                if constexpr (INCR) leader_contends[at] = contender ? 1 : 0;
             }
             __syncthreads();
             const int n_lead = n_leaders;
-            int n_contend = 0;
             for (int k = wave; k < n_lead; k += kGridThreads / 64) {
                 const int row = __builtin_amdgcn_readfirstlane(wg * kGridThreads + leaders[k]);
-                bool contends = true;
-                if constexpr (INCR) contends = __builtin_amdgcn_readfirstlane(static_cast<int>(leader_contends[k])) != 0;
-                n_contend += contends ? 1 : 0;
                 float s32 = 0.0f;
                 bool done = false;
-                if constexpr (INCR) {
-                  if (incremental) {
-                    RowRecord* g = records + row;
-                    WaveRecord wr;
-                    record_load(&g->rec, lane, wr);
-                    const bool steady = t > 0 && take >= 1 && take == take_at(t - 1) - 1;   // one entry leaves the prefix per pick
-                    // what the previous pick's winner is to this row (the same address in every lane: said so, the update's
-                    // control flow stays on the scalar unit)
-                    const int lw = __builtin_amdgcn_readfirstlane(last_winner);
-                    uint32_t xk = 0u;
-                    int k_pos = 0;
-                    if (t > 0) {
-                        xk = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(
-                            static_cast<int>(__float_as_uint(dist[static_cast<int64_t>(lw) * n + row]))));
-                        k_pos = __builtin_amdgcn_readfirstlane(static_cast<int>(rank_t[static_cast<int64_t>(lw) * n + row]));
-                    }
-                    const bool beyond = (xk & 0x7f800000u) == 0x7f800000u;
-                    if (steady && wr.valid_pick == t - 1) {
-                        if (incremental_score<DEV>(sorted_val, n, row, lane, rescore_stage[wave], wr, k_pos, xk, beyond)) {
-                            s32 = __uint_as_float(wr.s);
-                            done = true;
-                            wr.valid_pick = t;
-                            record_store(&g->rec, lane, wr);
-                            if (lane == 0) ++n_from_records;
-                        }
-                    }
-                    if (!done) {
-                        // no usable record: one is being built (a slice per pick while the row only tracks; to the end as soon as it
-                        // contends), or is started now
-                        BuildState st;
-                        int b_r0 = __builtin_amdgcn_readfirstlane(g->build_r0);
-                        bool resumed = false;
-                        if (tracking && steady && b_r0 >= 0 && wr.valid_pick == -(t - 1) - 2) {   // built up to the previous pick
-                            st.r0 = b_r0;
-                            st.got = __builtin_amdgcn_readfirstlane(g->build_got);
-                            st.literal_left = __builtin_amdgcn_readfirstlane(g->build_literal);
-                            st.last_kept = __builtin_amdgcn_readfirstlane(g->build_last_kept);
-                            const int b_flags = __builtin_amdgcn_readfirstlane(g->build_flags);
-                            st.head_noted = (b_flags & 1) != 0;
-                            wr.overflow = (b_flags & 2) != 0;
-                            st.s = __uint_as_float(static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(g->build_s))));
-                            resumed = st.head_noted;
-                            if (resumed && !beyond && k_pos < st.r0) {
-                                // the previous pick's winner lies in the part that is already added: the partial chain moves
-                                wr.end = st.r0;
-                                wr.s = __float_as_uint(st.s);
-                                resumed = incremental_score<false>(sorted_val, n, row, lane, rescore_stage[wave], wr, k_pos, xk, false);
-                                st.s = __uint_as_float(wr.s);
-                                st.got -= 1;
-                            }
-                            resumed = resumed && st.got < take;
-                        }
-                        if (!resumed) {
-                            st.s = 0.0f;
-                            st.r0 = 0;
-                            st.got = 0;
-                            st.literal_left = head_chunks;
-                            st.last_kept = -1;
-                            st.head_noted = false;
-                            wr.n_events = 0;
-                            wr.overflow = false;
-                            wr.lane = lane;
-                        }
-                        wr.valid_pick = -1;
-                        bool gave_up = false;
-                        const unsigned long long cb0 = DEV ? __builtin_readcyclecounter() : 0ull;
-                        const bool finished = build_slice(sorted_val, n, row, take, lane, rescore_stage[wave], wr, st,
-                                                          (contends || !tracking) ? 0x7fffffff : slice_batches, gave_up);
-                        if (DEV && lane == 0) {   // (development) a contender's build runs to the end: the pick waits for it
-                            atomicAdd(&g_rescore_clock[contends ? 10 : 11], 1ull);
-                            atomicAdd(&g_rescore_clock[contends ? 12 : 13], __builtin_readcyclecounter() - cb0);
-                        }
-                        if (finished) {
-                            s32 = __uint_as_float(wr.s);
-                            done = true;
-                            wr.valid_pick = wr.valid_pick == 0 ? t : -1;
-                            record_store(&g->rec, lane, wr);
-                            if (lane == 0) g->build_r0 = -1;
-                        } else if (!gave_up) {
-                            // (only a row that tracks gets here) the slice is done: the state waits for the next pick
-                            wr.valid_pick = -t - 2;   // "being built, up to pick t"
-                            record_store(&g->rec, lane, wr);
-                            if (lane == 0) {
-                                g->build_r0 = st.r0;
-                                g->build_got = st.got;
-                                g->build_literal = st.literal_left;
-                                g->build_last_kept = st.last_kept;
-                                g->build_flags = (st.head_noted ? 1 : 0) | (wr.overflow ? 2 : 0);
-                                g->build_s = __float_as_uint(st.s);
-                            }
-                            done = true;   // (nothing to score: the row does not contend)
-                        } else if (lane == 0) {
-                            g->rec.valid_pick = -1;
-                            g->build_r0 = -1;
-                        }
-                    }
-                  }
-                }
-                if (!incremental && marked)
-                    s32 = reference_score_marked<DEV>(sorted_val, n, row, take, lane, rescore_stage[wave], head_chunks, done);
-                if (!contends) continue;
+                if (marked) s32 = reference_score_marked<DEV>(sorted_val, n, row, take, lane, rescore_stage[wave], head_chunks, done);
                 if (!done) s32 = reference_score_plain(sorted_val, sorted_idx, removed, n, row, take, lane, rescore_stage[wave]);
                 if (s32 < kKrumInit) {
                     Candidate o{static_cast<double>(s32), visit_position(row), row};
                     if (better(o, r)) r = o;
                 }
             }
-            if (tracking && lane == 0 && n_contend != 0) atomicAdd(&n_leaders_contending, n_contend);
         }
         if (d.mode == 1) {
-            if (tracking) __syncthreads();
-            const int n_lead = tracking ? n_leaders_contending : n_leaders;
+            const int n_lead = n_leaders;
             if (wave == 0 && lane == 0) n_rescored += n_lead;
             const Candidate local = block_best(r, slots);   // every lane of a wave holds the same r
             if (wave == 0) {
@@ -1580,7 +1020,6 @@ __global__ __launch_bounds__(kGridThreads) void bulyan_grid_kernel(
             break;   // uniform across the grid: every workgroup reaches the same decision (or times out)
         }
         const int w = d.winner;
-        last_winner = w;
         if (tid == 0) {
             if (wg == 0) selection[t] = w;
             removed[w >> 5] |= 1u << (w & 31);
@@ -1621,7 +1060,6 @@ __global__ __launch_bounds__(kGridThreads) void bulyan_grid_kernel(
         if (result != 0) atomicMax(status, result);
         if (n_rescored) atomicAdd(rescored, n_rescored);
     }
-    if (lane == 0 && n_from_records != 0) atomicAdd(rescored + 1, n_from_records);   // (every wave's lane 0 counts its own)
 }
 
 }  // namespace
@@ -1701,65 +1139,28 @@ int launch_bulyan_loop(byz_ctx* ctx, const float* dist, int64_t n, int64_t theta
         rescore_mode += 1;
         const unsigned long long zero[14] = {0};
         BYZ_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_rescore_clock), zero, sizeof(zero)));
-        BYZ_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_incr_probe), zero, 8 * sizeof(unsigned long long)));
-        const int on = 1;
-        BYZ_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_incr_probe_on), &on, sizeof(int)));
     }
     BYZ_HIP(hipMemsetAsync(ctx->xchg.ptr, 0, static_cast<size_t>(2 * 3 * kGridMaxWgs) * sizeof(unsigned long long), stream));
-    BYZ_HIP(hipMemsetAsync(status_dev, 0, 3 * sizeof(int32_t), stream));   // status, rows re-scored, of them from their records
-    // BYZ_BULYAN_INCR=1 (round 4, opt-in): a row that was scored at the previous pick is re-scored from the record of that chain
-    // (rescore_incr.hpp: the same bits), and the rows NEAR the band are kept scored (BYZ_BULYAN_TRACK) so that an entrant's first
-    // score is ready before it contends.  Exact on every selection test and A/B; not the default because an update costs
-    // ~14,000 cycles as compiled today (the whole chain: ~50,000) and only N = 10,000 distinct rows gain.
-    RowRecord* records = nullptr;
-    {
-        const char* e = std::getenv("BYZ_BULYAN_INCR");
-        if (rescore_mode != 0 && e != nullptr && std::atoi(e) != 0) {
-            BYZ_TRY(ctx->rescore_records.ensure(static_cast<size_t>(n) * sizeof(RowRecord)));
-            records = ctx->rescore_records.as<RowRecord>();
-        }
-    }
-    // BYZ_BULYAN_TRACK=<x>: rows with an exact score within x times the band are kept scored from pick to pick (0: only the
-    // contenders of a pick are scored, each in full unless it was scored at the previous pick); BYZ_BULYAN_SLICE: 512-entry
-    // batches a record that is being built advances by per pick
-    float track_factor = n >= 2048 ? 2.75f : 0.0f;
-    if (const char* e = std::getenv("BYZ_BULYAN_TRACK")) track_factor = static_cast<float>(std::atof(e));
-    int slice_batches = 4;
-    if (const char* e = std::getenv("BYZ_BULYAN_SLICE")) slice_batches = std::atoi(e) > 0 ? std::atoi(e) : 4;
+    BYZ_HIP(hipMemsetAsync(status_dev, 0, 3 * sizeof(int32_t), stream));   // status, rows re-scored, (unused)
     KernelTimer t(ctx, BYZ_K_BULYAN_LOOP, stream);
     twin_class_kernel<<<static_cast<unsigned>(ceil_div(n, 4)), 256, 0, stream>>>(dist, (int)n, cls_tmp);
     BYZ_TRY(check_launch("twin_class_kernel"));
     twin_class_fix_kernel<<<static_cast<unsigned>(ceil_div(n, 256)), 256, 0, stream>>>(cls_tmp, (int)n, cls);
     BYZ_TRY(check_launch("twin_class_fix_kernel"));
     const unsigned n_wgs = static_cast<unsigned>(ceil_div(n, kGridThreads));   // <= 64: all resident, they wait for each other
-    auto* kernel = records != nullptr ? (clocks ? &bulyan_grid_kernel<true, true> : &bulyan_grid_kernel<true, false>)
-                                      : (clocks ? &bulyan_grid_kernel<false, true> : &bulyan_grid_kernel<false, false>);
+    auto* kernel = clocks ? &bulyan_grid_kernel<true> : &bulyan_grid_kernel<false>;
     kernel<<<n_wgs, kGridThreads, 0, stream>>>(
         dist, (int)n, (int)theta, (int)drop_count, (int)users_count, (int)corrupted, ctx->sorted_idx.as<uint16_t>(),
         ctx->rank_t.as<uint16_t>(), ctx->sorted_val.as<float>(), ctx->row_total.as<double>(), ctx->row_top.as<double>(), cls,
-        ctx->xchg.as<unsigned long long>(), band_scale, selection_dev, status_dev, status_dev + 1, rescore_mode, head_chunks,
-        records, records != nullptr ? track_factor : 0.0f, slice_batches);
+        ctx->xchg.as<unsigned long long>(), band_scale, selection_dev, status_dev, status_dev + 1, rescore_mode, head_chunks);
     BYZ_TRY(check_launch("bulyan_grid_kernel"));
     if (clocks) {
         unsigned long long c[14];
         BYZ_HIP(hipStreamSynchronize(stream));
-        const int off = 0;
-        BYZ_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_incr_probe_on), &off, sizeof(int)));
         BYZ_HIP(hipMemcpyFromSymbol(c, HIP_SYMBOL(g_rescore_clock), sizeof(c)));
         const double r = c[0] ? static_cast<double>(c[0]) : 1.0;
         std::fprintf(stderr, "bulyan re-scores: %llu; per re-score: %.1f batches, %.1f integer passes, %.0f cycles (%.0f inside the passes)\n",
                      c[0], c[1] / r, c[2] / r, c[3] / r, c[4] / r);
-        if (c[5] != 0) {
-            const double q = static_cast<double>(c[5]);
-            std::fprintf(stderr, "updates from records: %llu (%llu gave up); per update: head %.0f, windows %.0f, walk %.0f cycles\n",
-                         c[5], c[9], c[6] / q, c[7] / q, c[8] / q);
-            std::fprintf(stderr, "  builds run to the end for a contender %llu (%.0f cycles each), slices of tracked rows %llu (%.0f cycles each)\n",
-                         c[10], c[10] ? (double)c[12] / c[10] : 0.0, c[11], c[11] ? (double)c[13] / c[11] : 0.0);
-            unsigned long long pr[8];
-            BYZ_HIP(hipMemcpyFromSymbol(pr, HIP_SYMBOL(g_incr_probe), sizeof(pr)));
-            std::fprintf(stderr, "  walks past the prologue %llu, literal iterations %llu, crossings met at their entry %llu, at the next entry %llu, "
-                                 "through the literal region %llu, walks to the end %llu; straight-line walks %llu\n", pr[0], pr[1], pr[2], pr[5], pr[3], pr[4], pr[6]);
-        }
     }
     return BYZ_OK;
 }

@@ -533,12 +533,6 @@ class Engine:
         _check(self.lib.byz_bulyan_rescored(self.ctx, ctypes.byref(rows)))
         return int(rows.value)
 
-    def bulyan_from_records(self):
-        """... of which: exact updates of the chain recorded at the previous pick (csrc/rescore_incr.hpp), not whole chains."""
-        rows = ctypes.c_int64(0)
-        _check(self.lib.byz_bulyan_from_records(self.ctx, ctypes.byref(rows)))
-        return int(rows.value)
-
     def bulyan(self, g, users_count, corrupted_count, return_selection=False):
         assert users_count >= 4 * corrupted_count + 3  # defences.py:56
         m = self._device_matrix(g)

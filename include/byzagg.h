@@ -159,9 +159,6 @@ int byz_krum_bulyan_select_dev(byz_ctx* ctx, const float* dist_dev, int64_t n_ro
 /* Rows the last selection loop had to re-score in the reference's sequential fp32 arithmetic because   */
 /* their exact scores lay within that arithmetic's rounding band (0 for well separated clients).        */
 int byz_bulyan_rescored(const byz_ctx* ctx, int64_t* rows_host);
-/* ... and how many of those re-scores were exact UPDATES of the chain recorded at the previous pick      */
-/* (csrc/rescore_incr.hpp: one entry leaves a row's prefix per pick) instead of the whole chain again.    */
-int byz_bulyan_from_records(const byz_ctx* ctx, int64_t* rows_host);
 /* Whole function (asserts users_count >= 4*corrupted_count + 3).  selection_dev optional.  */
 int byz_bulyan_dev(byz_ctx* ctx, const float* G_dev, int64_t n_rows, int64_t n_cols, int64_t ld,
                    int64_t users_count, int64_t corrupted_count, float* out_dev,

@@ -251,38 +251,3 @@ def test_krum_and_bulyan_from_one_row_sort(eng, n, identical):
     check_selection(dist, n, f, list(sel))
     idx2, sel_dev = eng.krum_bulyan_select(eng.pairwise_distances(np.random.default_rng(n).standard_normal((n, 64)).astype(np.float32)), n, f, on_device=True)
     assert len(sel_dev.numpy()) == n - 2 * f and 0 <= idx2 < n
-
-
-@pytest.mark.gpu
-@pytest.mark.parametrize('n,identical', [(4000, 0), (4000, 960), (10000, 0), (10000, 2400)])
-@pytest.mark.parametrize('settings', [{'BYZ_BULYAN_TRACK': '0'}, {'BYZ_BULYAN_TRACK': '2.75', 'BYZ_BULYAN_SLICE': '2'}],
-                         ids=['contenders-only', 'tracking'])
-def test_bulyan_incremental_rescore_selects_like_the_full_rescore(eng, n, identical, settings):
-    """BYZ_BULYAN_INCR=1 (opt-in, csrc/rescore_incr.hpp): a row that was scored at the previous pick is re-scored from the
-    record of that chain -- its ties and binade crossings -- instead of adding its 3000 .. 7600 entries again, and with
-    tracking the rows near the band are kept scored, their first record built a few batches per pick.  Exact by construction
-    (every fall-back is the full chain), and checked here where it matters: the selections must be the full re-score's pick
-    for pick, on the scaled family and under the attack's identical rows, and most re-scores must have come from records."""
-    import os
-    from attacking_federate_learning_amd.engine import Distances
-    from test_gpu_scale import point_distances
-    f = int(n * 0.24)
-    dev = Distances(eng.to_device(point_distances(4100 + n, n, identical=identical)), n)
-    saved = {k: os.environ.get(k) for k in ('BYZ_BULYAN_INCR', 'BYZ_BULYAN_TRACK', 'BYZ_BULYAN_SLICE')}
-    try:
-        os.environ.pop('BYZ_BULYAN_INCR', None)
-        want = np.asarray(eng.bulyan_select(dev, n, f))
-        full = eng.bulyan_rescored()
-        assert eng.bulyan_from_records() == 0
-        os.environ['BYZ_BULYAN_INCR'] = '1'
-        os.environ.update(settings)
-        got = np.asarray(eng.bulyan_select(dev, n, f))
-        assert np.array_equal(got, want), 'first differing pick: %d' % int(np.flatnonzero(got != want)[0])
-        assert eng.bulyan_rescored() == full
-        assert eng.bulyan_from_records() >= 0.25 * full, (eng.bulyan_from_records(), full)
-    finally:
-        for k, v in saved.items():
-            if v is None:
-                os.environ.pop(k, None)
-            else:
-                os.environ[k] = v

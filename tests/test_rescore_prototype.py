@@ -98,63 +98,3 @@ def test_predicted_units_on_long_prefixes_leave_few_batches_sequential(proto, pr
     below = np.concatenate([np.full(1023, 1.0), [0.99999], np.full(3000, 1e-4)]).astype(np.float32)
     for v in (on, below):
         assert proto.bits_of(proto.literal(v)) == proto.bits_of(proto_pred.seqsum_pred(v))
-
-
-# ---- the incremental re-score (scripts/proto/seqsum_incr.py): one entry marked per pick --------------
-@pytest.fixture(scope='module')
-def proto_incr():
-    spec = importlib.util.spec_from_file_location('seqsum_incr', os.path.join(ROOT, 'scripts', 'proto', 'seqsum_incr.py'))
-    mod = importlib.util.module_from_spec(spec)
-    spec.loader.exec_module(mod)
-    return mod
-
-
-def incr_cases():
-    rng = np.random.default_rng(23)
-    out = []
-    for n in (40, 600, 1500, 3040):
-        out.append(('distance-like %d' % n, np.sort((1.0 + 0.25 * rng.random(n)).astype(np.float32) * np.float32(37.0))))
-    out.append(('all equal: a tie at every other step', np.full(1800, 1.25, dtype=np.float32)))
-    lattice = np.sort(rng.integers(1, 1 << 12, 2200).astype(np.float32) * np.float32(2.0 ** -9))
-    out.append(('lattice: ties everywhere', lattice))
-    out.append(('twins in front (the attack): zeros, then distances',
-                np.concatenate([np.zeros(700, dtype=np.float32), np.sort(rng.random(1500).astype(np.float32) + np.float32(3.0))])))
-    out.append(('exact powers of two', np.concatenate([[1.0] * 600, [2.0] * 600, [4.0] * 600]).astype(np.float32)))
-    out.append(('wide range', np.sort(np.exp(rng.uniform(-20.0, 20.0, 2000)).astype(np.float32))))
-    return out
-
-
-@pytest.mark.parametrize('name,values', incr_cases(), ids=[c[0] for c in incr_cases()])
-def test_incremental_rescore_follows_the_literal_chain_pick_by_pick(proto_incr, name, values):
-    """A row's prefix loses one entry per pick -- the winner's distance somewhere inside it (marked: it adds nothing from then
-    on) or, when the winner lay behind the prefix, its last live entry.  The update from the recorded events of the old chain
-    (ties, binade crossings) must give the bits of the literal chain after every pick; a fallback to the literal chain is
-    allowed (and counted), a wrong sum is not."""
-    rng = np.random.default_rng(len(values))
-    vals = values.view(np.uint32).copy()
-    rec = proto_incr.Record(vals, len(vals) - len(vals) // 10)
-    assert rec.s == rec.literal()
-    exact = fallbacks = 0
-    for pick in range(min(260, len(vals) // 3)):
-        live = np.flatnonzero(vals[:rec.end])
-        if len(live) < 2:
-            break
-        mode = rng.random()
-        if mode < 0.6:
-            k = int(live[min(len(live) - 1, int(rng.exponential(len(live) / 20.0)))])   # near the front, as winners are
-        elif mode < 0.8:
-            k = int(live[rng.integers(len(live))])                                        # anywhere
-        elif mode < 0.9 and rec.events:
-            k = int(rec.events[rng.integers(len(rec.events))][0])                         # an event itself (a tie, a crossing)
-            if vals[k] == 0:
-                k = int(live[-1])
-        else:
-            k = None                                                                      # the winner lay behind the prefix
-        cost = rec.mark(k)
-        assert rec.s == rec.literal(), '%s: pick %d (k = %s): incremental %08x, literal %08x' % (name, pick, k, rec.s, rec.literal())
-        exact += cost >= 0
-        fallbacks += cost < 0
-    assert exact > 0
-    if name.startswith('distance-like') and len(values) > 1000:
-        # (a tenth of the picks above mark an event on purpose, and marking a crossing IS a fallback)
-        assert fallbacks <= 0.2 * (exact + fallbacks), 'on distance-like rows the update should rarely fall back'
