@@ -1,4 +1,4 @@
-"""profiles/hbm_traffic.json from the raw PMC sums of one GPU visit (scripts/gpu_round3.sh writes pmc_traffic_raw.json).
+"""profiles/hbm_traffic.json from the raw PMC sums of one GPU visit (scripts/gpu_round5.sh writes pmc_traffic_raw.json).
 
     python scripts/update_traffic.py gpurun_out/<tag>/pmc_traffic_raw.json <tag>
 
@@ -27,6 +27,11 @@ RULES = {
     'c4/trimmed_mean': ('c4/window_lean_kernel', 'window_lean.hip', 2.0, 1, '64-byte row segments of neighbouring tiles merged into 128-byte requests', {}),
     'c3/trimmed_mean': ('c3/window_lean_kernel', 'window_lean.hip', 2.0, 1, '64-byte row segments of neighbouring tiles merged into 128-byte requests', {}),
     'c2/gram_tile': ('c2/small_gram_kernel', 'krum_small.hip', 2.0, 1, '8 x 16-byte loads per row slice', {'arithmetic': 'f16x2'}),
+    # the register-resident attack statistics read 4 bytes per lane, 128-byte row segments (one per half wave): which way the
+    # counter tallies them is decided from the count itself -- a kernel cannot fetch LESS than its input (m x D x 4 bytes), so a
+    # raw count below three quarters of that is the halved tally (scale 2), anything else is taken as it is (scale 1)
+    'attack/column_stats': ('attack/column_resident_kernel', 'column_stats.hip', None, 1, '4-byte loads, 128-byte row segments',
+                            {'algorithmic_bytes': 2400 * 1000000 * 4.0}),
 }
 
 
@@ -46,12 +51,14 @@ def main():
         name, v = max(hits, key=lambda kv: kv[1]['FETCH_SIZE_KB_sum'])
         launches = v['launches']
         fetch, write = v['FETCH_SIZE_KB_sum'] / launches, v['WRITE_SIZE_KB_sum'] / launches
+        if scale is None:
+            scale = 2.0 if fetch * 1024.0 < 0.75 * extra['algorithmic_bytes'] else 1.0
         rec = {'kernel': name.split('/', 1)[1], 'source': src, 'source_sha16': sha16(src), 'measured': tag,
                'FETCH_SIZE_KB_per_launch': fetch, 'WRITE_SIZE_KB_per_launch': write, 'fetch_scale': scale,
                'hbm_bytes_per_launch': (scale * fetch + write) * 1024.0, 'launches_sampled': launches,
                'launches_per_step': per_step,
                'method': 'rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes of the bench command '
-                         '(scripts/gpu_round3.sh); KB -> bytes x 1024; fetch_scale %.1f: %s.  Fabric side of L2: '
+                         '(scripts/gpu_round5.sh); KB -> bytes x 1024; fetch_scale %.1f: %s.  Fabric side of L2: '
                          'Infinity-Cache hits are included' % (scale, note)}
         rec.update(extra)
         table[key] = rec
