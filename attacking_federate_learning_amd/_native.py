@@ -48,6 +48,8 @@ _PROTOTYPES = {
     'byz_krum_bulyan_select_dev': [c_vp, c_vp, c_i64, c_i64, c_i64, _P(c_i32), c_vp, c_vp],
     'byz_bulyan_dev': [c_vp, c_vp, c_i64, c_i64, c_i64, c_i64, c_i64, c_vp, c_vp, c_vp],
     'byz_drift_attack_dev': [c_vp, c_vp, c_i64, c_i64, c_i64, c_f32, c_vp, c_vp, c_vp, c_int, c_vp],
+    'byz_column_chain_dev': [c_vp, c_vp, c_i64, c_i64, c_i64, c_vp, c_vp, c_vp, c_vp],
+    'byz_column_finish_dev': [c_vp, c_vp, c_vp, c_i64, c_f32, c_i64, c_vp, c_vp, c_vp, c_vp],
     'byz_drift_axpy_dev': [c_vp, c_vp, c_vp, c_i64, c_f32, c_vp],
     'byz_server_update_dev': [c_vp, c_vp, c_vp, c_vp, c_i64, c_f32, c_f32, c_vp],
     'byz_backdoor_initial_params_dev': [c_vp, c_vp, c_vp, c_i64, c_f32, c_vp, c_vp],

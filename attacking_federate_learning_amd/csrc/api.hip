@@ -526,6 +526,20 @@ int byz_drift_attack_dev(byz_ctx* ctx, float* G, int64_t n_rows, int64_t n_cols,
     return BYZ_OK;
 }
 
+int byz_column_chain_dev(byz_ctx* ctx, const float* G, int64_t n_rows, int64_t n_cols, int64_t ld, const float* carry_in,
+                         const float* mean, float* out_sum, void* stream) {
+    BYZ_TRY(enter(ctx));
+    BYZ_TRY(check_matrix(G, n_rows, n_cols, ld, "column_chain"));
+    BYZ_REQUIRE(out_sum, "column_chain: null output");
+    return launch_column_chain(ctx, G, n_rows, n_cols, ld, carry_in, mean, out_sum, as_stream(stream));
+}
+
+int byz_column_finish_dev(byz_ctx* ctx, const float* sum, const float* sumsq, int64_t total_rows, float num_std, int64_t n_cols,
+                          float* mean, float* stdev, float* drift, void* stream) {
+    BYZ_TRY(enter(ctx));
+    return launch_column_finish(ctx, sum, sumsq, total_rows, num_std, n_cols, mean, stdev, drift, as_stream(stream));
+}
+
 int byz_drift_axpy_dev(byz_ctx* ctx, float* mean, const float* stdev, int64_t n, float num_std, void* stream) {
     BYZ_TRY(enter(ctx));
     BYZ_REQUIRE(mean && stdev && n > 0, "drift_axpy: bad arguments");

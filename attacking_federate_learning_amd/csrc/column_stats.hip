@@ -131,6 +131,83 @@ __global__ __launch_bounds__(kThreads) void column_sequential_kernel(
     }
 }
 
+// One LINK of the chain, for rows that are spread over several owners (the clients layout: the malicious clients' rows sit on the
+// first ranks, sharded.py): out[c] = carry[c] (or +0.0) followed by this owner's rows in row order -- of x, or with `mean` of
+// fl(fl(x - mean)^2).  The owners call it one after the other, each handing its `out` to the next as `carry`; the additions are
+// then the very chain column_sequential_kernel runs over the stacked rows.
+template <int VEC, bool SQUARES>
+__global__ __launch_bounds__(kThreads) void column_chain_kernel(
+    const float* __restrict__ G, int64_t n_rows, int64_t n_cols, int64_t ld, const float* __restrict__ carry,
+    const float* __restrict__ mean, float* __restrict__ out) {
+    const int64_t c0 = (static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x) * VEC;
+    if (c0 >= n_cols) return;
+    const bool full = c0 + VEC <= n_cols;
+    float s[VEC], mu[VEC];
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) {
+        const bool in = c0 + v < n_cols;
+        s[v] = (carry != nullptr && in) ? carry[c0 + v] : 0.0f;
+        mu[v] = (SQUARES && in) ? mean[c0 + v] : 0.0f;
+    }
+    const float* p = G + c0;
+    int64_t r = 0;
+    for (; r + kRowRun <= n_rows; r += kRowRun) {
+        float x[kRowRun][VEC];
+#pragma unroll
+        for (int u = 0; u < kRowRun; ++u) load_columns<VEC>(p + (r + u) * ld, full, c0, n_cols, x[u]);
+#pragma unroll
+        for (int u = 0; u < kRowRun; ++u)
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) {
+                if constexpr (SQUARES) {
+                    const float d = x[u][v] - mu[v];
+                    const float q = d * d;
+                    s[v] = s[v] + q;
+                } else {
+                    s[v] = s[v] + x[u][v];
+                }
+            }
+    }
+    for (; r < n_rows; ++r) {
+        float x[VEC];
+        load_columns<VEC>(p + r * ld, full, c0, n_cols, x);
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) {
+            if constexpr (SQUARES) {
+                const float d = x[v] - mu[v];
+                const float q = d * d;
+                s[v] = s[v] + q;
+            } else {
+                s[v] = s[v] + x[v];
+            }
+        }
+    }
+#pragma unroll
+    for (int v = 0; v < VEC; ++v)
+        if (c0 + v < n_cols) out[c0 + v] = s[v];
+}
+
+// The end of a chain: mean = sum / m; std = sqrt(sumsq / m), drift = mean - z std (either half optional).
+__global__ __launch_bounds__(kThreads) void column_finish_kernel(const float* __restrict__ sum, const float* __restrict__ sumsq,
+                                                                 float rows_f, float num_std, int64_t n_cols,
+                                                                 float* __restrict__ mean, float* __restrict__ stdev,
+                                                                 float* __restrict__ drift) {
+    const int64_t c = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x;
+    if (c >= n_cols) return;
+    float m = 0.0f;
+    if (sum != nullptr) {
+        m = sum[c] / rows_f;
+        mean[c] = m;
+    } else if (sumsq != nullptr) {
+        m = mean[c];
+    }
+    if (sumsq != nullptr) {
+        const float sd = __builtin_sqrtf(sumsq[c] / rows_f);
+        if (stdev != nullptr) stdev[c] = sd;
+        if (drift != nullptr) drift[c] = m - num_std * sd;
+    }
+}
+
 // ---- the attack's statistics with the rows RESIDENT IN REGISTERS between the two walks -----------------------------------
 //
 // The variance needs the mean first, so the rows are walked twice, and a matrix of m = 2400 rows x 3.125e6 columns (30 GB)
@@ -440,6 +517,33 @@ int launch_column_mean(byz_ctx* ctx, const float* G, int64_t n_rows, int64_t n_c
 int launch_column_drift(byz_ctx* ctx, const float* G, int64_t n_rows, int64_t n_cols, int64_t ld, float num_std,
                         float* drift, float* mean, float* stdev, hipStream_t stream) {
     return column_pass(ctx, G, n_rows, n_cols, ld, true, num_std, mean, stdev, drift, stream);
+}
+
+int launch_column_chain(byz_ctx* ctx, const float* G, int64_t n_rows, int64_t n_cols, int64_t ld, const float* carry,
+                        const float* mean, float* out, hipStream_t stream) {
+    BYZ_REQUIRE(G && out && n_rows > 0 && n_cols > 0 && ld >= n_cols, "column chain: bad shape %lld x %lld ld %lld",
+                (long long)n_rows, (long long)n_cols, (long long)ld);
+    const bool vec4 = (ld % 4 == 0) && (reinterpret_cast<uintptr_t>(G) % 16 == 0) &&
+                      n_cols >= static_cast<int64_t>(4) * kThreads * ctx->num_cus * 2;
+    const unsigned blocks = static_cast<unsigned>(ceil_div(n_cols, static_cast<int64_t>(kThreads) * (vec4 ? 4 : 1)));
+    KernelTimer t(ctx, BYZ_K_COLUMN_STATS, stream);
+    if (mean != nullptr) {
+        if (vec4) column_chain_kernel<4, true><<<blocks, kThreads, 0, stream>>>(G, n_rows, n_cols, ld, carry, mean, out);
+        else column_chain_kernel<1, true><<<blocks, kThreads, 0, stream>>>(G, n_rows, n_cols, ld, carry, mean, out);
+    } else {
+        if (vec4) column_chain_kernel<4, false><<<blocks, kThreads, 0, stream>>>(G, n_rows, n_cols, ld, carry, nullptr, out);
+        else column_chain_kernel<1, false><<<blocks, kThreads, 0, stream>>>(G, n_rows, n_cols, ld, carry, nullptr, out);
+    }
+    return check_launch("column_chain_kernel");
+}
+
+int launch_column_finish(byz_ctx* ctx, const float* sum, const float* sumsq, int64_t total_rows, float num_std, int64_t n_cols,
+                         float* mean, float* stdev, float* drift, hipStream_t stream) {
+    BYZ_REQUIRE((sum || sumsq) && mean && total_rows > 0 && n_cols > 0, "column finish: bad arguments");
+    KernelTimer t(ctx, BYZ_K_MISC, stream);
+    column_finish_kernel<<<static_cast<unsigned>(ceil_div(n_cols, kThreads)), kThreads, 0, stream>>>(
+        sum, sumsq, static_cast<float>(total_rows), num_std, n_cols, mean, stdev, drift);
+    return check_launch("column_finish_kernel");
 }
 
 int launch_broadcast_rows(byz_ctx* ctx, float* G, int64_t n_rows, int64_t n_cols, int64_t ld, const float* vec,

@@ -204,6 +204,10 @@ int launch_column_mean(byz_ctx* ctx, const float* G, int64_t n_rows, int64_t n_c
                        float* out, hipStream_t stream);
 int launch_column_drift(byz_ctx* ctx, const float* G, int64_t n_rows, int64_t n_cols, int64_t ld,
                         float num_std, float* drift, float* mean, float* stdev, hipStream_t stream);
+int launch_column_chain(byz_ctx* ctx, const float* G, int64_t n_rows, int64_t n_cols, int64_t ld, const float* carry,
+                        const float* mean, float* out, hipStream_t stream);
+int launch_column_finish(byz_ctx* ctx, const float* sum, const float* sumsq, int64_t total_rows, float num_std, int64_t n_cols,
+                         float* mean, float* stdev, float* drift, hipStream_t stream);
 int launch_broadcast_rows(byz_ctx* ctx, float* G, int64_t n_rows, int64_t n_cols, int64_t ld,
                           const float* vec, hipStream_t stream);
 int launch_drift_axpy(byz_ctx* ctx, float* mean, const float* stdev, int64_t n, float num_std,

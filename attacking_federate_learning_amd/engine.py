@@ -567,6 +567,41 @@ class Engine:
                                              int(bool(write_back)), _vp(m.stream)))
         return outs[0][0], outs[1][0], outs[2][0]
 
+    def column_chain(self, rows, carry=None, mean=None):
+        """One link of the attack's statistics over rows that several owners hold (sharded.py, clients layout): the running
+        column sums after THESE rows, continuing `carry` (the previous owner's result; None: the chain starts here) -- of the
+        values, or with `mean` of their squared fp32 deviations.  Device tensors in, a device vector out."""
+        m = self._device_matrix(rows)
+        if m is None or m.torch_like is None:
+            raise ValueError('column_chain() takes a torch CUDA matrix')
+        import torch
+        for v in (carry, mean):
+            if v is not None and (not _is_torch(v) or v.dtype != torch.float32 or not v.is_contiguous() or v.numel() != m.cols
+                                  or v.device != m.torch_like.device):
+                raise ValueError('carry / mean must be contiguous float32 vectors of %d columns on the matrix\'s device' % m.cols)
+        out = torch.empty(m.cols, dtype=torch.float32, device=m.torch_like.device)
+        _check(self.lib.byz_column_chain_dev(self.ctx, _vp(m.ptr), m.rows, m.cols, m.ld,
+                                             _vp(carry.data_ptr() if carry is not None else None),
+                                             _vp(mean.data_ptr() if mean is not None else None), _vp(out.data_ptr()), _vp(m.stream)))
+        return out
+
+    def column_finish(self, total_rows, num_std, sum=None, sumsq=None, mean=None):
+        """The end of a chain.  sum given: returns mean = sum / total_rows.  sumsq (and mean) given: returns (std, drift) =
+        (sqrt(sumsq / total_rows), mean - num_std * std)."""
+        import torch
+        ref = sum if sum is not None else sumsq
+        n = ref.numel()
+        stream = torch.cuda.current_stream(ref.device).cuda_stream
+        if sum is not None:
+            mean = torch.empty_like(sum)
+            _check(self.lib.byz_column_finish_dev(self.ctx, _vp(sum.data_ptr()), None, int(total_rows), float(num_std), n,
+                                                  _vp(mean.data_ptr()), None, None, _vp(stream)))
+            return mean
+        std, drift = torch.empty_like(sumsq), torch.empty_like(sumsq)
+        _check(self.lib.byz_column_finish_dev(self.ctx, None, _vp(sumsq.data_ptr()), int(total_rows), float(num_std), n,
+                                              _vp(mean.data_ptr()), _vp(std.data_ptr()), _vp(drift.data_ptr()), _vp(stream)))
+        return std, drift
+
     def drift_axpy_host(self, mean, std, num_std):
         """DriftAttack._attack_grads on host vectors (malicious.py:34-36), computed on the device."""
         mean_c = np.ascontiguousarray(mean, dtype=np.float32)

@@ -84,6 +84,12 @@ class HipKernels:
     def drift(self, rows_local, num_std, write_back=False):
         return self.engine.drift_attack(rows_local, num_std, write_back=write_back)
 
+    def column_chain(self, rows_local, carry=None, mean=None):
+        return self.engine.column_chain(rows_local, carry=carry, mean=mean)
+
+    def column_finish(self, total_rows, num_std, sum=None, sumsq=None, mean=None):
+        return self.engine.column_finish(total_rows, num_std, sum=sum, sumsq=sumsq, mean=mean)
+
     def row(self, g_local, index):
         return g_local[index].clone()
 
@@ -325,28 +331,56 @@ class ShardedAggregator:
         return self._maybe_gather(drift, gather, total_columns), mean, std
 
     def drift_attack_clients(self, rows_local, rows_per_rank, n_malicious, num_std, write_back=True):
-        """clients layout.  The malicious rows 0..m-1 sit on the first ranks: per-rank column statistics over the local
-        malicious rows, combined through one all-reduce of (sum, sum of squares) in fp64 (2 D doubles), the drifted vector
-        written into every local malicious row.  Returns (drift, mean, std) as full D-vectors."""
+        """clients layout.  The malicious rows 0..m-1 sit on the first ranks.  numpy's mean / var add in row order
+        (malicious.py:18-19), so per column the additions are ONE chain through those ranks: each continues the running sums of
+        the rank before it over its own malicious rows (`column_chain`: a point-to-point hop of D floats), the last holder
+        ends the chain (`column_finish`) and broadcasts -- first the mean (the squared deviations need it), then std and the
+        drifted vector.  Bit for bit what the unsharded attack returns (rounds 1-4 combined per-rank (sum, sum of squares) in
+        fp64: 1e-6 close).  The drifted vector is written into every local malicious row.  Returns (drift, mean, std) as full
+        D-vectors on every rank."""
         import torch
+        if n_malicious <= 0:
+            raise ValueError('drift_attack_clients: no malicious rows')
         offsets = self._row_owner(rows_per_rank)
         first = int(offsets[self.rank])
         m_local = int(min(max(n_malicious - first, 0), rows_per_rank[self.rank]))
+        holders = [r for r in range(self.world)
+                   if min(max(n_malicious - int(offsets[r]), 0), rows_per_rank[r]) > 0]
+        last = holders[-1]
         d = rows_local.shape[1]
-        acc = torch.zeros((2, d), dtype=torch.float64, device=rows_local.device)
-        if m_local > 0:
-            _, mean_r, std_r = self.kernels.drift(rows_local[:m_local], 0.0, write_back=False)
-            mean64, std64 = mean_r.to(torch.float64), std_r.to(torch.float64)
-            acc[0] = mean64 * m_local
-            acc[1] = (std64 * std64 + mean64 * mean64) * m_local
-        self._all_reduce('allreduce_attack_stats', acc)
-        mean = acc[0] / n_malicious
-        var = (acc[1] / n_malicious - mean * mean).clamp_min_(0.0)
-        mean32, std32 = mean.to(torch.float32), var.sqrt().to(torch.float32)
-        drift = mean32 - num_std * std32                      # malicious.py:34-36
+        where = holders.index(self.rank) if self.rank in holders else -1
+
+        def walk(mean):
+            """My link of one walk over the malicious rows; the total on the last holder."""
+            if where < 0:
+                return None
+            carry = None
+            if where > 0:
+                carry = torch.empty(d, dtype=torch.float32, device=rows_local.device)
+                self._timed('attack_chain_hop', 4 * d, carry, lambda: self.dist.recv(carry, src=holders[where - 1], group=self.group))
+            total = self.kernels.column_chain(rows_local[:m_local], carry=carry, mean=mean)
+            if where + 1 < len(holders):
+                self._timed('attack_chain_hop', 4 * d, total, lambda: self.dist.send(total, dst=holders[where + 1], group=self.group),
+                            count=False)
+            return total
+
+        total = walk(None)
+        mean = (self.kernels.column_finish(n_malicious, num_std, sum=total) if self.rank == last
+                else torch.empty(d, dtype=torch.float32, device=rows_local.device))
+        if self._collective():
+            self._timed('broadcast_attack_mean', 4 * d, mean, lambda: self.dist.broadcast(mean, src=last, group=self.group))
+        squares = walk(mean)
+        if self.rank == last:
+            std, drift = self.kernels.column_finish(n_malicious, num_std, sumsq=squares, mean=mean)
+            both = torch.stack([std, drift])
+        else:
+            both = torch.empty((2, d), dtype=torch.float32, device=rows_local.device)
+        if self._collective():
+            self._timed('broadcast_attack_vector', 8 * d, both, lambda: self.dist.broadcast(both, src=last, group=self.group))
+        std, drift = both[0], both[1]
         if write_back and m_local > 0:
             rows_local[:m_local] = drift
-        return drift, mean32, std32
+        return drift, mean, std
 
     # ---- layout conversion ---------------------------------------------------------------------------------------------
     def column_slices(self, n_cols):

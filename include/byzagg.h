@@ -172,6 +172,19 @@ int byz_bulyan_dev(byz_ctx* ctx, const float* G_dev, int64_t n_rows, int64_t n_c
 int byz_drift_attack_dev(byz_ctx* ctx, float* G_dev, int64_t n_rows, int64_t n_cols, int64_t ld,
                          float num_std, float* drift_dev, float* mean_dev, float* std_dev,
                          int write_back, void* stream);
+/* The same statistics when the rows are spread over several owners (the clients layout of   */
+/* sharded.py: the malicious clients' rows sit on the first ranks).  numpy adds in row order,  */
+/* so the additions form ONE chain through all owners: each calls byz_column_chain_dev on its  */
+/* rows with the previous owner's output as carry_in (NULL for the first) -- out_sum[c] =      */
+/* carry_in[c] + its rows' values in row order, or with `mean` their fl(fl(x - mean)^2) -- and */
+/* the last owner ends a chain with byz_column_finish_dev: sum != NULL: mean = sum / total_rows */
+/* (written); sumsq != NULL: std = sqrt(sumsq / total_rows), drift = mean - num_std * std (mean */
+/* read where sum is NULL).  Bit for bit what byz_drift_attack_dev returns on the stacked rows. */
+int byz_column_chain_dev(byz_ctx* ctx, const float* G_dev, int64_t n_rows, int64_t n_cols, int64_t ld,
+                         const float* carry_in_dev, const float* mean_dev, float* out_sum_dev, void* stream);
+int byz_column_finish_dev(byz_ctx* ctx, const float* sum_dev, const float* sumsq_dev, int64_t total_rows,
+                          float num_std, int64_t n_cols, float* mean_dev, float* std_dev, float* drift_dev,
+                          void* stream);
 /* The hook alone (malicious.py:34-36): mean[:] -= num_std * std[:], in place on the device. */
 int byz_drift_axpy_dev(byz_ctx* ctx, float* mean_dev, const float* std_dev, int64_t n,
                        float num_std, void* stream);

@@ -247,3 +247,33 @@ def test_gpu_no_defense_is_numpys_mean_bit_for_bit(eng, n, d):
     rng = np.random.default_rng(9100 + n)
     g = (rng.standard_normal((n, d)) + 0.125).astype(np.float32)
     assert same_bits(eng.no_defense(g, n, 0), faithful.no_defense(g, n, 0))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('m,cuts,d,z', [(24, (7, 15), 21840, 1.5), (2400, (1250, 2400 - 1), 4099, 1.5), (240, (1,), 79510, 0.7),
+                                        (100, (33, 34, 99), 1 << 20, 1.5)])
+def test_gpu_attack_chain_through_several_owners_is_the_unsharded_attack(eng, m, cuts, d, z):
+    """The clients layout's attack (sharded.drift_attack_clients): the malicious rows sit on several ranks, each continues the
+    previous one's running sums over its own rows (byz_column_chain_dev), the last ends the chain (byz_column_finish_dev).
+    Looped over the owners on one GPU: bit for bit numpy on the stacked rows, and the unsharded kernels' result."""
+    torch = pytest.importorskip('torch')
+    rng = np.random.default_rng(9400 + m)
+    rows = (rng.standard_normal((m, d)) * 1.5 + 0.3).astype(np.float32)
+    dev = torch.from_numpy(rows).cuda()
+    bounds = [0] + list(cuts) + [m]
+    pieces = [dev[a:b] for a, b in zip(bounds[:-1], bounds[1:]) if b > a]
+
+    def walk(mean):
+        carry = None
+        for piece in pieces:
+            carry = eng.column_chain(piece, carry=carry, mean=mean)
+        return carry
+
+    mean = eng.column_finish(m, z, sum=walk(None))
+    std, drift = eng.column_finish(m, z, sumsq=walk(mean), mean=mean)
+    eng.check()
+    want_mean, want_std = faithful.attack_statistics(rows)
+    assert same_bits(mean.cpu().numpy(), want_mean) and same_bits(std.cpu().numpy(), want_std)
+    assert same_bits(drift.cpu().numpy(), faithful.drift_vector(rows, z))
+    d2, m2, s2 = eng.drift_attack(dev, z)
+    assert torch.equal(d2, drift) and torch.equal(m2, mean) and torch.equal(s2, std)
