@@ -194,6 +194,7 @@ void byz_ctx_destroy(byz_ctx* ctx) {
     ctx->plane_order.release();
     ctx->split_redo.release();
     ctx->plane_unscale.release();
+    ctx->gram_chunk_sums.release();
     ctx->dup_rep.release();
     ctx->row_signature.release();
     ctx->unique_rows.release();

@@ -100,6 +100,7 @@ struct byz_ctx {
     byz::Buffer dup_rep;         // representative row of every group of identical rows (+ one flag word)
     byz::Buffer gram_tickets;    // chunked Gram schedule: next chunk allowed to update a tile's slab
     byz::Buffer gram_planes;     // pre-split Gram: the bf16 planes of one super-chunk of columns, in MFMA fragment order
+    byz::Buffer gram_chunk_sums; // pre-split Gram, f16x2: the fp32 level-1 sums of every (chunk, tile) of a launch (deferred slab update)
     byz::Buffer plane_unscale;   // pre-split Gram, f16x2: 2^-shift of every (chunk, row) of the super-chunk (fp64)
     byz::Buffer plane_order;     // pre-split Gram: (256-row block, 128-row block) of every workgroup tile
     byz::Buffer split_redo;      // pre-split Gram: (chunk, row block) pairs whose sampled scale did not hold (count first)

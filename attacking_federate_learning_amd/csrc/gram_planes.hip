@@ -387,14 +387,20 @@ struct Frags<2, MB> {
 // bit 5 every workgroup's DMA reads tile (0, 0) (the L2 -> LDS rate without misses).
 // MB = 32-row blocks of a wave's sub-tile along the A side: 2 -> eight waves of 64 x 64, two per SIMD.  (MB = 4, four waves of
 // 128 x 64, was built in round 4, is bitwise equal and lost by 8.6 %: EXPERIMENTS.md G4; only MB = 2 is instantiated.)
-template <int PLANES, int NBUF, int DBG, int MB = 2>
+// DEFER (round 5, f16x2): a chunk does not read-modify-write its tile's fp64 slabs (512 KB through the fabric per workgroup
+// and chunk, behind a ticket, with the matrix pipe idle: 8 % of the kernel, EXPERIMENTS.md G3) but WRITES its level-1 sums as
+// they are -- fp32, 128 KB, no read, no ticket -- into `chunk_sums`; chunk_reduce_kernel adds them into the slabs afterwards,
+// in chunk order, in the same fp64 operations: the Gram is bitwise the same.
+template <int PLANES, int NBUF, int DBG, int MB = 2, bool DEFER = false>
 __global__ __launch_bounds__(64 * 16 / MB, 1) void gram_planes_kernel(const u32x4* __restrict__ planes, int64_t n_steps,
                                                                   const double* __restrict__ unscale, int64_t rows_pad,
                                                                   double* __restrict__ partial, int n_tiles,
                                                                   const int2* __restrict__ tile_order, int n_chunks,
                                                                   int* __restrict__ tickets, int round_size, int t128,
                                                                   int slab_live0, int n_blocks32,
-                                                                  int32_t* __restrict__ device_status) {
+                                                                  int32_t* __restrict__ device_status,
+                                                                  float* __restrict__ chunk_sums,
+                                                                  float* __restrict__ ragged_sums) {
     constexpr int kRbBytes = PLANES * kFragBytes;           // one 32-row block, one stage: [plane][1 KiB]
     constexpr int kStage = kRowBlocks * kRbBytes;           // 36,864 (bf16x3) / 24,576 (f16x2)
     constexpr int NW = 16 / MB;                             // waves of the workgroup
@@ -621,6 +627,33 @@ __global__ __launch_bounds__(64 * 16 / MB, 1) void gram_planes_kernel(const u32x
     }
     auto block_live = [&](int m, int n) __attribute__((always_inline)) { return ((live_blocks >> (m * 2 + n)) & 1u) != 0; };
 
+    if constexpr (DEFER) {
+        // this chunk's level-1 sums, as they are: slab `sel` of workgroup tile t_list, chunk `chunk`; element (i, j) where the
+        // fp64 slab has it.  A chunk whose last MFMA chain has not been flushed (n_stages not a multiple of kFlushSteps: only
+        // the ragged last chunk of the matrix) leaves that chain's sums next to them.
+        if (live_wave) {
+            const int sel = (wr * MB) / 4;
+            const bool unflushed = (n_stages % kFlushSteps) != 0;
+            float* out = chunk_sums + ((static_cast<int64_t>(chunk) * n_tiles + t_list) * 2 + sel) * (kSlab * kSlab);
+            float* rag = ragged_sums + (static_cast<int64_t>(t_list) * 2 + sel) * (kSlab * kSlab);
+#pragma unroll
+            for (int m = 0; m < MB; ++m)
+#pragma unroll
+                for (int n = 0; n < 2; ++n) {
+                    if (!block_live(m, n)) continue;
+                    const int j = wc * 64 + n * 32 + (lane & 31);
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        const int i = row_in_slab + m * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+                        out[i * kSlab + j] = acc2[m][n][e];
+                        if (unflushed) rag[i * kSlab + j] = acc[m][n][e];
+                    }
+                }
+        }
+        __syncthreads();
+        if (tid == 0) __hip_atomic_fetch_add(done, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return;
+    }
     // epilogue: chunks of a tile add into its slabs in chunk order (gram.hip's ticket protocol)
     bool lost = false;
     if (chunk > 0) {
@@ -680,6 +713,42 @@ __global__ __launch_bounds__(64 * 16 / MB, 1) void gram_planes_kernel(const u32x
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __hip_atomic_store(tickets + t_list, chunk + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_fetch_add(done, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+// The deferred slab update: slab entry (i, j) of every tile of the launch += its chunks' sums in chunk order -- per chunk
+// v = (double)level-1 sum (+ (double)unflushed chain), v *= 2^-shift_i 2^-shift_j, slab = v + slab: the fp64 operations of
+// the in-kernel update, in its order.  One workgroup per (tile, slab); entries of blocks nobody computed are left alone.
+__global__ __launch_bounds__(256) void chunk_reduce_kernel(const float* __restrict__ chunk_sums, const float* __restrict__ ragged_sums,
+                                                           int n_tiles, int n_chunks, int ragged_chunk,
+                                                           const int2* __restrict__ tile_order, const double* __restrict__ unscale,
+                                                           int64_t rows_pad, double* __restrict__ partial, int slab_live0,
+                                                           int t128, int n_blocks32) {
+    const int t_list = blockIdx.x >> 1, sel = blockIdx.x & 1;
+    const int2 tt = tile_order[t_list];
+    const int ti = 2 * tt.x + sel, tj = tt.y;
+    if (!(tj <= ti && ti < t128)) return;
+    double* out = partial + (static_cast<int64_t>(ti) * (ti + 1) / 2 + tj) * (kSlab * kSlab);
+    const int64_t slab_stride = static_cast<int64_t>(n_tiles) * 2 * (kSlab * kSlab);
+    const float* in = chunk_sums + (static_cast<int64_t>(t_list) * 2 + sel) * (kSlab * kSlab);
+    const float* rag = ragged_sums + (static_cast<int64_t>(t_list) * 2 + sel) * (kSlab * kSlab);
+    for (int idx = threadIdx.x; idx < kSlab * kSlab; idx += 256) {
+        const int i = idx >> 7, j = idx & 127;
+        if (n_blocks32 >= 0) {       // the tile kernel's rule: block (i / 32, j / 32) was computed iff ...
+            const int rblk = ti * 4 + (i >> 5), cblk = tj * 4 + (j >> 5);
+            if (!(rblk < n_blocks32 && cblk <= rblk)) continue;
+        }
+        double v = slab_live0 != 0 ? out[idx] : 0.0;
+        bool live = slab_live0 != 0;
+        for (int c = 0; c < n_chunks; ++c) {
+            double p = static_cast<double>(in[c * slab_stride + idx]);
+            if (c == ragged_chunk) p += static_cast<double>(rag[idx]);
+            const double* un = unscale + static_cast<int64_t>(c) * rows_pad;
+            p *= un[static_cast<int64_t>(ti) * kSlab + i] * un[static_cast<int64_t>(tj) * kSlab + j];
+            v = live ? p + v : p;
+            live = true;
+        }
+        out[idx] = v;
     }
 }
 
@@ -757,8 +826,10 @@ int launch_gram_planes(byz_ctx* ctx, const float* G, int64_t n_rows, int64_t n_c
     int* tickets = ctx->gram_tickets.as<int>();
     u32x4* planes = ctx->gram_planes.as<u32x4>();
     typedef void (*kernel_t)(const u32x4*, int64_t, const double*, int64_t, double*, int, const int2*, int, int*, int, int,
-                             int, int, int32_t*);
-    kernel_t kernel = f16 ? &gram_planes_kernel<2, 6, 0> : &gram_planes_kernel<3, 4, 0>;
+                             int, int, int32_t*, float*, float*);
+    // BYZ_GRAM_DEFER=0: round 4's in-kernel slab update (the same-box A/B and the bitwise comparison of the tests)
+    bool defer = f16 && env_int("BYZ_GRAM_DEFER", 1) != 0;
+    kernel_t kernel = defer ? &gram_planes_kernel<2, 6, 0, 2, true> : f16 ? &gram_planes_kernel<2, 6, 0> : &gram_planes_kernel<3, 4, 0>;
     int nbuf = f16 ? 6 : 4;
     const int threads = kThreads;
 #ifdef BYZ_GRAM_DEBUG_VARIANTS
@@ -766,6 +837,7 @@ int launch_gram_planes(byz_ctx* ctx, const float* G, int64_t n_rows, int64_t n_c
     // Not compiled into the shipped library: build with -DBYZ_GRAM_DEBUG_VARIANTS to get them back.
     {
         const int variant = env_int("BYZ_GRAM_PLANES_VARIANT", 0);
+        if (variant != 0) defer = false;
         if (f16) {
             kernel = variant == 10 ? &gram_planes_kernel<2, 6, 1> : variant == 20 ? &gram_planes_kernel<2, 6, 2>
                      : variant == 50 ? &gram_planes_kernel<2, 6, 5>      // no DMA, no barrier
@@ -780,10 +852,20 @@ int launch_gram_planes(byz_ctx* ctx, const float* G, int64_t n_rows, int64_t n_c
         }
     }
 #endif
+    float* chunk_sums = nullptr;
+    float* ragged_sums = nullptr;
+    if (defer) {
+        // fp32 level-1 sums of every (chunk, tile, slab) of a launch + one more slab pair per tile for an unflushed chain
+        const size_t per_chunk = static_cast<size_t>(n_tiles) * 2 * kSlab * kSlab * sizeof(float);
+        BYZ_TRY(ctx->gram_chunk_sums.ensure(per_chunk * static_cast<size_t>(chunks_per_sc + 1)));
+        chunk_sums = ctx->gram_chunk_sums.as<float>();
+        ragged_sums = chunk_sums + (per_chunk / sizeof(float)) * static_cast<size_t>(chunks_per_sc);
+    }
     const size_t lds_bytes = static_cast<size_t>(nbuf) * kRowBlocks * n_planes * kFragBytes;
     BYZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 static_cast<int>(lds_bytes)));
     const int round_size = env_int("BYZ_GRAM_ROUND", ctx->num_cus / 8);   // one workgroup per CU
+    const int n_blocks32 = env_int("BYZ_GRAM_BLOCK_SKIP", 1) != 0 ? static_cast<int>(ceil_div(n_rows, 32)) : -1;
     const int64_t per_xcd = ceil_div(n_tiles, 8);
     for (int64_t sc = 0; sc < n_sc; ++sc) {
         const int64_t k0 = sc * sc_cols;
@@ -829,8 +911,16 @@ int launch_gram_planes(byz_ctx* ctx, const float* G, int64_t n_rows, int64_t n_c
             kernel<<<static_cast<unsigned>(grid), threads, lds_bytes, stream>>>(
                 planes, n_steps, unscale, rows_pad, slabs, static_cast<int>(n_tiles), ctx->plane_order.as<int2>(),
                 static_cast<int>(n_chunks), tickets, round_size, static_cast<int>(t128), sc > 0 ? 1 : 0,
-                env_int("BYZ_GRAM_BLOCK_SKIP", 1) != 0 ? static_cast<int>(ceil_div(n_rows, 32)) : -1, device_status_word(ctx));
+                n_blocks32, device_status_word(ctx), chunk_sums, ragged_sums);
             BYZ_TRY(check_launch("gram_planes_kernel"));
+        }
+        if (defer) {
+            KernelTimer t(ctx, BYZ_K_GRAM_REDUCE, stream);
+            const int ragged_chunk = (n_steps % kChunkSteps) % kFlushSteps != 0 ? static_cast<int>(n_chunks) - 1 : -1;
+            chunk_reduce_kernel<<<static_cast<unsigned>(2 * n_tiles), 256, 0, stream>>>(
+                chunk_sums, ragged_sums, static_cast<int>(n_tiles), static_cast<int>(n_chunks), ragged_chunk,
+                ctx->plane_order.as<int2>(), unscale, rows_pad, slabs, sc > 0 ? 1 : 0, static_cast<int>(t128), n_blocks32);
+            BYZ_TRY(check_launch("chunk_reduce_kernel"));
         }
     }
     return BYZ_OK;

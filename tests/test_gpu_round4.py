@@ -125,6 +125,20 @@ def test_gram_with_skipped_blocks_is_bitwise_the_slab_granular_gram(eng, monkeyp
     assert torch.equal(base, lean), float((base - lean).abs().max())
     assert torch.equal(base, lean_many)
     assert torch.equal(lean, lean.T)
+    # round 5, second change: the chunks' level-1 sums are written out and added into the fp64 slabs by a kernel behind the
+    # tile kernel (chunk order, the same fp64 operations) instead of read-modify-written under a ticket inside it
+    # (BYZ_GRAM_DEFER=0: the in-kernel update): bitwise the same, with one super-chunk and with several, skip on and off
+    monkeypatch.setenv('BYZ_GRAM_DEFER', '0')
+    inline_many = eng.gram(g).clone()
+    monkeypatch.delenv('BYZ_GRAM_PLANE_MB')
+    inline_one = eng.gram(g).clone()
+    monkeypatch.setenv('BYZ_GRAM_BLOCK_SKIP', '0')
+    inline_all_blocks = eng.gram(g).clone()
+    monkeypatch.setenv('BYZ_GRAM_DEFER', '1')
+    deferred_all_blocks = eng.gram(g).clone()
+    eng.check()
+    assert torch.equal(inline_many, lean) and torch.equal(inline_one, lean)
+    assert torch.equal(inline_all_blocks, lean) and torch.equal(deferred_all_blocks, lean)
     # the last rows and the diagonal against fp64
     rows = torch.tensor([0, 1, 31, 32, 63, 64, 127, 128, n - 33, n - 32, n - 2, n - 1], device='cuda')
     want = g[rows].double() @ g.double().T
