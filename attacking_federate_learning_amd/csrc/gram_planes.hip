@@ -718,12 +718,16 @@ __global__ __launch_bounds__(64 * 16 / MB, 1) void gram_planes_kernel(const u32x
 
 // The deferred slab update: slab entry (i, j) of every tile of the launch += its chunks' sums in chunk order -- per chunk
 // v = (double)level-1 sum (+ (double)unflushed chain), v *= 2^-shift_i 2^-shift_j, slab = v + slab: the fp64 operations of
-// the in-kernel update, in its order.  One workgroup per (tile, slab); entries of blocks nobody computed are left alone.
+// the in-kernel update, in its order.  One workgroup per (tile, slab, quarter of its rows); a thread owns four consecutive
+// columns of a row and keeps kReduceRun chunks' loads in flight (the additions then run in chunk order: a first version with
+// one dependent load per addition ran at 0.7 TB/s, 6 ms per launch).  Entries of blocks nobody computed are left alone.
+constexpr int kReduceRun = 8;
 __global__ __launch_bounds__(256) void chunk_reduce_kernel(const float* __restrict__ chunk_sums, const float* __restrict__ ragged_sums,
                                                            int n_tiles, int n_chunks, int ragged_chunk,
                                                            const int2* __restrict__ tile_order, const double* __restrict__ unscale,
                                                            int64_t rows_pad, double* __restrict__ partial, int slab_live0,
                                                            int t128, int n_blocks32) {
+    typedef double f64x4 __attribute__((ext_vector_type(4)));
     const int t_list = blockIdx.x >> 1, sel = blockIdx.x & 1;
     const int2 tt = tile_order[t_list];
     const int ti = 2 * tt.x + sel, tj = tt.y;
@@ -732,23 +736,49 @@ __global__ __launch_bounds__(256) void chunk_reduce_kernel(const float* __restri
     const int64_t slab_stride = static_cast<int64_t>(n_tiles) * 2 * (kSlab * kSlab);
     const float* in = chunk_sums + (static_cast<int64_t>(t_list) * 2 + sel) * (kSlab * kSlab);
     const float* rag = ragged_sums + (static_cast<int64_t>(t_list) * 2 + sel) * (kSlab * kSlab);
-    for (int idx = threadIdx.x; idx < kSlab * kSlab; idx += 256) {
-        const int i = idx >> 7, j = idx & 127;
-        if (n_blocks32 >= 0) {       // the tile kernel's rule: block (i / 32, j / 32) was computed iff ...
-            const int rblk = ti * 4 + (i >> 5), cblk = tj * 4 + (j >> 5);
+    // blockIdx.y: a quarter of the slab's rows; a thread: row i, columns j .. j + 3 (all in one 32 x 32 block)
+    const int i = static_cast<int>(blockIdx.y) * 32 + (threadIdx.x >> 3), j = (threadIdx.x & 7) * 4;
+    for (int jb = 0; jb < kSlab; jb += 32) {
+        const int jj = jb + j;
+        if (n_blocks32 >= 0) {       // the tile kernel's rule: block (i / 32, jj / 32) was computed iff ...
+            const int rblk = ti * 4 + (i >> 5), cblk = tj * 4 + (jj >> 5);
             if (!(rblk < n_blocks32 && cblk <= rblk)) continue;
         }
-        double v = slab_live0 != 0 ? out[idx] : 0.0;
+        const int idx = i * kSlab + jj;
+        f64x4 v = {0.0, 0.0, 0.0, 0.0};
         bool live = slab_live0 != 0;
-        for (int c = 0; c < n_chunks; ++c) {
-            double p = static_cast<double>(in[c * slab_stride + idx]);
-            if (c == ragged_chunk) p += static_cast<double>(rag[idx]);
-            const double* un = unscale + static_cast<int64_t>(c) * rows_pad;
-            p *= un[static_cast<int64_t>(ti) * kSlab + i] * un[static_cast<int64_t>(tj) * kSlab + j];
-            v = live ? p + v : p;
-            live = true;
+        if (live) v = *reinterpret_cast<const f64x4*>(out + idx);
+        for (int c0 = 0; c0 < n_chunks; c0 += kReduceRun) {
+            f32x4 p[kReduceRun];
+            double ui[kReduceRun];
+            f64x4 uj[kReduceRun];
+#pragma unroll
+            for (int k = 0; k < kReduceRun; ++k) {
+                const int c = c0 + k < n_chunks ? c0 + k : n_chunks - 1;
+                p[k] = *reinterpret_cast<const f32x4*>(in + c * slab_stride + idx);
+                const double* un = unscale + static_cast<int64_t>(c) * rows_pad;
+                ui[k] = un[static_cast<int64_t>(ti) * kSlab + i];
+                uj[k] = *reinterpret_cast<const f64x4*>(un + static_cast<int64_t>(tj) * kSlab + jj);
+            }
+#pragma unroll
+            for (int k = 0; k < kReduceRun; ++k) {
+                if (c0 + k >= n_chunks) break;
+                f64x4 q = {static_cast<double>(p[k][0]), static_cast<double>(p[k][1]), static_cast<double>(p[k][2]),
+                           static_cast<double>(p[k][3])};
+                if (c0 + k == ragged_chunk) {
+                    const f32x4 r = *reinterpret_cast<const f32x4*>(rag + idx);
+                    q[0] += static_cast<double>(r[0]); q[1] += static_cast<double>(r[1]);
+                    q[2] += static_cast<double>(r[2]); q[3] += static_cast<double>(r[3]);
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    q[e] *= ui[k] * uj[k][e];
+                    v[e] = live ? q[e] + v[e] : q[e];
+                }
+                live = true;
+            }
         }
-        out[idx] = v;
+        *reinterpret_cast<f64x4*>(out + idx) = v;
     }
 }
 
@@ -917,7 +947,7 @@ int launch_gram_planes(byz_ctx* ctx, const float* G, int64_t n_rows, int64_t n_c
         if (defer) {
             KernelTimer t(ctx, BYZ_K_GRAM_REDUCE, stream);
             const int ragged_chunk = (n_steps % kChunkSteps) % kFlushSteps != 0 ? static_cast<int>(n_chunks) - 1 : -1;
-            chunk_reduce_kernel<<<static_cast<unsigned>(2 * n_tiles), 256, 0, stream>>>(
+            chunk_reduce_kernel<<<dim3(static_cast<unsigned>(2 * n_tiles), 4), 256, 0, stream>>>(
                 chunk_sums, ragged_sums, static_cast<int>(n_tiles), static_cast<int>(n_chunks), ragged_chunk,
                 ctx->plane_order.as<int2>(), unscale, rows_pad, slabs, sc > 0 ? 1 : 0, static_cast<int>(t128), n_blocks32);
             BYZ_TRY(check_launch("chunk_reduce_kernel"));

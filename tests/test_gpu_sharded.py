@@ -303,5 +303,6 @@ def test_sharded_aggregator_over_rccl_at_world_size_one(eng):
     report = json.loads([ln for ln in proc.stdout.splitlines() if ln.startswith('{')][-1])
     assert report['ok'], report
     for name in ('allreduce_gram', 'allreduce_near_pairs', 'allgather_row_tiles', 'allgather_output',
-                 'reshard_selected_rows', 'reshard_clients_to_columns', 'broadcast_row', 'allreduce_attack_stats'):
+                 'reshard_selected_rows', 'reshard_clients_to_columns', 'broadcast_row', 'broadcast_attack_mean',
+                 'broadcast_attack_vector'):
         assert report['comm'].get(name, {}).get('calls', 0) >= 1, (name, report['comm'])
