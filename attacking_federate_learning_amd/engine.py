@@ -752,21 +752,21 @@ class Engine:
         if n_clients == 0:
             return
         n_seg = len(clients_grads[0])
-        flat = list(itertools.chain.from_iterable(clients_grads))
-        if len(flat) != n_clients * n_seg:
-            raise ValueError('every client must hand over the same number of tensors')
         key = None
-        if _is_torch(flat[0]):
+        if n_seg and _is_torch(clients_grads[0][0]):
             import torch
-            try:     # C-level map: no Python frame per tensor
-                key = (n_clients, n_seg, m.cols, tuple(map(torch.Tensor.data_ptr, flat)))
+            try:     # C-level chain + map: no Python frame per tensor, no intermediate list
+                key = (n_clients, n_seg, m.cols, tuple(map(torch.Tensor.data_ptr, itertools.chain.from_iterable(clients_grads))))
             except TypeError:
                 key = None      # DeviceBuffers among them: the general path below
-        if key is not None and key == self._assemble_key:
+        if key is not None and key == self._assemble_key:      # (equal keys: equal tensor counts too)
             _check(self.lib.byz_assemble_rows_again_dev(self.ctx, _vp(m.ptr), m.rows, m.cols, m.ld, int(first_row), n_clients,
                                                         n_seg, _vp(m.stream)))
             return
         self._assemble_key = None
+        flat = list(itertools.chain.from_iterable(clients_grads))
+        if len(flat) != n_clients * n_seg:
+            raise ValueError('every client must hand over the same number of tensors')
         ptrs, keep, lens, temporaries = [], [], None, False
         for c in range(n_clients):
             mine = []
