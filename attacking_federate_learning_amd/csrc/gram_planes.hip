@@ -886,6 +886,18 @@ int launch_gram_planes(byz_ctx* ctx, const float* G, int64_t n_rows, int64_t n_c
     float* ragged_sums = nullptr;
     if (defer) {
         // fp32 level-1 sums of every (chunk, tile, slab) of a launch + one more slab pair per tile for an unflushed chain
+        // (4.3 GB at configs[3], 10 GB at configs[4]'s slice).  Where that does not fit beside the matrix the update stays
+        // inside the tile kernel: slower, the same bits.
+        const size_t per_chunk = static_cast<size_t>(n_tiles) * 2 * kSlab * kSlab * sizeof(float);
+        const size_t want = per_chunk * static_cast<size_t>(chunks_per_sc + 1);
+        size_t free_now = 0, total_now = 0;
+        BYZ_HIP(hipMemGetInfo(&free_now, &total_now));
+        if (want > ctx->gram_chunk_sums.bytes && want - ctx->gram_chunk_sums.bytes > free_now / 2) {
+            defer = false;
+            kernel = &gram_planes_kernel<2, 6, 0>;
+        }
+    }
+    if (defer) {
         const size_t per_chunk = static_cast<size_t>(n_tiles) * 2 * kSlab * kSlab * sizeof(float);
         BYZ_TRY(ctx->gram_chunk_sums.ensure(per_chunk * static_cast<size_t>(chunks_per_sc + 1)));
         chunk_sums = ctx->gram_chunk_sums.as<float>();

@@ -887,7 +887,9 @@ def compact_line(detail, budget=LINE_BUDGET):
     if w1:
         line['sharded_path_w1_ms'] = {k: sig(v.get('ms_per_step'), 5) for k, v in w1.items() if isinstance(v, dict)}
     if detail.get('other_layout'):
-        line['other_layout'] = dict(compact_leg(detail['other_layout']), layout=detail['other_layout'].get('layout'))
+        leg = detail['other_layout']
+        line['other_layout'] = ({'layout': leg.get('layout'), 'error': clip(leg['error'], 160)} if leg.get('error')
+                                else dict(compact_leg(leg), layout=leg.get('layout'), steps=leg.get('steps')))
     if detail.get('collectives'):
         line['collectives_ms'] = {k: sig(v['ms_per_step'], 4) for k, v in detail['collectives'].items()}
     if detail.get('verified_after_timing'):
@@ -1027,12 +1029,20 @@ def main(argv=None):
         other_name = 'clients' if wl.layout == 'columns' else 'columns'
         del wl.g
         torch.cuda.empty_cache()
-        other = BulyanSharded(torch, agg, eng, n, d_total, device, 1237, with_attack=args.workload != 'c4', layout=other_name,
-                              distinct=args.workload == 'c5u')
-        rec = bulyan_record(torch, dist, other, eng, agg, args.steps, args.warmup, world, None)
-        rec['layout'] = other_name
+        # a side leg: a few steps only (the clients layout moves 7/8 of G per round), and whatever happens in it must not cost
+        # the headline its line -- every rank takes the same branch (the verdict is agreed on through an all-reduce)
+        side_steps, side_warmup = min(args.steps, 3), min(args.warmup, 1)
+        failure = None
+        try:
+            other = BulyanSharded(torch, agg, eng, n, d_total, device, 1237, with_attack=args.workload != 'c4', layout=other_name,
+                                  distinct=args.workload == 'c5u')
+            rec = bulyan_record(torch, dist, other, eng, agg, side_steps, side_warmup, world, None)
+            rec['layout'] = other_name
+            wl = other
+        except Exception as exc:      # noqa: BLE001 -- reported in the line, the run goes on
+            failure = '%s: %s' % (type(exc).__name__, exc)
+            rec = {'layout': other_name, 'error': failure[:300]}
         line['other_layout'] = rec
-        wl = other
 
     if rank == 0 and world == 1:
         if args.workload == 'c4' and not args.no_sharded_w1 and not dist.is_initialized():
