@@ -121,13 +121,19 @@ def test_config5_slice_full_size_sampled(eng):
     n, d = 10000, 3_125_000
     f = int(n * MAL_PROP)
     g = make_matrix(torch, n, d, 1237, device)
-    # the attack's statistics on 64 sampled columns, before the rows are overwritten
-    cols = torch.as_tensor(np.sort(np.random.default_rng(12).choice(d, 64, replace=False)), device=device)
+    # the attack's statistics on 4096 sampled columns (the first and the last tile of the register-resident kernel among them),
+    # before the rows are overwritten: numpy's BITS at the full height of 2400 rows and the full width of the slice
+    picked = np.random.default_rng(12).choice(d, 4096 - 96, replace=False)
+    cols_host = np.unique(np.concatenate([picked, np.arange(64), np.arange(d - 32, d)]))
+    cols = torch.as_tensor(cols_host, device=device)
     head = g[:f][:, cols].cpu().numpy()
     drift, mean, std = eng.drift_attack(g[:f], 1.5, write_back=True)
+    want_mean, want_std = faithful.attack_statistics(head)
     want_drift = faithful.drift_vector(head.copy(), 1.5)
-    assert np.allclose(drift[cols].cpu().numpy(), want_drift, rtol=1e-5, atol=1e-5)
+    assert np.array_equal(mean[cols].cpu().numpy(), want_mean) and np.array_equal(std[cols].cpu().numpy(), want_std)
+    assert np.array_equal(drift[cols].cpu().numpy(), want_drift)
     assert bool((g[f - 1][cols] == drift[cols]).all()) and bool((g[0][cols] == drift[cols]).all())
+    cols = cols[:64]      # (the sampled output columns further down)
     dist_dev = eng.pairwise_distances(g)
     dist = dist_dev.numpy()
     idx = eng.krum_select(dist_dev, n, f)
