@@ -85,6 +85,23 @@ def test_minimal_record_no_cpu_baseline_no_extras():
     assert line['roofline']['frac'] > 0
 
 
+def test_multi_gpu_record_with_a_failed_side_leg_still_gives_the_line():
+    """An 8-rank record: collectives booked, the other layout's side leg either timed or failed -- the headline's line stands."""
+    rec = full_record()
+    rec['n_gpus'] = rec['ranks_seen'] = 8
+    for key in ('cpu_baseline', 'other_workloads', 'sharded_path_w1', 'projected'):
+        rec.pop(key, None)
+    rec['collectives'] = {'allreduce_gram': {'calls_per_step': 1.0, 'MB_per_step': 112.0, 'ms_per_step': 1.4},
+                          'allgather_output': {'calls_per_step': 1.0, 'MB_per_step': 35.0, 'ms_per_step': 0.3}}
+    rec['other_layout'] = {'layout': 'clients', 'error': 'RuntimeError: ' + 'x' * 500}
+    line = json.loads(bench.compact_line(rec))
+    assert line['n_gpus'] == 8 and line['other_layout']['layout'] == 'clients' and len(line['other_layout']['error']) <= 160
+    assert line['collectives_ms']['allreduce_gram'] == 1.4 and line['cpu_baseline'] is None
+    rec['other_layout'] = dict(full_record()['other_workloads']['c5s'], layout='clients', steps=3)
+    line = json.loads(bench.compact_line(rec))
+    assert line['other_layout']['layout'] == 'clients' and line['other_layout']['steps'] == 3 and line['other_layout']['value'] > 0
+
+
 def test_emit_writes_the_detail_file_and_one_stdout_line(tmp_path, capfd):
     rec = full_record()
     path = str(tmp_path / 'detail.json')
