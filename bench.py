@@ -1022,30 +1022,55 @@ def main(argv=None):
         line['verified_after_timing'] = wl.verify()
     if world == 1 and isinstance(wl, BulyanSharded) and wl.layout == 'columns':
         line['projected'] = projected_scaling(wl, line['kernels'], ms_per_step)
-    if args.workload in ('c4', 'c5s', 'c5u') and (args.layout == 'both' or (world > 1 and args.layout == 'columns'
-                                                                           and os.environ.get('BYZ_BENCH_ONE_LAYOUT') != '1')):
-        # the other layout, same K steps: north_star names client sharding with an all-gather of row tiles; which one is
-        # faster is a measurement, so every multi-GPU run records both
+    want_side_leg = args.workload in ('c4', 'c5s', 'c5u') and (args.layout == 'both' or (
+        world > 1 and args.layout == 'columns' and os.environ.get('BYZ_BENCH_ONE_LAYOUT') != '1'))
+
+    def side_leg():
+        """The other layout, a few steps (the clients layout moves 7/8 of G per round): north_star names client sharding with
+        row tiles exchanged over xGMI; which layout is faster is a measurement, so every multi-GPU run
+        records both.  Whatever happens in it is reported, never raised."""
         other_name = 'clients' if wl.layout == 'columns' else 'columns'
-        del wl.g
+        wl.g = None
         torch.cuda.empty_cache()
-        # a side leg: a few steps only (the clients layout moves 7/8 of G per round), and whatever happens in it must not cost
-        # the headline its line -- every rank takes the same branch (the verdict is agreed on through an all-reduce)
         side_steps, side_warmup = min(args.steps, 3), min(args.warmup, 1)
-        failure = None
         try:
             other = BulyanSharded(torch, agg, eng, n, d_total, device, 1237, with_attack=args.workload != 'c4', layout=other_name,
                                   distinct=args.workload == 'c5u')
             rec = bulyan_record(torch, dist, other, eng, agg, side_steps, side_warmup, world, None)
             rec['layout'] = other_name
-            wl = other
-        except Exception as exc:      # noqa: BLE001 -- reported in the line, the run goes on
-            failure = '%s: %s' % (type(exc).__name__, exc)
-            rec = {'layout': other_name, 'error': failure[:300]}
-        line['other_layout'] = rec
+            return rec, other
+        except Exception as exc:      # noqa: BLE001
+            return {'layout': other_name, 'error': ('%s: %s' % (type(exc).__name__, exc))[:300]}, None
+
+    if want_side_leg and world > 1:
+        # At W > 1 the headline's line goes out FIRST: the side leg runs code no multi-GPU box has run yet (one GPU is all the
+        # builder ever had), and neither an exception nor a hang in it may cost the record its headline.  A watchdog ends every
+        # rank with status 0 if the leg outlives its budget; its result, when there is one, goes to the detail file.
+        if rank == 0:
+            emit(line, args.detail_file)
+        import threading
+        watchdog = threading.Timer(float(os.environ.get('BYZ_BENCH_SIDE_LEG_SECONDS', '240')), lambda: os._exit(0))
+        watchdog.daemon = True
+        watchdog.start()
+        rec, _ = side_leg()
+        watchdog.cancel()
+        if rank == 0 and args.detail_file:
+            line['other_layout'] = rec
+            try:
+                with open(args.detail_file, 'w') as fh:
+                    json.dump(line, fh, indent=1)
+            except OSError:
+                pass
+        if dist.is_initialized():
+            dist.destroy_process_group()
+        return
+    if want_side_leg:
+        line['other_layout'], other = side_leg()
+        if other is not None:
+            wl = other        # (the legs below run on the matrix that is resident now)
 
     if rank == 0 and world == 1:
-        if args.workload == 'c4' and not args.no_sharded_w1 and not dist.is_initialized():
+        if args.workload == 'c4' and not args.no_sharded_w1 and not dist.is_initialized() and getattr(wl, 'g', None) is not None:
             line['sharded_path_w1'] = sharded_path_at_one_rank(torch, dist, wl, eng, device, traffic)
             if wl.layout == 'columns' and 'columns' in line['sharded_path_w1']:
                 # the projection is built from the kernels that run at W > 1 (Gram -> all-reduce -> distances + near pairs)
