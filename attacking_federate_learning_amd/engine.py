@@ -708,10 +708,13 @@ class Engine:
                 else:
                     raise ValueError('a list of gradients must hold device tensors; pass host data as one flat vector')
                 keep.append(t)
+            sync_after = self._order_after_torch(m, keep)
             table = (ctypes.c_void_p * len(ptrs))(*ptrs)
             lengths = (ctypes.c_int64 * len(lens))(*lens)
             _check(self.lib.byz_assemble_row_dev(self.ctx, _vp(m.ptr), m.rows, m.cols, m.ld, int(row), len(ptrs),
                                                  table, lengths, _vp(m.stream)))
+            if sync_after:
+                self.synchronize(m.stream)
             return
         host = grads.detach().cpu().numpy() if _is_torch(grads) else np.asarray(grads)
         host = np.ascontiguousarray(host, dtype=np.float32).ravel()
@@ -822,10 +825,13 @@ class Engine:
             else:
                 raise ValueError('batched gradients must be device tensors')
             keep.append(t)
+        sync_after = self._order_after_torch(m, keep)
         table = (ctypes.c_void_p * len(ptrs))(*ptrs)
         lengths = (ctypes.c_int64 * len(lens))(*lens)
         _check(self.lib.byz_assemble_columns_dev(self.ctx, _vp(m.ptr), m.rows, m.cols, m.ld, len(ptrs), table, lengths,
                                                  _vp(m.stream)))
+        if sync_after:
+            self.synchronize(m.stream)
 
     # ---- timing ------------------------------------------------------------------------------
     def timing(self, on=True):
