@@ -10,6 +10,9 @@ mkdir -p $OUT
 export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
 if [ "${2:-}" != "skip-tests" ]; then
+  # (--timeout must stay far above what a COLD box needs for its first `import torch` (1-2 minutes): pytest-timeout's alarm in the
+  # middle of that import corrupts it and the interpreter dies with a core dump -- seen once with --timeout 120, reproduced with
+  # --timeout 4.  The driver's own command has no --timeout.)
   echo "== pytest -m gpu"
   timeout 1500 python -m pytest tests -m gpu -q --timeout 300 --durations=10 2>&1 | tail -40 > $OUT/pytest_gpu.txt; tail -4 $OUT/pytest_gpu.txt
   echo "== smoke"
