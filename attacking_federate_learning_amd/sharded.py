@@ -350,6 +350,10 @@ class ShardedAggregator:
         d = rows_local.shape[1]
         where = holders.index(self.rank) if self.rank in holders else -1
 
+        def peer(r):
+            """torch.distributed addresses send / recv / broadcast by GLOBAL rank even when a group is given."""
+            return self.dist.get_global_rank(self.group, r) if self.group is not None else r
+
         def walk(mean):
             """My link of one walk over the malicious rows; the total on the last holder."""
             if where < 0:
@@ -357,10 +361,10 @@ class ShardedAggregator:
             carry = None
             if where > 0:
                 carry = torch.empty(d, dtype=torch.float32, device=rows_local.device)
-                self._timed('attack_chain_hop', 4 * d, carry, lambda: self.dist.recv(carry, src=holders[where - 1], group=self.group))
+                self._timed('attack_chain_hop', 4 * d, carry, lambda: self.dist.recv(carry, src=peer(holders[where - 1]), group=self.group))
             total = self.kernels.column_chain(rows_local[:m_local], carry=carry, mean=mean)
             if where + 1 < len(holders):
-                self._timed('attack_chain_hop', 4 * d, total, lambda: self.dist.send(total, dst=holders[where + 1], group=self.group),
+                self._timed('attack_chain_hop', 4 * d, total, lambda: self.dist.send(total, dst=peer(holders[where + 1]), group=self.group),
                             count=False)
             return total
 
@@ -368,7 +372,7 @@ class ShardedAggregator:
         mean = (self.kernels.column_finish(n_malicious, num_std, sum=total) if self.rank == last
                 else torch.empty(d, dtype=torch.float32, device=rows_local.device))
         if self._collective():
-            self._timed('broadcast_attack_mean', 4 * d, mean, lambda: self.dist.broadcast(mean, src=last, group=self.group))
+            self._timed('broadcast_attack_mean', 4 * d, mean, lambda: self.dist.broadcast(mean, src=peer(last), group=self.group))
         squares = walk(mean)
         if self.rank == last:
             std, drift = self.kernels.column_finish(n_malicious, num_std, sumsq=squares, mean=mean)
@@ -376,7 +380,7 @@ class ShardedAggregator:
         else:
             both = torch.empty((2, d), dtype=torch.float32, device=rows_local.device)
         if self._collective():
-            self._timed('broadcast_attack_vector', 8 * d, both, lambda: self.dist.broadcast(both, src=last, group=self.group))
+            self._timed('broadcast_attack_vector', 8 * d, both, lambda: self.dist.broadcast(both, src=peer(last), group=self.group))
         std, drift = both[0], both[1]
         if write_back and m_local > 0:
             rows_local[:m_local] = drift

@@ -236,6 +236,69 @@ def test_ranks_equal_the_unsharded_oracle(world, n, d, f):
             assert r['comm']['allreduce_near_pairs']['calls'] >= 2
 
 
+def subgroup_worker(rank, world, port, members, n, d, m, f, results):
+    """A process group that does NOT start at global rank 0: every send / recv / broadcast of the sharded layer must
+    address peers by GLOBAL rank (drift_attack_clients passed group-local ranks)."""
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        group = dist.new_group(ranks=members)        # collective over the whole world: every rank calls it
+        if rank not in members:
+            return
+        from attacking_federate_learning_amd.sharded import ShardedAggregator
+        agg = ShardedAggregator(OracleKernels(), group=group)
+        assert agg.world == len(members) and agg.rank == members.index(rank)
+        g = make_matrix(n, d, m)
+        w = agg.world
+        rows_per_rank = [n // w + (1 if r < n % w else 0) for r in range(w)]
+        start = sum(rows_per_rank[:agg.rank])
+        mine = torch.from_numpy(g[start:start + rows_per_rank[agg.rank]].copy())
+        out = {}
+        drift, _, _ = agg.drift_attack_clients(mine, rows_per_rank, m, 1.5)
+        out['c_drift'] = drift.numpy()
+        out['c_rows'] = mine.numpy().copy()
+        out['c_krum_index'] = agg.krum_clients(mine, rows_per_rank, n, f, return_index=True)
+        out['c_krum'] = agg.krum_clients(mine, rows_per_rank, n, f).numpy()
+        b, sel = agg.bulyan_clients(mine, rows_per_rank, n, f, return_selection=True)
+        out['c_bulyan'], out['c_selection'] = b.numpy(), np.asarray(sel)
+        # ... and the columns layout through the same group
+        mine3 = torch.from_numpy(g[start:start + rows_per_rank[agg.rank]].copy())
+        g_local = agg.reshard_clients_to_columns(mine3, rows_per_rank)
+        agg.drift_attack(g_local, m, 1.5, write_back=True)
+        out['krum_index'] = agg.krum(g_local, n, f, return_index=True)
+        b2, sel2 = agg.bulyan(g_local, n, f, gather=True, return_selection=True, total_columns=d)
+        out['bulyan'], out['selection'] = b2.numpy(), np.asarray(sel2)
+        results[rank] = out
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('world,members,n,d,m,f', [(3, [1, 2], 23, 157, 14, 5), (4, [1, 3], 12, 64, 7, 2)])
+def test_a_subgroup_that_does_not_start_at_global_rank_zero(world, members, n, d, m, f):
+    """m malicious rows reach into the SECOND member's rows, so the chain hop (recv / send) and both broadcasts of
+    drift_attack_clients run between global ranks (1, 2) / (1, 3) while the group-local ranks are (0, 1)."""
+    with mp.Manager() as manager:
+        results = manager.dict()
+        mp.spawn(subgroup_worker, args=(world, free_port(), members, n, d, m, f, results), nprocs=world, join=True)
+        results = dict(results)
+    assert sorted(results) == members
+    g = make_matrix(n, d, m)
+    g[:m] = faithful.drift_vector(g[:m].copy(), 1.5)
+    want_bulyan, want_sel = faithful.bulyan(g, n, f, return_selection=True)
+    want_krum = faithful.krum(g, n, f, return_index=True)
+    w = len(members)
+    for rank in members:
+        r = results[rank]
+        assert np.array_equal(r['c_drift'], g[0])
+        lo = sum(n // w + (1 if q < n % w else 0) for q in range(members.index(rank)))
+        assert np.array_equal(r['c_rows'], g[lo:lo + len(r['c_rows'])])
+        assert r['c_krum_index'] == want_krum and r['krum_index'] == want_krum
+        assert np.allclose(r['c_krum'], g[want_krum], rtol=1e-6, atol=1e-6)
+        assert r['c_selection'].tolist() == want_sel and r['selection'].tolist() == want_sel
+        assert np.allclose(r['c_bulyan'], want_bulyan, rtol=1e-5, atol=1e-6)
+        assert np.array_equal(r['bulyan'], want_bulyan)
+
+
 def test_column_slices_cover_everything():
     from attacking_federate_learning_amd.sharded import ShardedAggregator
 
