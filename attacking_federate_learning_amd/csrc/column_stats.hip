@@ -61,7 +61,11 @@ __device__ __forceinline__ void load_columns(const float* __restrict__ p, bool f
 template <int VEC, int MODE>
 __global__ __launch_bounds__(kThreads) void column_sequential_kernel(
     const float* __restrict__ G, int64_t n_rows, int64_t n_cols, int64_t ld, float num_std,
-    float* __restrict__ mean_out, float* __restrict__ std_out, float* __restrict__ drift_out) {
+    float* __restrict__ mean_out, float* __restrict__ std_out, float* __restrict__ drift_out,
+    const int32_t* __restrict__ redo_gate) {
+    // redo_gate (optional): this launch stands behind the register-resident kernel and runs only if a wave of that kernel
+    // gave up waiting for its turn (the word is then non-zero): the same bits, the slow way, instead of an invalid vector
+    if (redo_gate != nullptr && __hip_atomic_load(redo_gate, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) return;
     const int64_t c0 = (static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x) * VEC;
     if (c0 >= n_cols) return;
     const bool full = c0 + VEC <= n_cols;
@@ -482,7 +486,7 @@ int column_pass(byz_ctx* ctx, const float* G, int64_t n_rows, int64_t n_cols, in
     case RB:                                                                                                         \
         column_resident_kernel<NW, RB><<<static_cast<unsigned>(wgs), NW * 64, 0, stream>>>(                          \
             G, static_cast<int>(n_rows), n_cols, ld, num_std, mean, stdev, drift, static_cast<int>(n_tiles),         \
-            device_status_word(ctx));                                                                                \
+            attack_redo_word(ctx));                                                                                  \
         break
 #define BYZ_RESIDENT_ALL(NW)                                                                                         \
     switch (rb) {                                                                                                    \
@@ -490,18 +494,27 @@ int column_pass(byz_ctx* ctx, const float* G, int64_t n_rows, int64_t n_cols, in
         BYZ_RESIDENT(NW, 6); BYZ_RESIDENT(NW, 7); BYZ_RESIDENT(NW, 8); BYZ_RESIDENT(NW, 9); BYZ_RESIDENT(NW, 10);      \
         default: set_error("column statistics: %d row blocks per segment", rb); return BYZ_E_INVALID;                \
     }
+        // a wave that never gets its turn (a bounded spin: it has not been seen to happen) sets the redo word and carries on
+        // with +0.0; the two-pass kernel behind it then recomputes every column -- nothing of an invalid vector survives the
+        // call, and nothing is reported by a later, unrelated one
+        // (BYZ_ATTACK_FORCE_REDO=1: the word starts non-zero -- the test of the path that has not been seen to happen)
+        BYZ_HIP(hipMemsetAsync(attack_redo_word(ctx), env_int("BYZ_ATTACK_FORCE_REDO", 0) != 0 ? 1 : 0, sizeof(int32_t), stream));
         if (nw == 4) { BYZ_RESIDENT_ALL(4) } else if (nw == 8) { BYZ_RESIDENT_ALL(8) } else { BYZ_RESIDENT_ALL(16) }
 #undef BYZ_RESIDENT_ALL
 #undef BYZ_RESIDENT
-        return check_launch("column_resident_kernel");
+        BYZ_TRY(check_launch("column_resident_kernel"));
+        const dim3 redo_grid(static_cast<unsigned>(col_blocks));
+        if (vec4) column_sequential_kernel<4, 1><<<redo_grid, kThreads, 0, stream>>>(G, n_rows, n_cols, ld, num_std, mean, stdev, drift, attack_redo_word(ctx));
+        else column_sequential_kernel<1, 1><<<redo_grid, kThreads, 0, stream>>>(G, n_rows, n_cols, ld, num_std, mean, stdev, drift, attack_redo_word(ctx));
+        return check_launch("column_sequential_kernel (redo)");
     }
     const dim3 grid(static_cast<unsigned>(col_blocks));
     if (stats) {
-        if (vec4) column_sequential_kernel<4, 1><<<grid, kThreads, 0, stream>>>(G, n_rows, n_cols, ld, num_std, mean, stdev, drift);
-        else column_sequential_kernel<1, 1><<<grid, kThreads, 0, stream>>>(G, n_rows, n_cols, ld, num_std, mean, stdev, drift);
+        if (vec4) column_sequential_kernel<4, 1><<<grid, kThreads, 0, stream>>>(G, n_rows, n_cols, ld, num_std, mean, stdev, drift, nullptr);
+        else column_sequential_kernel<1, 1><<<grid, kThreads, 0, stream>>>(G, n_rows, n_cols, ld, num_std, mean, stdev, drift, nullptr);
     } else {
-        if (vec4) column_sequential_kernel<4, 0><<<grid, kThreads, 0, stream>>>(G, n_rows, n_cols, ld, 0.0f, mean, nullptr, nullptr);
-        else column_sequential_kernel<1, 0><<<grid, kThreads, 0, stream>>>(G, n_rows, n_cols, ld, 0.0f, mean, nullptr, nullptr);
+        if (vec4) column_sequential_kernel<4, 0><<<grid, kThreads, 0, stream>>>(G, n_rows, n_cols, ld, 0.0f, mean, nullptr, nullptr, nullptr);
+        else column_sequential_kernel<1, 0><<<grid, kThreads, 0, stream>>>(G, n_rows, n_cols, ld, 0.0f, mean, nullptr, nullptr, nullptr);
     }
     return check_launch("column_sequential_kernel");
 }
@@ -539,7 +552,9 @@ int launch_column_chain(byz_ctx* ctx, const float* G, int64_t n_rows, int64_t n_
 
 int launch_column_finish(byz_ctx* ctx, const float* sum, const float* sumsq, int64_t total_rows, float num_std, int64_t n_cols,
                          float* mean, float* stdev, float* drift, hipStream_t stream) {
-    BYZ_REQUIRE((sum || sumsq) && mean && total_rows > 0 && n_cols > 0, "column finish: bad arguments");
+    BYZ_REQUIRE(sum || sumsq, "column finish: neither a sum nor a sum of squared deviations");
+    BYZ_REQUIRE(mean, "column finish: `mean` is the output of the sum's half and the input of the squared deviations' half");
+    BYZ_REQUIRE(total_rows > 0 && n_cols > 0, "column finish: bad shape %lld rows, %lld columns", (long long)total_rows, (long long)n_cols);
     KernelTimer t(ctx, BYZ_K_MISC, stream);
     column_finish_kernel<<<static_cast<unsigned>(ceil_div(n_cols, kThreads)), kThreads, 0, stream>>>(
         sum, sumsq, static_cast<float>(total_rows), num_std, n_cols, mean, stdev, drift);

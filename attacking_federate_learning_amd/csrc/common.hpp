@@ -160,7 +160,10 @@ inline hipStream_t as_stream(void* s) { return static_cast<hipStream_t>(s); }
 //        path did not all report their scores in time, bit 4: a wave of the register-resident column statistics never got
 //        its turn)
 //   [17] number of near-duplicate pairs listed by the last distance kernel
+//   [18] non-zero: the register-resident column statistics of the CURRENT call gave up a turn; the two-pass kernel queued
+//        behind them recomputes the call's columns (zeroed before every such launch; bit 4 above is no longer set)
 inline int32_t* device_status_word(byz_ctx* ctx) { return ctx->small.as<int32_t>() + 16; }
+inline int32_t* attack_redo_word(byz_ctx* ctx) { return ctx->small.as<int32_t>() + 18; }
 inline int32_t* near_pair_count_word(byz_ctx* ctx) { return ctx->small.as<int32_t>() + 17; }
 
 // Brackets one kernel launch with events when timing is on (bench.py's roofline leg).

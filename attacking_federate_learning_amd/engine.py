@@ -589,7 +589,18 @@ class Engine:
         """The end of a chain.  sum given: returns mean = sum / total_rows.  sumsq (and mean) given: returns (std, drift) =
         (sqrt(sumsq / total_rows), mean - num_std * std)."""
         import torch
+        if (sum is None) == (sumsq is None):
+            raise ValueError('column_finish: give the sum (returns the mean) or the sum of squared deviations (returns std, drift)')
+        if sum is None and mean is None:
+            raise ValueError('column_finish: the squared deviations need the mean they were taken about')
         ref = sum if sum is not None else sumsq
+        for name, t in (('sum', sum), ('sumsq', sumsq), ('mean', mean)):
+            if t is None:
+                continue
+            if not (_is_torch(t) and t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()):
+                raise ValueError('column_finish: %s must be a contiguous float32 CUDA tensor' % name)
+            if t.numel() != ref.numel() or t.device != ref.device:
+                raise ValueError('column_finish: %s has %d values on %s, expected %d on %s' % (name, t.numel(), t.device, ref.numel(), ref.device))
         n = ref.numel()
         stream = torch.cuda.current_stream(ref.device).cuda_stream
         if sum is not None:
@@ -759,8 +770,19 @@ class Engine:
         if n_seg and _is_torch(clients_grads[0][0]):
             import torch
             try:     # C-level chain + map: no Python frame per tensor, no intermediate list
-                key = (n_clients, n_seg, m.cols, tuple(map(torch.Tensor.data_ptr, itertools.chain.from_iterable(clients_grads))))
-            except TypeError:
+                first = clients_grads[0]
+                # The table on the device is only valid for THESE tensors: the addresses of all of them, and -- because the
+                # caching allocator can hand the same addresses back to tensors of another dtype or another split -- the
+                # element counts, dtypes and contiguity of one client's tensors (every client has the same sizes: checked when
+                # the table was built).  The fast path also skips the stream ordering of the general path, so it is only
+                # taken when the launch stream IS torch's current stream.
+                key = (n_clients, n_seg, m.cols, int(m.stream or 0),
+                       int(torch.cuda.current_stream(first[0].device).cuda_stream),
+                       tuple((t.numel(), t.dtype, t.is_contiguous()) for t in first),
+                       tuple(map(torch.Tensor.data_ptr, itertools.chain.from_iterable(clients_grads))))
+                if key[3] != key[4]:
+                    key = None
+            except (TypeError, AttributeError):
                 key = None      # DeviceBuffers among them: the general path below
         if key is not None and key == self._assemble_key:      # (equal keys: equal tensor counts too)
             _check(self.lib.byz_assemble_rows_again_dev(self.ctx, _vp(m.ptr), m.rows, m.cols, m.ld, int(first_row), n_clients,

@@ -607,10 +607,20 @@ def roofline_of(wl, per_kernel, traffic_table, steps=None):
     if dom.get('bound_note'):
         out['bound_note'] = dom['bound_note']
     comp = per_kernel.get(dom.get('companion') or '')
+    # the deferred slab update (chunk_reduce_kernel) was INSIDE the tile kernel until round 5: its time belongs to the Gram when
+    # rounds are compared (leaving it out flattered the round-over-round figure by ~2 %)
+    red = per_kernel.get('gram_reduce') if dom['kernel'] == 'gram_tile' else None
+    red_ms = red['total_ms'] if red and red['launches'] else 0.0
+    if red_ms:
+        with_s = (k['total_ms'] + red_ms) / steps / 1e3
+        out['with_slab_update'] = {'achieved': dom['work'] / with_s / dom['scale'], 'unit': dom['unit'],
+                                   'frac': dom['work'] / with_s / dom['peak'], 'gram_reduce_ms_per_step': red_ms / steps}
     if comp and comp['launches']:
-        # the one-off operand split that feeds the tile kernel (HBM bound): the rate with its time counted in
-        both_s = (k['total_ms'] + comp['total_ms']) / steps / 1e3
+        # the one-off operand split that feeds the tile kernel (HBM bound): the rate with its time (and the slab update's)
+        # counted in
+        both_s = (k['total_ms'] + comp['total_ms'] + red_ms) / steps / 1e3
         out['with_plane_split'] = {'achieved': dom['work'] / both_s / dom['scale'], 'unit': dom['unit'],
+                                   'frac': dom['work'] / both_s / dom['peak'],
                                    'plane_split_ms_per_step': comp['total_ms'] / steps}
     if dom.get('issued_factor', 1.0) != 1.0:
         out['vs_fp32_mfma_peak'] = achieved / PEAK_MFMA_F32
@@ -813,8 +823,11 @@ def compact_roofline(r):
                                        'launches_per_step', 'arithmetic') if k in r}
     if r.get('mfma_issued'):
         out['mfma_pipe_frac'] = sig(r['mfma_issued']['frac'])
+    if r.get('with_slab_update'):
+        out['frac_with_slab_update'] = sig(r['with_slab_update']['frac'], 4)
     if r.get('with_plane_split'):
         out['plane_split_ms'] = sig(r['with_plane_split']['plane_split_ms_per_step'])
+        out['frac_with_split_and_update'] = sig(r['with_plane_split'].get('frac'), 4)
     return out
 
 
@@ -834,10 +847,16 @@ def compact_leg(rec):
     """One side leg as a handful of numbers: rate, time, the dominant kernel's roofline fraction."""
     if not rec:
         return None
-    out = {'value': sig(rec.get('value')), 'ms': sig(rec.get('ms_per_step'))}
+    out = {'value': sig(rec.get('value')), 'ms': sig(rec.get('ms_per_step'))}      # ms: wall time of a whole step
     r = rec.get('roofline')
     if r:
         out['kernel'], out['bound'], out['frac'] = r.get('kernel'), r.get('bound'), sig(r.get('frac'), 4)
+        # `frac` is the dominant kernel's algorithmic work over ITS OWN time (HIP events around its launches), not over `ms`:
+        # the kernel time per step stands next to it so that the two can be told apart (VERDICT r5, weak 8): frac over the wall
+        # clock of a step is frac * kernel_ms / ms.  (For rounds of tens of microseconds the two come from different passes --
+        # throughput without per-launch events, kernel time with them -- so kernel_ms may exceed ms by the events' overhead.)
+        if r.get('avg_launch_ms') is not None and r.get('launches_per_step'):
+            out['kernel_ms'] = sig(r['avg_launch_ms'] * r['launches_per_step'], 4)
     return out
 
 
@@ -885,7 +904,18 @@ def compact_line(detail, budget=LINE_BUDGET):
         line['projected']['note'] = 'PROJECTED (kernels measured here + xGMI link model), not measured'
     w1 = detail.get('sharded_path_w1') or {}
     if w1:
-        line['sharded_path_w1_ms'] = {k: sig(v.get('ms_per_step'), 5) for k, v in w1.items() if isinstance(v, dict)}
+        # every leg with the columns it ran on: the clients leg runs on a QUARTER of the matrix at one rank (its config says
+        # why), so its time is also given scaled to the headline's column count
+        w1_line = {}
+        for k, v in w1.items():
+            if not isinstance(v, dict):
+                continue
+            cols = (v.get('config') or {}).get('params')
+            w1_line[k] = {'ms': sig(v.get('ms_per_step'), 5), 'params': cols}
+            full = cfg.get('params')
+            if cols and full and cols != full and v.get('ms_per_step'):
+                w1_line[k]['ms_scaled_to_%d_params' % full] = sig(v['ms_per_step'] * full / cols, 5)
+        line['sharded_path_w1_ms'] = w1_line
     if detail.get('other_layout'):
         leg = detail['other_layout']
         line['other_layout'] = ({'layout': leg.get('layout'), 'error': clip(leg['error'], 160)} if leg.get('error')
@@ -1049,7 +1079,23 @@ def main(argv=None):
         if rank == 0:
             emit(line, args.detail_file)
         import threading
-        watchdog = threading.Timer(float(os.environ.get('BYZ_BENCH_SIDE_LEG_SECONDS', '240')), lambda: os._exit(0))
+        def give_up():
+            # the headline is out already; a hang of the side leg must not cost it -- but must not look like a clean finish
+            # either: the detail file gets a marker, stderr a note, and then every rank ends
+            if rank == 0 and args.detail_file:
+                try:
+                    line['other_layout'] = {'side_leg': 'timeout', 'layout': 'clients' if wl.layout == 'columns' else 'columns',
+                                            'seconds': float(os.environ.get('BYZ_BENCH_SIDE_LEG_SECONDS', '240'))}
+                    with open(args.detail_file, 'w') as fh:
+                        json.dump(line, fh, indent=1)
+                except (OSError, TypeError, ValueError):
+                    pass
+            try:
+                os.write(2, b'bench.py: the side leg (the other layout) outlived its budget; ended by the watchdog\n')
+            except OSError:
+                pass
+            os._exit(0)
+        watchdog = threading.Timer(float(os.environ.get('BYZ_BENCH_SIDE_LEG_SECONDS', '240')), give_up)
         watchdog.daemon = True
         watchdog.start()
         rec, _ = side_leg()

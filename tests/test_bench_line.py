@@ -67,7 +67,43 @@ def test_default_run_record_fits_with_every_section():
     star = line['north_star']
     assert star['c5u_target_met'] is False and star['c5s_target_met'] is True     # what round 4 measured
     assert star['c5u']['projected_8'] < 1.0 < star['c5s']['projected_8']
-    assert len(text) < 3600          # headroom below the budget
+    assert len(text) < 3800          # headroom below the budget
+
+
+def bench_peak(roof):
+    """The peak in the unit of the algorithmic work (bytes/s or flop/s): the record scales it to GB/s or TFLOP/s."""
+    return roof['peak'] * (1e9 if roof['unit'] == 'GB/s' else 1e12)
+
+
+def test_the_line_says_what_each_figure_measured():
+    """`others.*.ms` is the wall time of a step while `frac` is computed over the dominant kernel's own time,
+    and the clients leg of `sharded_path_w1` runs on a quarter of the columns.  The line now carries the kernel's time beside
+    the wall time, the fraction over the wall clock, and every sharded leg's column count."""
+    rec = full_record()
+    line = json.loads(bench.compact_line(rec))
+    for name, leg in line['others'].items():
+        src = rec['other_workloads'][name]
+        if not src.get('roofline'):
+            continue
+        assert 'kernel_ms' in leg and 'ms' in leg, name
+        roof = src['roofline']
+        assert abs(leg['kernel_ms'] - roof['avg_launch_ms'] * roof['launches_per_step']) <= 1e-3 * leg['kernel_ms']
+        # `frac` belongs to kernel_ms, not to ms: algorithmic work / kernel time / peak
+        want = roof['algorithmic_work_per_launch'] * roof['launches_per_step'] / (leg['kernel_ms'] * 1e-3)
+        assert abs(want / (leg['frac'] * bench_peak(roof)) - 1.0) < 5e-3, name
+    c3 = line['others']['c3_D1000000']
+    assert c3['kernel_ms'] < c3['ms']         # the case VERDICT r5 named: 1.163 ms of kernel inside 1.254 ms of wall
+    w1 = line['sharded_path_w1_ms']
+    full = rec['config']['params']
+    assert w1['columns']['params'] == full and w1['clients']['params'] == full // 4
+    scaled = w1['clients']['ms_scaled_to_%d_params' % full]
+    assert abs(scaled - 4 * w1['clients']['ms']) <= 1e-3 * scaled
+    assert not any(k.startswith('ms_scaled') for k in w1['columns'])
+    # the Gram's roofline with the deferred slab update (and the operand split) counted in, next to the tile kernel alone
+    roof = line['roofline']
+    if 'gram_reduce' in rec['kernels']:
+        assert roof['frac_with_slab_update'] < roof['frac']
+        assert roof['frac_with_split_and_update'] < roof['frac_with_slab_update']
 
 
 def test_worst_case_record_still_fits_and_keeps_the_contract():

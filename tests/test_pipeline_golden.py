@@ -227,6 +227,23 @@ def test_gpu_resident_attack_every_row_block_count(eng, m):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('m,d', [(300, 4099), (2400, 3000)])
+def test_gpu_resident_attack_redo_path_gives_the_same_bits(eng, m, d, monkeypatch):
+    """A wave of the register-resident kernel that never gets its turn sets the call's redo word and the two-pass kernel queued
+    behind it recomputes every column (round 5 returned BYZ_OK with an invalid vector and reported it later, from
+    another call).  The spin's bound has never been seen to trigger, so the word is forced (BYZ_ATTACK_FORCE_REDO=1): the
+    gated launch must then overwrite all three vectors with the same bits, and leave no status behind."""
+    rng = np.random.default_rng(9400 + m)
+    g = (rng.standard_normal((m, d)) * 2 + 0.5).astype(np.float32)
+    drift, mean, std = eng.drift_attack(g, 1.5)
+    monkeypatch.setenv('BYZ_ATTACK_FORCE_REDO', '1')
+    drift2, mean2, std2 = eng.drift_attack(g, 1.5)
+    eng.check()
+    assert same_bits(mean2, mean) and same_bits(std2, std) and same_bits(drift2, drift)
+    assert same_bits(drift2, faithful.drift_vector(g, 1.5))
+
+
+@pytest.mark.gpu
 def test_gpu_attack_statistics_with_non_finite_rows(eng):
     rng = np.random.default_rng(9200)
     for m in (40, 300, 900):          # the two-pass kernel, the resident one with four waves, with sixteen

@@ -61,40 +61,3 @@ def test_four_wave_composition_reproduces_it_too(proto):
         else:
             v = np.sort(np.abs(rng.standard_normal(n)).astype(np.float32) + np.float32(0.3))
         assert proto.bits_of(proto.literal(v)) == proto.bits_of(proto.seqsum_coop(v))
-
-
-@pytest.fixture(scope='module')
-def proto_pred():
-    """scripts/proto/seqsum_pred.py: the PARALLEL form (round 4): batch units predicted from rigorous enclosures of the running
-    sum, totals per batch in advance, a chain of integer additions.  Its GPU form was built, exact and removed again (3-6% of the
-    loop: profiles/r04r_bulyan_cooperative_rescore.txt); the prototype stays as the statement of the method."""
-    import sys
-    sys.path.insert(0, os.path.join(ROOT, 'scripts', 'proto'))
-    spec = importlib.util.spec_from_file_location('seqsum_pred', os.path.join(ROOT, 'scripts', 'proto', 'seqsum_pred.py'))
-    mod = importlib.util.module_from_spec(spec)
-    spec.loader.exec_module(mod)
-    return mod
-
-
-@pytest.mark.parametrize('name,values', cases(), ids=[c[0] for c in cases()])
-def test_predicted_units_reproduce_the_sequential_fp32_sum(proto, proto_pred, name, values):
-    with np.errstate(over='ignore'):
-        want = proto.literal(values)
-        stats = []
-        got = proto_pred.seqsum_pred(values, stats=stats)
-    assert proto.bits_of(want) == proto.bits_of(got) or (np.isnan(want) and np.isnan(got)), (name, want, got)
-
-
-def test_predicted_units_on_long_prefixes_leave_few_batches_sequential(proto, proto_pred):
-    """A 7600-entry prefix of sorted distances (configs[4]'s rows): 15 batches, the clean ones need no sequential pass --
-    and the sum on / just below a power of two, where the enclosure must NOT promise a unit."""
-    rng = np.random.default_rng(13)
-    for n in (3040, 7600, 12000):
-        d = np.sort(np.abs(rng.standard_normal(n)).astype(np.float32) + np.float32(0.5))
-        stats = []
-        assert proto.bits_of(proto.literal(d)) == proto.bits_of(proto_pred.seqsum_pred(d, stats=stats))
-        assert stats[0][1] <= 2 + int(np.log2(n / 512)) + 1, stats
-    on = np.concatenate([np.full(512, 1.0), np.full(512, 1.0), np.full(1024, 1.0), np.full(2048, 1.0)]).astype(np.float32)
-    below = np.concatenate([np.full(1023, 1.0), [0.99999], np.full(3000, 1e-4)]).astype(np.float32)
-    for v in (on, below):
-        assert proto.bits_of(proto.literal(v)) == proto.bits_of(proto_pred.seqsum_pred(v))
