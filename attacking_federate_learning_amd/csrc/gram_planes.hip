@@ -50,6 +50,7 @@ constexpr int kChunkCols = 8192;        // must match gram.hip's chunk (the fp32
 constexpr int kChunkSteps = kChunkCols / 16;
 constexpr int kFlushSteps = 16;         // 256-column MFMA chains (the 16-bit MFMAs accumulate with truncation)
 constexpr int kStatusLostTicket = 1;
+constexpr int kDefaultSpan = 1;        // chunks a workgroup of the deferred tile kernel walks (BYZ_GRAM_KSPAN; round 6 A/B)
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -400,7 +401,7 @@ __global__ __launch_bounds__(64 * 16 / MB, 1) void gram_planes_kernel(const u32x
                                                                   int slab_live0, int n_blocks32,
                                                                   int32_t* __restrict__ device_status,
                                                                   float* __restrict__ chunk_sums,
-                                                                  float* __restrict__ ragged_sums) {
+                                                                  float* __restrict__ ragged_sums, int kspan) {
     constexpr int kRbBytes = PLANES * kFragBytes;           // one 32-row block, one stage: [plane][1 KiB]
     constexpr int kStage = kRowBlocks * kRbBytes;           // 36,864 (bf16x3) / 24,576 (f16x2)
     constexpr int NW = 16 / MB;                             // waves of the workgroup
@@ -418,7 +419,13 @@ __global__ __launch_bounds__(64 * 16 / MB, 1) void gram_planes_kernel(const u32x
     const int base = n_tiles >> 3, rem = n_tiles & 7;
     const int mine = base + (xcd < rem ? 1 : 0);
     const int first = xcd * base + (xcd < rem ? xcd : rem);
-    const int chunk = mine > 0 ? seq / mine : n_chunks;
+    // (DEFER, round 6) a workgroup owns a tile over a SPAN of `kspan` consecutive chunks: the planes of a row block are
+    // contiguous along K, so the DMA ring runs on across the chunk boundaries -- one launch, one ramp, one drain per span -- and
+    // at every boundary the chunk's level-1 sums leave for `chunk_sums` exactly as a one-chunk workgroup writes them: the Gram
+    // is bitwise the same for every kspan.  `chunk` below is the FIRST chunk of the span.
+    const int n_spans = DEFER ? (n_chunks + kspan - 1) / kspan : n_chunks;
+    const int span = mine > 0 ? seq / mine : n_spans;
+    const int chunk = DEFER ? span * kspan : span;
     int* done = tickets + n_tiles + xcd;
     {
         // rounds: a workgroup starts only when every workgroup of the earlier rounds of its XCD has finished, so that the
@@ -432,12 +439,12 @@ __global__ __launch_bounds__(64 * 16 / MB, 1) void gram_planes_kernel(const u32x
             }
         }
         __syncthreads();
-        if (chunk >= n_chunks) {
+        if (span >= n_spans) {
             if (threadIdx.x == 0) __hip_atomic_fetch_add(done, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             return;
         }
     }
-    const int t_list = first + (seq - chunk * mine);
+    const int t_list = first + (seq - span * mine);
     const int2 tt = tile_order[t_list];
     const int bi = __builtin_amdgcn_readfirstlane(tt.x);   // 256-row block of the A side
     const int tj = __builtin_amdgcn_readfirstlane(tt.y);   // 128-row block of the B side
@@ -475,7 +482,10 @@ __global__ __launch_bounds__(64 * 16 / MB, 1) void gram_planes_kernel(const u32x
 
     const int step0 = chunk * kChunkSteps;
     int n_stages = static_cast<int>(n_steps) - step0;
-    if (n_stages > kChunkSteps) n_stages = kChunkSteps;
+    {
+        const int span_steps = DEFER ? kspan * kChunkSteps : kChunkSteps;
+        if (n_stages > span_steps) n_stages = span_steps;
+    }
 
     // LDS-DMA: piece q = wave + 8 i of the stage (row block q / PLANES, plane q % PLANES): a wave-uniform byte offset from
     // `planes` plus 16 bytes per lane; the LDS image of a stage is piece-linear, and so is a row block's stage in HBM
@@ -553,7 +563,29 @@ __global__ __launch_bounds__(64 * 16 / MB, 1) void gram_planes_kernel(const u32x
                 for (int n = 0; n < 2; ++n)
                     if (((MASK >> (m * 2 + n)) & 1u) != 0) mfma_term(f, t, m, n);   // folds: the loops are unrolled
     };
-    auto flush = [&](int s) __attribute__((always_inline)) {
+    // this wave's level-1 sums of chunk `c` -> chunk_sums (slab `sel` of workgroup tile t_list; element (i, j) where the fp64
+    // slab has it); only the blocks somebody reads
+    auto store_chunk = [&](int c, auto mask_c) __attribute__((always_inline)) {
+        constexpr unsigned MASK = decltype(mask_c)::value;
+        const int sel = (wr * MB) / 4;
+        // The addresses are formed HERE, from values the compiler cannot see through: hoisted out of the K loop they cost 52
+        // registers and 248 bytes of scratch per lane in the hot loop (256 VGPRs against 204).
+        int lane_o = lane, c_o = c;
+        asm volatile("" : "+v"(lane_o));
+        asm volatile("" : "+s"(c_o));
+        float* out = chunk_sums + ((static_cast<int64_t>(c_o) * n_tiles + t_list) * 2 + sel) * (kSlab * kSlab) +
+                     (row_in_slab + 4 * (lane_o >> 5)) * kSlab + wc * 64 + (lane_o & 31);
+#pragma unroll
+        for (int m = 0; m < MB; ++m)
+#pragma unroll
+            for (int n = 0; n < 2; ++n) {
+                if (((MASK >> (m * 2 + n)) & 1u) == 0) continue;
+#pragma unroll
+                for (int e = 0; e < 16; ++e)      // element (i, j): i = row_in_slab + 32 m + (e & 3) + 8 (e >> 2) + 4 (lane >> 5), j = 64 wc + 32 n + (lane & 31)
+                    out[(m * 32 + (e & 3) + 8 * (e >> 2)) * kSlab + n * 32] = acc2[m][n][e];
+            }
+    };
+    auto flush = [&](int s, auto mask_c) __attribute__((always_inline)) {
         if ((s + 1) % kFlushSteps == 0) {
 #pragma unroll
             for (int m = 0; m < MB; ++m)
@@ -564,6 +596,21 @@ __global__ __launch_bounds__(64 * 16 / MB, 1) void gram_planes_kernel(const u32x
                         acc2[m][n][e] += acc[m][n][e];
                         acc[m][n][e] = 0.0f;
                     }
+            if constexpr (DEFER) {
+                // a chunk of the span ends here and another follows (the span's last chunk leaves in the epilogue)
+                if ((s + 1) % kChunkSteps == 0 && s + 1 < n_stages) {
+                    store_chunk(chunk + (s + 1) / kChunkSteps - 1, mask_c);
+#pragma unroll
+                    for (int m = 0; m < MB; ++m)
+#pragma unroll
+                        for (int n = 0; n < 2; ++n)
+#pragma unroll
+                            for (int e = 0; e < 16; ++e) acc2[m][n][e] = 0.0f;
+                    // stores count in vmcnt like the DMA's loads, and the counted waits of the ring assume that whatever is
+                    // outstanding returns in issue order: nothing of either kind stays in flight across the boundary
+                    wait_vmcnt<0>();
+                }
+            }
         }
     };
     // one stage: multiply `cur` (stage s, in registers), read stage s + 1 into `next`, keep the DMA kLead stages ahead
@@ -580,7 +627,7 @@ __global__ __launch_bounds__(64 * 16 / MB, 1) void gram_planes_kernel(const u32x
         else wait_vmcnt<(kLead - 2) * (kPerWave - 1)>();
         if (DBG & 4) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         else asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        if (kLive) flush(s);
+        if (kLive) flush(s, mask_c);
     };
     auto drain = [&](int s, const frags_t& cur, frags_t& next, auto mask_c) __attribute__((always_inline)) {
         constexpr bool kLive = decltype(mask_c)::value != 0;
@@ -593,7 +640,7 @@ __global__ __launch_bounds__(64 * 16 / MB, 1) void gram_planes_kernel(const u32x
         const int ahead = last - (s + 2);
         wait_vmcnt_dyn((ahead > 0 ? ahead : 0) * my_dmas);
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        if (kLive) flush(s);
+        if (kLive) flush(s, mask_c);
     };
 
     for (int a = 0; a < kLead && a < n_stages; ++a) dma(a);
@@ -634,7 +681,8 @@ __global__ __launch_bounds__(64 * 16 / MB, 1) void gram_planes_kernel(const u32x
         if (live_wave) {
             const int sel = (wr * MB) / 4;
             const bool unflushed = (n_stages % kFlushSteps) != 0;
-            float* out = chunk_sums + ((static_cast<int64_t>(chunk) * n_tiles + t_list) * 2 + sel) * (kSlab * kSlab);
+            const int last_chunk = chunk + (n_stages - 1) / kChunkSteps;
+            float* out = chunk_sums + ((static_cast<int64_t>(last_chunk) * n_tiles + t_list) * 2 + sel) * (kSlab * kSlab);
             float* rag = ragged_sums + (static_cast<int64_t>(t_list) * 2 + sel) * (kSlab * kSlab);
 #pragma unroll
             for (int m = 0; m < MB; ++m)
@@ -856,7 +904,7 @@ int launch_gram_planes(byz_ctx* ctx, const float* G, int64_t n_rows, int64_t n_c
     int* tickets = ctx->gram_tickets.as<int>();
     u32x4* planes = ctx->gram_planes.as<u32x4>();
     typedef void (*kernel_t)(const u32x4*, int64_t, const double*, int64_t, double*, int, const int2*, int, int*, int, int,
-                             int, int, int32_t*, float*, float*);
+                             int, int, int32_t*, float*, float*, int);
     // BYZ_GRAM_DEFER=0: round 4's in-kernel slab update (the same-box A/B and the bitwise comparison of the tests)
     bool defer = f16 && env_int("BYZ_GRAM_DEFER", 1) != 0;
     kernel_t kernel = defer ? &gram_planes_kernel<2, 6, 0, 2, true> : f16 ? &gram_planes_kernel<2, 6, 0> : &gram_planes_kernel<3, 4, 0>;
@@ -945,7 +993,17 @@ int launch_gram_planes(byz_ctx* ctx, const float* G, int64_t n_rows, int64_t n_c
         BYZ_HIP(hipMemsetAsync(tickets, 0, static_cast<size_t>(n_tiles + 8) * sizeof(int), stream));
         {
             KernelTimer t(ctx, BYZ_K_GRAM, stream);
-            const int64_t grid = 8 * per_xcd * n_chunks;
+            // chunks per workgroup (DEFER only): BYZ_GRAM_KSPAN as given, else kDefaultSpan -- but never so many that the launch
+            // has fewer than ~8 workgroups per CU (the tail of the last round would cost more than the turnover saves)
+            int64_t kspan = 1;
+            if (defer) {
+                kspan = env_int("BYZ_GRAM_KSPAN", 0);
+                if (kspan < 1) {
+                    kspan = kDefaultSpan;
+                    while (kspan > 1 && 8 * per_xcd * ceil_div(n_chunks, kspan) < static_cast<int64_t>(ctx->num_cus) * 8) kspan /= 2;
+                }
+            }
+            const int64_t grid = 8 * per_xcd * ceil_div(n_chunks, kspan);
             if (grid > 0x7fffffff) {
                 set_error("gram: grid too large");
                 return BYZ_E_UNSUPPORTED;
@@ -953,7 +1011,7 @@ int launch_gram_planes(byz_ctx* ctx, const float* G, int64_t n_rows, int64_t n_c
             kernel<<<static_cast<unsigned>(grid), threads, lds_bytes, stream>>>(
                 planes, n_steps, unscale, rows_pad, slabs, static_cast<int>(n_tiles), ctx->plane_order.as<int2>(),
                 static_cast<int>(n_chunks), tickets, round_size, static_cast<int>(t128), sc > 0 ? 1 : 0,
-                n_blocks32, device_status_word(ctx), chunk_sums, ragged_sums);
+                n_blocks32, device_status_word(ctx), chunk_sums, ragged_sums, static_cast<int>(kspan));
             BYZ_TRY(check_launch("gram_planes_kernel"));
         }
         if (defer) {

@@ -209,3 +209,41 @@ int ref_verify_picks(const float* dist, int n, int64_t users_count, int64_t corr
     free(t.sorted);
     return bad;
 }
+
+/* The margin protocol's second clause: a selection that was made on DIFFERENT numbers (the engine's
+ * distances, fp32 sums) is replayed on these: at every pick t the rows selection[0..t-1] are removed -- the state is the
+ * selection's OWN, not the oracle's -- every live row is scored (defences.py:26-37, `mode` arithmetic), and
+ *   excess[t] = score(selection[t]) / min score - 1      how far from the optimum the selection's pick is (0: it IS an argmin)
+ *   margin[t] = (runner-up - min) / min                  how contested the pick was
+ *   argmin[t] = the row the rule itself picks in that state (visit order 1, 0, 2, ..., strict '<')
+ * A pick is "inside tau" when margin[t] <= tau; the protocol bounds excess[t] for every pick and counts the contested ones.
+ * O(theta n^2), rows in parallel.  Returns theta, or -2 on allocation failure, -3 when the selection repeats a row. */
+int ref_replay_selection(const float* dist, int n, int64_t users_count, int64_t corrupted, int mode, const int32_t* selection,
+                         int theta, double* excess, double* margin, int32_t* argmin) {
+    table_t t;
+    if (build_table(dist, n, &t)) return -2;
+    uint8_t* removed = (uint8_t*)calloc((size_t)n, 1);
+    double* scores = (double*)malloc((size_t)n * sizeof(double));
+    int rc = theta;
+    for (int k = 0; k < theta; ++k) {
+        const int mine = selection[k];
+        if (mine < 0 || mine >= n || removed[mine]) {
+            rc = -3;
+            break;
+        }
+        double m = 0.0;
+        const int idx = pick(&t, removed, n - k, users_count - k, corrupted, mode, scores, &m);
+        double best = INFINITY;
+        for (int u = 0; u < n; ++u)
+            if (!removed[u] && scores[u] < best) best = scores[u];
+        const double denom = fabs(best) > 1e-300 ? fabs(best) : 1e-300;
+        excess[k] = (scores[mine] - best) / denom;
+        margin[k] = m;
+        argmin[k] = idx;
+        removed[mine] = 1;
+    }
+    free(scores);
+    free(removed);
+    free(t.sorted);
+    return rc;
+}

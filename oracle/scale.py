@@ -44,6 +44,7 @@ def _load():
         lib.ref_bulyan_selection.argtypes = [vp, ctypes.c_int, i64, i64, ctypes.c_int, vp, vp]
         lib.ref_set_threads.argtypes = [ctypes.c_int]
         lib.ref_verify_picks.argtypes = [vp, ctypes.c_int, i64, i64, ctypes.c_int, vp, ctypes.c_int, vp, ctypes.c_int, vp, vp]
+        lib.ref_replay_selection.argtypes = [vp, ctypes.c_int, i64, i64, ctypes.c_int, vp, ctypes.c_int, vp, vp, vp]
         try:
             usable = len(os.sched_getaffinity(0))
         except AttributeError:
@@ -108,3 +109,28 @@ def verify_picks(dist, users_count, corrupted_count, selection, picks, mode='fai
                                    ctypes.addressof(first_bad), ctypes.addressof(expected))
     assert bad >= 0
     return bad, first_bad.value, expected.value
+
+
+def replay_selection(dist, users_count, corrupted_count, selection, mode='ideal'):
+    """SURVEY.md 8(d), the margin protocol's second clause.  `selection` was made on other numbers (the engine's distances
+    and fp32 sums); here it is replayed on `dist` in `mode` arithmetic IN ITS OWN STATE: before pick t the rows selection[:t]
+    are gone, every live row is scored (defences.py:26-37) and
+
+        excess[t]  = score(selection[t]) / min score - 1     (0 where the selection's pick is an argmin of these scores)
+        margin[t]  = (runner-up - min) / min                  (how contested pick t is)
+        argmin[t]  = the row the rule picks in that state
+
+    Returns (excess, margin, argmin).  The protocol: excess[t] <= tau for EVERY pick (also the ones after the first contested
+    pick, where the selection and the oracle's own have parted ways), and the number of picks with margin[t] <= tau is
+    reported."""
+    d = _dense(dist)
+    sel = np.ascontiguousarray(selection, dtype=np.int32)
+    theta = len(sel)
+    excess, margin = np.zeros(theta, dtype=np.float64), np.zeros(theta, dtype=np.float64)
+    argmin = np.full(theta, -1, dtype=np.int32)
+    rc = _load().ref_replay_selection(d.ctypes.data, d.shape[0], int(users_count), int(corrupted_count), _MODES[mode],
+                                      sel.ctypes.data, theta, excess.ctypes.data, margin.ctypes.data, argmin.ctypes.data)
+    if rc == -3:
+        raise ValueError('replay_selection: the selection repeats a row or names one outside the matrix')
+    assert rc == theta, rc
+    return excess, margin, argmin

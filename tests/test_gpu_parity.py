@@ -488,6 +488,14 @@ def test_bulyan_vs_fp64_oracle(eng, n, d, f):
     assert sel[:first_noisy] == want_sel[:first_noisy]
     if first_noisy == len(sel):
         assert close(out, ideal.trimmed_mean(g[want_sel], 2 * f))
+    # the protocol's second clause (tests/test_gpu_scale.py::margin_protocol): the engine's selection replayed
+    # in fp64 IN ITS OWN STATE -- every pick, also those after the first contested one, within tau of the optimum; a pick that
+    # is not the fp64 argmin is a contested one; the count of contested picks against a ceiling (measured: 0 .. 4 at these sizes)
+    from oracle import scale
+    excess, margin, argmin = scale.replay_selection(np.ascontiguousarray(dist, dtype=np.float32), n, f, sel, mode='ideal')
+    assert float(excess.max()) <= tau, (float(excess.max()), tau)
+    assert np.all(margin[argmin != np.asarray(sel, dtype=np.int32)] <= tau)
+    assert int((margin <= tau).sum()) <= 12, int((margin <= tau).sum())
     # whatever was picked, the second stage must be the reference's trimmed mean of exactly those rows
     assert close(out, ideal.trimmed_mean(g[sel], 2 * f))
 

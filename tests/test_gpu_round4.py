@@ -139,6 +139,19 @@ def test_gram_with_skipped_blocks_is_bitwise_the_slab_granular_gram(eng, monkeyp
     eng.check()
     assert torch.equal(inline_many, lean) and torch.equal(inline_one, lean)
     assert torch.equal(inline_all_blocks, lean) and torch.equal(deferred_all_blocks, lean)
+    # round 6: a workgroup of the deferred kernel walks a SPAN of consecutive chunks without leaving (BYZ_GRAM_KSPAN; the DMA
+    # ring runs across the chunk boundaries, each chunk's level-1 sums leave at its boundary): bitwise the same for every span --
+    # spans that divide the chunk count and spans that do not, one longer than the matrix, with one super-chunk and several
+    monkeypatch.setenv('BYZ_GRAM_BLOCK_SKIP', '1')
+    for span, plane_mb in ((2, None), (3, None), (64, None), (2, '300'), (5, '300')):
+        monkeypatch.setenv('BYZ_GRAM_KSPAN', str(span))
+        if plane_mb:
+            monkeypatch.setenv('BYZ_GRAM_PLANE_MB', plane_mb)
+        spanned = eng.gram(g).clone()
+        eng.check()
+        monkeypatch.delenv('BYZ_GRAM_PLANE_MB', raising=False)
+        assert torch.equal(spanned, lean), (span, plane_mb, float((spanned - lean).abs().max()))
+    monkeypatch.delenv('BYZ_GRAM_KSPAN')
     # the last rows and the diagonal against fp64
     rows = torch.tensor([0, 1, 31, 32, 63, 64, 127, 128, n - 33, n - 32, n - 2, n - 1], device='cuda')
     want = g[rows].double() @ g.double().T

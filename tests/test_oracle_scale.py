@@ -93,3 +93,59 @@ def test_verify_picks_agrees_with_the_full_selection():
     wrong[30], wrong[31] = wrong[31], wrong[30]
     bad, first, expected = scale.verify_picks(dist, n, f, wrong, np.arange(len(sel)))
     assert bad >= 1 and first == 30 and expected == sel[30]
+
+
+def test_replay_selection_scores_a_selection_in_its_own_state():
+    """SURVEY.md 8(d), the margin protocol's second clause: a selection made on other numbers is replayed pick by pick with
+    ITS OWN picks removed.  Replaying the rule's own selection gives zero excess, the rule's own margins and argmin == pick;
+    a selection that parts ways at one pick is charged exactly the score ratio of that pick, and what follows is judged in
+    the state that pick left behind (not the oracle's)."""
+    n, f = 60, 14
+    dist = point_distances(31, n)
+    want, margins = scale.bulyan_selection(dist, n, f, mode='ideal', with_margins=True)
+    excess, margin, argmin = scale.replay_selection(dist, n, f, want, mode='ideal')
+    assert np.all(excess == 0.0) and argmin.tolist() == want and np.array_equal(margin, margins)
+    # part ways at pick 5: take the runner-up instead of the winner
+    _, _, scores = scale.krum_pick(dist, n, f, mode='ideal', with_scores=True)
+    removed = np.zeros(n, dtype=bool)
+    removed[want[:5]] = True
+    live = np.flatnonzero(~removed)
+    sub = dist[np.ix_(live, live)]
+    # the rule's scores in that state, by the numpy oracle: prefix length (n - 5) - f of the live rows' sorted lists
+    take = (n - 5) - f
+    sc = np.array([np.sort(np.delete(sub[i], i).astype(np.float64))[:take].sum() for i in range(len(live))])
+    order = np.argsort(sc, kind='stable')
+    assert live[order[0]] == want[5]
+    runner_up = int(live[order[1]])
+    mine = want[:5] + [runner_up]
+    # continue with the rule itself from the state the runner-up left behind
+    gone = set(mine)
+    while len(mine) < n - 2 * f:
+        live = np.array([r for r in range(n) if r not in gone])
+        sub = dist[np.ix_(live, live)]
+        take = max(min(n - len(mine) - f, len(live) - 1), 0)
+        sc = np.array([np.sort(np.delete(sub[i], i).astype(np.float64))[:take].sum() for i in range(len(live))])
+        # visit order 1, 0, 2, ... with a strict '<' (defences.py:27-37)
+        visit = sorted(range(len(live)), key=lambda k: (0 if live[k] == 1 else 1 if live[k] == 0 else 2, live[k]))
+        best, best_k = 1e20, -1
+        for k in visit:
+            if sc[k] < best:
+                best, best_k = sc[k], k
+        mine.append(int(live[best_k]))
+        gone.add(int(live[best_k]))
+    excess, margin, argmin = scale.replay_selection(dist, n, f, mine, mode='ideal')
+    want_excess = (np.sort(sc_at_pick5(dist, want, n, f))[1] / np.sort(sc_at_pick5(dist, want, n, f))[0]) - 1.0
+    assert excess[5] == pytest.approx(want_excess, rel=1e-12) and excess[5] > 0.0
+    assert np.all(np.delete(excess, 5) == 0.0)                 # every other pick is the argmin of the state it was made in
+    assert argmin[5] == want[5] and np.array_equal(np.delete(argmin, 5), np.delete(np.array(mine, dtype=np.int32), 5))
+    with pytest.raises(ValueError):
+        scale.replay_selection(dist, n, f, want[:3] + want[:3], mode='ideal')
+
+
+def sc_at_pick5(dist, want, n, f):
+    removed = np.zeros(n, dtype=bool)
+    removed[want[:5]] = True
+    live = np.flatnonzero(~removed)
+    sub = dist[np.ix_(live, live)]
+    take = (n - 5) - f
+    return np.array([np.sort(np.delete(sub[i], i).astype(np.float64))[:take].sum() for i in range(len(live))])
