@@ -64,6 +64,24 @@ __device__ __forceinline__ float from_okey(uint32_t k) {
     return __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k);
 }
 __device__ __forceinline__ bool is_finite(float v) { return (__float_as_uint(v) & 0x7f800000u) != 0x7f800000u; }
+// Sweep B keeps its predicates as LANE MASKS (what v_cmp writes: an SGPR pair) instead of per-lane booleans (round 6).  From
+// `acc += in ? d : 0; top += hit ? 1 : 0` hipcc makes two v_cndmask and a v_addc per value: it folds two steps' increments
+// into one add-with-carry and materialises the other step's as a 0 / 1 register.  With the masks in hand the increment is ONE
+// v_addc (carry-in = the mask) and `hit = le & ~in` is scalar work.
+typedef unsigned long long lane_mask;
+__device__ __forceinline__ lane_mask lanes_lt(float a, float b) { return __builtin_amdgcn_fcmpf(a, b, 4); }   // ordered <
+__device__ __forceinline__ lane_mask lanes_le(float a, float b) { return __builtin_amdgcn_fcmpf(a, b, 5); }   // ordered <=
+__device__ __forceinline__ int add_mask(int count, lane_mask m) {      // count + (lane in m ? 1 : 0)
+    lane_mask carry_out;
+    int out;
+    asm("v_addc_co_u32_e64 %0, %1, 0, %2, %3" : "=v"(out), "=s"(carry_out) : "v"(count), "s"(m));
+    return out;
+}
+__device__ __forceinline__ float keep_mask(float v, lane_mask m) {     // lane in m ? v : +0.0
+    float out;
+    asm("v_cndmask_b32_e64 %0, 0, %1, %2" : "=v"(out) : "v"(v), "s"(m));
+    return out;
+}
 __device__ __forceinline__ int sgpr(int v) { return __builtin_amdgcn_readfirstlane(v); }
 __device__ __forceinline__ float sgpr(float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); }
 
@@ -526,6 +544,7 @@ __global__ __launch_bounds__(64 * W, 4) void window_lean_kernel(const float* __r
                 const f32x2 z = __builtin_elementwise_fma(y - magic2, two2, nsum2);   // 2 b - (bm1 + bm2); NaN / inf: in no class
                 const f32x2 d = v - piv2;
                 const float az0 = __builtin_fabsf(z.x), az1 = __builtin_fabsf(z.y);
+#ifdef BYZ_TM_SWEEP_B_BOOLEANS     // round 5's form, for the same-box A/B (scripts/gpu_r06c.sh builds a second library with it)
                 const bool in0 = __builtin_fabsf(az0 - p0.mid) < p0.half, in1 = __builtin_fabsf(az1 - p1.mid) < p1.half;
                 const bool hit0 = az0 <= p0.outer && !in0, hit1 = az1 <= p1.outer && !in1;
                 acc0 = __fadd_rn(acc0, in0 ? d.x : 0.0f);
@@ -534,6 +553,16 @@ __global__ __launch_bounds__(64 * W, 4) void window_lean_kernel(const float* __r
                 mine1[min(top1, LS) * T] = __float_as_uint(v.y);
                 top0 += hit0 ? 1 : 0;
                 top1 += hit1 ? 1 : 0;
+#else
+                const lane_mask in0 = lanes_lt(__builtin_fabsf(az0 - p0.mid), p0.half), in1 = lanes_lt(__builtin_fabsf(az1 - p1.mid), p1.half);
+                const lane_mask hit0 = lanes_le(az0, p0.outer) & ~in0, hit1 = lanes_le(az1, p1.outer) & ~in1;
+                acc0 = __fadd_rn(acc0, keep_mask(d.x, in0));
+                acc1 = __fadd_rn(acc1, keep_mask(d.y, in1));
+                mine0[min(top0, LS) * T] = __float_as_uint(v.x);
+                mine1[min(top1, LS) * T] = __float_as_uint(v.y);
+                top0 = add_mask(top0, hit0);
+                top1 = add_mask(top1, hit1);
+#endif
             }
             // the pair's counts and sums leave the registers at once (the tile fills half the register file).  One partial
             // per wave and column, in a fixed order: inside the 16-lane row, then across the four rows
