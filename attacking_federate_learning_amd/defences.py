@@ -9,8 +9,8 @@ with a C-contiguous np.float32 matrix and gets a 1-D np.float32 vector back.  De
 (torch CUDA tensors) are accepted too and then nothing crosses PCIe.
 
 Differences a caller can observe, all documented in DESIGN.md:
-  * `krum` returns a copy of the winning row, not a view into `users_grads` (the reference's view is
-    consumed immediately by server.py:89);
+  * `krum` on a host numpy matrix returns a VIEW of the winning row, as the reference does (defences.py:42); on a
+    device-resident matrix it returns a copy made on the device, so that the index need not cross to the host;
   * `_krum_create_distances` returns a `Distances` handle (GPU-resident N x N matrix) instead of a dict
     of dicts; `krum(..., distances=handle)` accepts it, `handle.to_dict()` rebuilds the reference's form.
 """

@@ -417,10 +417,14 @@ class Engine:
             return self._row(g, idx)
         m = self._device_matrix(g)
         if m is None:
+            out, aux = self.defend_host('Krum', g, users_count, corrupted_count, check_assert=False, want_aux=True)
             if return_index:
-                _, aux = self.defend_host('Krum', g, users_count, corrupted_count, check_assert=False, want_aux=True)
                 return int(aux[0])
-            return self.defend_host('Krum', g, users_count, corrupted_count, check_assert=False)
+            if isinstance(g, np.ndarray) and g.ndim == 2:
+                # the reference returns users_grads[index] -- a VIEW of the caller's matrix (defences.py:42), -1 = numpy's last
+                # row when no score beat 1e20 -- and since round 6 so does the host path (missing 6)
+                return g[int(aux[0])]
+            return out
         idx = ctypes.c_int32(-2)
         out, ptr = (None, None) if return_index else self._out_like(m, m.cols)
         # the winning row is copied on the device; the index crosses to the host (one sync) only when asked for

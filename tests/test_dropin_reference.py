@@ -41,7 +41,7 @@ class OracleBackedEngine:
 
     def krum(self, g, users_count, corrupted_count, distances=None, return_index=False):
         out = faithful.krum(np.asarray(g), users_count, corrupted_count, distances=distances, return_index=return_index)
-        return out if return_index else np.array(out, copy=True)     # the engine hands back a copy, not a view
+        return out        # a view of the caller's matrix, like the reference (and, since round 6, like the engine's host path)
 
     def trimmed_mean(self, g, users_count=None, corrupted_count=0):
         return faithful.trimmed_mean(np.asarray(g), users_count, corrupted_count)

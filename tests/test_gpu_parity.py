@@ -144,6 +144,23 @@ def test_assertions_like_the_reference(defences):
     assert set(defences.defend) == {'NoDefense', 'Krum', 'TrimmedMean', 'Bulyan'}
 
 
+def test_krum_on_a_host_matrix_returns_a_view_like_the_reference(defences):
+    """defences.py:42 returns `users_grads[minimal_error_index]`: a VIEW of the caller's matrix.  The host
+    path does the same since round 6; with no score below 1e20 (all distances NaN) the index stays -1 = numpy's last row."""
+    g = gaussian(2, 12, 300)
+    row = defences.krum(g, 12, 2)
+    idx = defences.krum(g, 12, 2, return_index=True)
+    assert row.base is g and np.shares_memory(row, g) and np.array_equal(row, g[idx])
+    assert idx == faithful.krum(g, 12, 2, return_index=True)
+    g[idx, 0] = 123.0
+    assert row[0] == 123.0                       # it IS the caller's row
+    poisoned = g.copy()
+    poisoned[:, 5] = np.nan
+    last = defences.krum(poisoned, 12, 2)
+    assert defences.krum(poisoned, 12, 2, return_index=True) == -1
+    assert np.shares_memory(last, poisoned) and np.array_equal(last, poisoned[-1], equal_nan=True)
+
+
 # ---- seeded random inputs against the oracle --------------------------------------------------------
 @pytest.mark.parametrize('n,d', [(2, 1), (3, 7), (10, 79510), (100, 21840), (100, 79510), (129, 4097),
                                  (300, 20000), (1000, 3001)])
