@@ -91,12 +91,10 @@ __device__ __forceinline__ void split_f16x2(const f32x4& lo4, const f32x4& hi4, 
     mp = __builtin_bit_cast(u32x4, m);
 }
 
-template <bool NT = false>
 __device__ __forceinline__ f32x4 load4_tail(const float* __restrict__ src, int64_t k, int64_t n_cols) {
     f32x4 v = {0.0f, 0.0f, 0.0f, 0.0f};
     if (k + 3 < n_cols) {
-        if constexpr (NT) v = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(src + k));   // G is read once per round
-        else v = *reinterpret_cast<const f32x4*>(src + k);
+        v = *reinterpret_cast<const f32x4*>(src + k);
     } else {
         if (k + 0 < n_cols) v.x = src[k + 0];
         if (k + 1 < n_cols) v.y = src[k + 1];
@@ -250,7 +248,6 @@ __global__ __launch_bounds__(256) void plane_split_f16_kernel(const float* __res
 // Gram, and twin rows in row blocks of which only one was redone do not give bitwise equal Gram entries -- which is why
 // rows proven identical get their zero distance from the proof, gram.hip distance_kernel, not from cancellation).
 constexpr int kSampleGroups = 16;
-template <bool NT>
 __global__ __launch_bounds__(256) void plane_split_f16_stream_kernel(const float* __restrict__ G, int64_t n_rows, int64_t n_cols,
                                                                      int64_t ld, const int32_t* __restrict__ row_index, int64_t k0,
                                                                      int64_t n_steps, u32x4* __restrict__ planes,
@@ -298,7 +295,7 @@ __global__ __launch_bounds__(256) void plane_split_f16_stream_kernel(const float
     bool bad = false;
     f32x4 cur[4], nxt[4];
 #pragma unroll
-    for (int p = 0; p < 4; ++p) cur[p] = load4_tail<NT>(src, k0 + step_base * 16 + 4 * c + 32 * p, n_cols);
+    for (int p = 0; p < 4; ++p) cur[p] = load4_tail(src, k0 + step_base * 16 + 4 * c + 32 * p, n_cols);
     __syncthreads();   // row_scale
     for (int sub = 0; sub < kChunkCols / kSplitCols; ++sub) {
         const int64_t step0 = step_base + sub * (kSplitCols / 16);
@@ -306,7 +303,7 @@ __global__ __launch_bounds__(256) void plane_split_f16_stream_kernel(const float
         const bool more = sub + 1 < kChunkCols / kSplitCols && step0 + kSplitCols / 16 < n_steps;
         if (more) {
 #pragma unroll
-            for (int p = 0; p < 4; ++p) nxt[p] = load4_tail<NT>(src, k0 + (step0 + kSplitCols / 16) * 16 + 4 * c + 32 * p, n_cols);
+            for (int p = 0; p < 4; ++p) nxt[p] = load4_tail(src, k0 + (step0 + kSplitCols / 16) * 16 + 4 * c + 32 * p, n_cols);
         }
         float (*t)[kSplitCols + 4] = tile[sub & 1];
 #pragma unroll
@@ -978,13 +975,9 @@ int launch_gram_planes(byz_ctx* ctx, const float* G, int64_t n_rows, int64_t n_c
                     BYZ_TRY(ctx->split_redo.ensure(static_cast<size_t>(1 + 2 * pairs) * sizeof(int32_t)));
                     int32_t* redo = ctx->split_redo.as<int32_t>();
                     BYZ_HIP(hipMemsetAsync(redo, 0, sizeof(int32_t), stream));
-                    // BYZ_GRAM_SPLIT_NT=1: the stream's loads of G non-temporal (round 6 A/B)
-                    if (env_int("BYZ_GRAM_SPLIT_NT", 0) != 0)
-                        plane_split_f16_stream_kernel<true><<<grid, 256, 0, stream>>>(G, n_rows, n_cols, ld, row_index, k0, n_steps,
-                                                                                      planes, unscale, rows_pad, redo);
-                    else
-                        plane_split_f16_stream_kernel<false><<<grid, 256, 0, stream>>>(G, n_rows, n_cols, ld, row_index, k0, n_steps,
-                                                                                       planes, unscale, rows_pad, redo);
+                    // (non-temporal loads of G here: measured in round 6, 6.38 ms per launch either way -- EXPERIMENTS.md G6)
+                    plane_split_f16_stream_kernel<<<grid, 256, 0, stream>>>(G, n_rows, n_cols, ld, row_index, k0, n_steps, planes,
+                                                                            unscale, rows_pad, redo);
                     BYZ_TRY(check_launch("plane_split_f16_stream_kernel"));
                     // (sized for a few thousand listed blocks; the surplus workgroups leave at once, and a longer list --
                     // pathological data -- is walked in a grid-stride loop: no host read-back of the count.)

@@ -685,9 +685,14 @@ __device__ unsigned long long g_rescore_clock[14];
 
 // One wave; wave-uniform result; `ok` = false when the row holds a negative value (the passes assume distances: the caller
 // then takes the literal chain).  `head`: 512 floats of LDS for the literal chain over the first entries.
+// `front` (LDS, one word per row of the workgroup, zero at the start of the loop): the number of leading 512-entry batches of
+// this row that hold nothing but marks.  The winners of the picks so far are every central row's NEAREST neighbours, so the
+// front of a contender's table fills with marks as the loop goes (up to ten batches at N = 10,000) -- and a mark never
+// becomes live again, so a batch found empty once is skipped, unfetched, by every later re-score of the row (round 6).
 template <bool CLOCKS>
 __device__ __forceinline__ float reference_score_marked(const float* sorted_val, int n, int u, int take, int lane,
-                                                        float* __restrict__ head, int head_chunks, bool& ok) {
+                                                        float* __restrict__ head, int head_chunks, bool& ok,
+                                                        uint16_t* __restrict__ front) {
     constexpr bool clocks = CLOCKS;   // (development: a compile-time switch -- what is compiled into this loop costs even when it never runs)
     typedef uint32_t u32x4u __attribute__((ext_vector_type(4), aligned(4)));
     typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -707,6 +712,9 @@ __device__ __forceinline__ float reference_score_marked(const float* sorted_val,
     float s = 0.0f;
     int got = 0, literal_left = head_chunks;
     bool negative = false;
+    const int first_batch = front != nullptr ? __builtin_amdgcn_readfirstlane(static_cast<int>(*front)) : 0;   // (uniform)
+    int empty_in_front = first_batch;   // batches known to hold only marks once this re-score is done
+    bool in_front = true;
     // returns true behind the last batch of the prefix
     auto add = [&](const Batch& b, int r0) __attribute__((always_inline)) -> bool {
         uint32_t xb[8];
@@ -726,8 +734,10 @@ __device__ __forceinline__ float reference_score_marked(const float* sorted_val,
             // nothing live in these 512 entries: the winners of the picks so far are every row's NEAREST neighbours, so late in the
             // loop the front of the table is one run of marks -- up to ten such batches at N = 10,000 -- and there is nothing to add
             ++n_batches;
+            if (in_front) ++empty_in_front;
             return r0 + 512 >= n;
         }
+        in_front = false;
         if (got + total > take) {   // uniform: the prefix ends inside this batch
             int room = take - got - static_cast<int>(incl - cnt);   // live entries of this lane that still belong to it
 #pragma unroll
@@ -793,10 +803,11 @@ __device__ __forceinline__ float reference_score_marked(const float* sorted_val,
         return got >= take || r0 + 512 >= n;
     };
     Batch b0, b1, b2;
-    fetch(b0, 0);
-    fetch(b1, 512);
-    fetch(b2, 1024);
-    for (int r0 = 0;; r0 += 3 * 512) {
+    const int r_first = 512 * first_batch;
+    fetch(b0, r_first);
+    fetch(b1, r_first + 512);
+    fetch(b2, r_first + 1024);
+    for (int r0 = r_first;; r0 += 3 * 512) {
         if (add(b0, r0)) break;
         fetch(b0, r0 + 3 * 512);
         if (add(b1, r0 + 512)) break;
@@ -805,6 +816,7 @@ __device__ __forceinline__ float reference_score_marked(const float* sorted_val,
         fetch(b2, r0 + 5 * 512);
     }
     ok = __ballot(negative) == 0ull;
+    if (front != nullptr && lane == 0) *front = static_cast<uint16_t>(empty_in_front);
     if (clocks && lane == 0) {
         atomicAdd(&g_rescore_clock[0], 1ull);
         atomicAdd(&g_rescore_clock[1], n_batches);
@@ -829,7 +841,7 @@ __global__ __launch_bounds__(kGridThreads) void bulyan_grid_kernel(
     const uint16_t* __restrict__ sorted_idx, const uint16_t* __restrict__ rank_t, float* sorted_val,
     const double* __restrict__ row_total, const double* __restrict__ row_top, const int32_t* __restrict__ cls,
     unsigned long long* __restrict__ xchg, float band_scale, int32_t* __restrict__ selection,
-    int32_t* __restrict__ status, int32_t* __restrict__ rescored, int rescore_mode, int head_chunks) {
+    int32_t* __restrict__ status, int32_t* __restrict__ rescored, int rescore_mode, int head_chunks, int skip_front) {
     __shared__ __attribute__((aligned(16))) float rescore_stage[kGridThreads / 64][512];
     __shared__ Candidate slots[kGridThreads / 64];
     __shared__ double second_slots[kGridThreads / 64];
@@ -838,10 +850,12 @@ __global__ __launch_bounds__(kGridThreads) void bulyan_grid_kernel(
     __shared__ unsigned long long class_leader[256];
     __shared__ int leaders[kGridThreads];
     __shared__ int n_leaders;
+    __shared__ uint16_t front_batches[kGridThreads];   // per local row: leading batches of its table that hold only marks
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n_wgs = gridDim.x, wg = blockIdx.x;
     const int u = wg * kGridThreads + tid;
     for (int i = tid; i < kMaxSelectRows / 32; i += kGridThreads) removed[i] = 0u;
+    front_batches[tid] = 0;
 
     bool alive = u < n;
     double tot = alive ? row_total[u] : 0.0;
@@ -976,7 +990,8 @@ __global__ __launch_bounds__(kGridThreads) void bulyan_grid_kernel(
                 const int row = __builtin_amdgcn_readfirstlane(wg * kGridThreads + leaders[k]);
                 float s32 = 0.0f;
                 bool done = false;
-                if (marked) s32 = reference_score_marked<DEV>(sorted_val, n, row, take, lane, rescore_stage[wave], head_chunks, done);
+                if (marked) s32 = reference_score_marked<DEV>(sorted_val, n, row, take, lane, rescore_stage[wave], head_chunks, done,
+                                                              skip_front != 0 ? &front_batches[leaders[k]] : nullptr);
                 if (!done) s32 = reference_score_plain(sorted_val, sorted_idx, removed, n, row, take, lane, rescore_stage[wave]);
                 if (s32 < kKrumInit) {
                     Candidate o{static_cast<double>(s32), visit_position(row), row};
@@ -1133,6 +1148,9 @@ int launch_bulyan_loop(byz_ctx* ctx, const float* dist, int64_t n, int64_t theta
     // 64-entry chunks of a re-score that go through the literal chain before the passes take over (measured, N = 4000 / 10,000
     // scaled / 10,000 attack: 1 chunk 32.7 / 163 / 95.7 ms, 4 chunks 30.9 / 158 / 95.8, 8 chunks 30.4 / 157 / 94.1)
     const int head_chunks = 8;
+    // BYZ_BULYAN_FRONT=0: every re-score starts at the row's first entry (round 5's behaviour: the same-box A/B)
+    int skip_front = 1;
+    if (const char* e = std::getenv("BYZ_BULYAN_FRONT")) skip_front = std::atoi(e) != 0 ? 1 : 0;
     const char* clocks_env = std::getenv("BYZ_BULYAN_CLOCKS");
     const bool clocks = rescore_mode != 0 && clocks_env != nullptr && std::atoi(clocks_env) != 0;
     if (clocks) {
@@ -1152,7 +1170,8 @@ int launch_bulyan_loop(byz_ctx* ctx, const float* dist, int64_t n, int64_t theta
     kernel<<<n_wgs, kGridThreads, 0, stream>>>(
         dist, (int)n, (int)theta, (int)drop_count, (int)users_count, (int)corrupted, ctx->sorted_idx.as<uint16_t>(),
         ctx->rank_t.as<uint16_t>(), ctx->sorted_val.as<float>(), ctx->row_total.as<double>(), ctx->row_top.as<double>(), cls,
-        ctx->xchg.as<unsigned long long>(), band_scale, selection_dev, status_dev, status_dev + 1, rescore_mode, head_chunks);
+        ctx->xchg.as<unsigned long long>(), band_scale, selection_dev, status_dev, status_dev + 1, rescore_mode, head_chunks,
+        skip_front);
     BYZ_TRY(check_launch("bulyan_grid_kernel"));
     if (clocks) {
         unsigned long long c[14];

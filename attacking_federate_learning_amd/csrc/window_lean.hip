@@ -544,16 +544,6 @@ __global__ __launch_bounds__(64 * W, 4) void window_lean_kernel(const float* __r
                 const f32x2 z = __builtin_elementwise_fma(y - magic2, two2, nsum2);   // 2 b - (bm1 + bm2); NaN / inf: in no class
                 const f32x2 d = v - piv2;
                 const float az0 = __builtin_fabsf(z.x), az1 = __builtin_fabsf(z.y);
-#ifdef BYZ_TM_SWEEP_B_BOOLEANS     // round 5's form, for the same-box A/B (scripts/gpu_r06c.sh builds a second library with it)
-                const bool in0 = __builtin_fabsf(az0 - p0.mid) < p0.half, in1 = __builtin_fabsf(az1 - p1.mid) < p1.half;
-                const bool hit0 = az0 <= p0.outer && !in0, hit1 = az1 <= p1.outer && !in1;
-                acc0 = __fadd_rn(acc0, in0 ? d.x : 0.0f);
-                acc1 = __fadd_rn(acc1, in1 ? d.y : 0.0f);
-                mine0[min(top0, LS) * T] = __float_as_uint(v.x);
-                mine1[min(top1, LS) * T] = __float_as_uint(v.y);
-                top0 += hit0 ? 1 : 0;
-                top1 += hit1 ? 1 : 0;
-#else
                 const lane_mask in0 = lanes_lt(__builtin_fabsf(az0 - p0.mid), p0.half), in1 = lanes_lt(__builtin_fabsf(az1 - p1.mid), p1.half);
                 const lane_mask hit0 = lanes_le(az0, p0.outer) & ~in0, hit1 = lanes_le(az1, p1.outer) & ~in1;
                 acc0 = __fadd_rn(acc0, keep_mask(d.x, in0));
@@ -562,7 +552,6 @@ __global__ __launch_bounds__(64 * W, 4) void window_lean_kernel(const float* __r
                 mine1[min(top1, LS) * T] = __float_as_uint(v.y);
                 top0 = add_mask(top0, hit0);
                 top1 = add_mask(top1, hit1);
-#endif
             }
             // the pair's counts and sums leave the registers at once (the tile fills half the register file).  One partial
             // per wave and column, in a fixed order: inside the 16-lane row, then across the four rows

@@ -1,10 +1,10 @@
 #!/bin/bash
-# One GPU visit of round 5: the whole GPU suite, smoke, the contract bench exactly as the driver runs it (wall-clocked; the
+# One GPU visit of round 6: the whole GPU suite, smoke, the contract bench exactly as the driver runs it (wall-clocked; the
 # stdout line's size checked), the rocprofv3 kernel stats of the same workload, the HBM-traffic PMC passes (FETCH_SIZE and
 # WRITE_SIZE in separate runs, kernel-trace only) and the sanitized torch-free subset.
-# Usage (from the repo root on the GPU box): bash scripts/gpu_round5.sh <tag> [skip-tests]
+# Usage (from the repo root on the GPU box): bash scripts/gpu_round6.sh <tag> [skip-tests]
 set -u
-TAG=${1:-r05}
+TAG=${1:-r06}
 OUT=$GRAFT_REPO_ROOT/gpurun_out/$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
@@ -68,5 +68,5 @@ json.dump(res, open(out + '/pmc_traffic_raw.json', 'w'), indent=1)
 PY
 find $OUT -name '*counter_collection.csv' -size +1M -delete
 find $OUT -name '*kernel_trace.csv' -delete
-echo "== sanitized run (host side under ASan + UBSan), torch-free subset"
-timeout 300 bash scripts/run_sanitized.sh python -m pytest tests/test_gpu_parity.py -m gpu -q -k "not chunked and not from_torch and not batched_client and not device_server and not torch_device and not config3 and not config2" 2>&1 | tail -15 > $OUT/sanitized.txt; tail -5 $OUT/sanitized.txt
+echo "== sanitized run (host side under ASan + UBSan), torch-free subset; the sanitized library is built HERE (round 6: its 38 MB no longer travel with the tree)"
+timeout 900 bash scripts/run_sanitized.sh python -m pytest tests/test_gpu_parity.py -m gpu -q -k "not chunked and not from_torch and not batched_client and not device_server and not torch_device and not config3 and not config2" 2>&1 | tail -15 > $OUT/sanitized.txt; tail -5 $OUT/sanitized.txt

@@ -1,4 +1,4 @@
-"""profiles/hbm_traffic.json from the raw PMC sums of one GPU visit (scripts/gpu_round5.sh writes pmc_traffic_raw.json).
+"""profiles/hbm_traffic.json from the raw PMC sums of one GPU visit (scripts/gpu_round6.sh writes pmc_traffic_raw.json).
 
     python scripts/update_traffic.py gpurun_out/<tag>/pmc_traffic_raw.json <tag>
 
@@ -58,7 +58,7 @@ def main():
                'hbm_bytes_per_launch': (scale * fetch + write) * 1024.0, 'launches_sampled': launches,
                'launches_per_step': per_step,
                'method': 'rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes of the bench command '
-                         '(scripts/gpu_round5.sh); KB -> bytes x 1024; fetch_scale %.1f: %s.  Fabric side of L2: '
+                         '(scripts/gpu_round6.sh); KB -> bytes x 1024; fetch_scale %.1f: %s.  Fabric side of L2: '
                          'Infinity-Cache hits are included' % (scale, note)}
         rec.update(extra)
         table[key] = rec
