@@ -999,6 +999,7 @@ int launch_gram_planes(byz_ctx* ctx, const float* G, int64_t n_rows, int64_t n_c
             int64_t kspan = 1;
             if (defer) {
                 kspan = env_int("BYZ_GRAM_KSPAN", 0);
+                if (kspan > n_chunks) kspan = n_chunks;   // (a span longer than the launch is the launch; keeps span x steps inside an int)
                 if (kspan < 1) {
                     kspan = kDefaultSpan;
                     while (kspan > 1 && 8 * per_xcd * ceil_div(n_chunks, kspan) < static_cast<int64_t>(ctx->num_cus) * 8) kspan /= 2;
