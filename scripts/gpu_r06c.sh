@@ -1,6 +1,8 @@
 #!/bin/bash
 # Round 6, visit c: same-box A/B of the trimmed mean's sweep B -- predicates as lane masks (libbyzagg.so) against round 5's
 # booleans (libbyzagg_tm_r05.so: the same sources with -DBYZ_TM_SWEEP_B_BOOLEANS) -- two processes alternated on one box,
+# (libbyzagg_tm_r05.so = window_lean.hip of commit a36073c compiled with -DBYZ_TM_SWEEP_B_BOOLEANS and linked with the other objects; the macro
+# left the source again once this A/B was recorded: EXPERIMENTS.md T3)
 # then the trimmed-mean GPU tests on the new library.
 set -u
 export TMPDIR=/tmp
