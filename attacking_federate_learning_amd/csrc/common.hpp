@@ -8,6 +8,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <string>
+#include <unordered_map>
 #include <vector>
 
 #include "../../include/byzagg.h"
@@ -137,6 +138,9 @@ struct byz_ctx {
     byz::Buffer selection;       // theta int32
     byz::Buffer small;           // misc device scalars (winner index, status words)
     bool small_configured = false;   // krum_small.hip: dynamic-LDS attributes set for this context's device
+    // kernels whose hipFuncAttributeMaxDynamicSharedMemorySize has been raised for this context's device, and to what: the
+    // attribute belongs to the (function, device) pair and setting it is a runtime call per launch otherwise (round 6)
+    std::unordered_map<const void*, int> dynamic_lds;
     byz::Buffer assemble_table;  // byz_assemble_rows_dev: segment starts + every client's tensor pointers
     std::vector<int64_t> assemble_host;   // its host image: owned by the context, because an async copy out of pageable memory
     hipEvent_t assemble_copied = nullptr; // may still be reading it when the call returns; recorded behind that copy
@@ -152,6 +156,15 @@ struct byz_ctx {
 namespace byz {
 
 inline hipStream_t as_stream(void* s) { return static_cast<hipStream_t>(s); }
+
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per (kernel, context) and size, not once per launch
+inline hipError_t allow_dynamic_lds(byz_ctx* ctx, const void* kernel, int bytes) {
+    auto it = ctx->dynamic_lds.find(kernel);
+    if (it != ctx->dynamic_lds.end() && it->second >= bytes) return hipSuccess;
+    const hipError_t e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e == hipSuccess) ctx->dynamic_lds[kernel] = bytes;
+    return e;
+}
 
 // ctx->small (256 bytes, allocated and zeroed with the context) holds the device-side scalars:
 //   [0] Krum winner   [8] Bulyan loop status   [9] rows the Bulyan loop re-scored

@@ -952,8 +952,7 @@ int launch_gram_planes(byz_ctx* ctx, const float* G, int64_t n_rows, int64_t n_c
         ragged_sums = chunk_sums + (per_chunk / sizeof(float)) * static_cast<size_t>(chunks_per_sc);
     }
     const size_t lds_bytes = static_cast<size_t>(nbuf) * kRowBlocks * n_planes * kFragBytes;
-    BYZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                static_cast<int>(lds_bytes)));
+    BYZ_HIP(allow_dynamic_lds(ctx, reinterpret_cast<const void*>(kernel), static_cast<int>(lds_bytes)));
     const int round_size = env_int("BYZ_GRAM_ROUND", ctx->num_cus / 8);   // one workgroup per CU
     const int n_blocks32 = env_int("BYZ_GRAM_BLOCK_SKIP", 1) != 0 ? static_cast<int>(ceil_div(n_rows, 32)) : -1;
     const int64_t per_xcd = ceil_div(n_tiles, 8);

@@ -1103,15 +1103,13 @@ int launch_row_sort(byz_ctx* ctx, const float* dist, int64_t n, int64_t prefix_l
     const size_t lds = static_cast<size_t>(n_pad) * 8 + static_cast<size_t>(threads) * 8;
     KernelTimer t(ctx, BYZ_K_ROW_SORT, stream);
     if (want_tables) {
-        BYZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&row_sort_kernel<true>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
+        BYZ_HIP(allow_dynamic_lds(ctx, reinterpret_cast<const void*>(&row_sort_kernel<true>), static_cast<int>(lds)));
         row_sort_kernel<true><<<static_cast<unsigned>(n), threads, lds, stream>>>(
             dist, (int)n, (int)n_pad, (int)prefix_len, (int)drop_count, ctx->scores.as<float>(),
             ctx->sorted_idx.as<uint16_t>(), ctx->rank_t.as<uint16_t>(), ctx->row_total.as<double>(),
             ctx->row_top.as<double>(), ctx->sorted_val.as<float>());
     } else {
-        BYZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&row_sort_kernel<false>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
+        BYZ_HIP(allow_dynamic_lds(ctx, reinterpret_cast<const void*>(&row_sort_kernel<false>), static_cast<int>(lds)));
         row_sort_kernel<false><<<static_cast<unsigned>(n), threads, lds, stream>>>(
             dist, (int)n, (int)n_pad, (int)prefix_len, (int)drop_count, ctx->scores.as<float>(), nullptr,
             nullptr, nullptr, nullptr, nullptr);

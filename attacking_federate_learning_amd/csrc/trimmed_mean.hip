@@ -270,13 +270,11 @@ int launch_trimmed_mean_sorted(byz_ctx* ctx, const float* G, int64_t n_rows, int
     const int64_t grid = n_quads < static_cast<int64_t>(ctx->num_cus) * 2 ? n_quads : static_cast<int64_t>(ctx->num_cus) * 2;
     const size_t lds = static_cast<size_t>(n_pad) * vec * sizeof(float);
     if (vec == 4) {
-        BYZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&trimmed_mean_lds_kernel<4>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
+        BYZ_HIP(allow_dynamic_lds(ctx, reinterpret_cast<const void*>(&trimmed_mean_lds_kernel<4>), static_cast<int>(lds)));
         trimmed_mean_lds_kernel<4><<<static_cast<unsigned>(grid), 1024, lds, stream>>>(G, (int)n_rows, (int)n_pad, n_cols, ld,
                                                                                        row_index, (int)keep, out);
     } else {
-        BYZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&trimmed_mean_lds_kernel<2>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
+        BYZ_HIP(allow_dynamic_lds(ctx, reinterpret_cast<const void*>(&trimmed_mean_lds_kernel<2>), static_cast<int>(lds)));
         trimmed_mean_lds_kernel<2><<<static_cast<unsigned>(grid), 1024, lds, stream>>>(G, (int)n_rows, (int)n_pad, n_cols, ld,
                                                                                        row_index, (int)keep, out);
     }

@@ -714,7 +714,7 @@ __global__ __launch_bounds__(64 * W, 4) void window_lean_kernel(const float* __r
 }
 
 template <int W, int RPW, int B, int SR, int LS>
-int launch_lean_shape(const float* G, int64_t n_rows, int64_t n_cols, int64_t ld, const int32_t* row_index, int64_t keep,
+int launch_lean_shape(byz_ctx* ctx, const float* G, int64_t n_rows, int64_t n_cols, int64_t ld, const int32_t* row_index, int64_t keep,
                       float* out, int32_t* redo, hipStream_t stream) {
     const int64_t n_tiles = ceil_div(n_cols, static_cast<int64_t>(kTileCols));
     constexpr int kHist = 8 * (B + 4), kStack = 4 * (LS + 1) * 64 * W;
@@ -735,8 +735,8 @@ int launch_lean_shape(const float* G, int64_t n_rows, int64_t n_cols, int64_t ld
     const bool pipe = pipe_env != nullptr ? std::atoi(pipe_env) != 0 : W >= 8;
 #define BYZ_LEAN(E, P)                                                                                              \
     do {                                                                                                            \
-        BYZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&window_lean_kernel<W, RPW, B, SR, LS, E, P>),     \
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));            \
+        BYZ_HIP(allow_dynamic_lds(ctx, reinterpret_cast<const void*>(&window_lean_kernel<W, RPW, B, SR, LS, E, P>),  \
+                                  static_cast<int>(lds)));                                                          \
         window_lean_kernel<W, RPW, B, SR, LS, E, P><<<static_cast<unsigned>(n_tiles), 64 * W, lds, stream>>>(        \
             G, static_cast<int>(n_rows), n_cols, ld, row_index, static_cast<int>(keep), out, redo, by_xcd, timing); \
     } while (0)
@@ -780,12 +780,11 @@ int launch_lean_shape(const float* G, int64_t n_rows, int64_t n_cols, int64_t ld
 // Returns BYZ_E_UNSUPPORTED for a height it has no instantiation for (the caller keeps its other kernels).
 int launch_window_lean(byz_ctx* ctx, const float* G, int64_t n_rows, int64_t n_cols, int64_t ld, const int32_t* row_index,
                        int64_t keep, float* out, int32_t* redo, hipStream_t stream) {
-    (void)ctx;
     if (ld >= (int64_t{1} << 30)) return BYZ_E_UNSUPPORTED;   // the kernel forms row offsets as 32 x 32 -> 64-bit products
     if (n_rows < 65 || keep < 1) return BYZ_E_UNSUPPORTED;
     const int64_t blocks = ceil_div(n_rows, 16);
 #define BYZ_SHAPE(W, RPW, B, SR, LS) \
-    if (blocks <= (W) * (RPW)) return launch_lean_shape<W, RPW, B, SR, LS>(G, n_rows, n_cols, ld, row_index, keep, out, redo, stream)
+    if (blocks <= (W) * (RPW)) return launch_lean_shape<W, RPW, B, SR, LS>(ctx, G, n_rows, n_cols, ld, row_index, keep, out, redo, stream)
     // (Twice the waves per tile with half the rows per lane -- (8, 8) for 1000 rows: 76 registers, three workgroups per CU;
     // (16, 9) for 2080 rows: 64 registers with spills -- measured slower: 0.445 vs 0.420 ms and 1.67 vs 0.95 ms per 2^18
     // columns.  Not kept.)

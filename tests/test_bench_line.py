@@ -106,6 +106,15 @@ def test_the_line_says_what_each_figure_measured():
         assert roof['frac_with_split_and_update'] < roof['frac_with_slab_update']
 
 
+def test_side_workloads_are_timed_over_a_quarter_second_not_ten_steps():
+    """Round 6 (profiles/r06j_short_run_artifact.txt): ten 1 ms rounds after idle measure the chip on its way up, not the round."""
+    assert bench.side_leg_steps(1.2e-3, 10) == (209, 20)          # configs[2]'s trimmed mean
+    steps, warm = bench.side_leg_steps(30e-6, 10)                   # configs[1]'s Krum: capped
+    assert steps == 5000 and warm == 500
+    assert bench.side_leg_steps(0.6, 10) == (10, 3)                 # a long round keeps --extras-steps
+    assert bench.side_leg_steps(0.0, 0)[0] >= 1
+
+
 def test_worst_case_record_still_fits_and_keeps_the_contract():
     text = bench.compact_line(inflate(full_record()))
     line = check_line(text)
