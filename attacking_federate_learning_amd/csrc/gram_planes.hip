@@ -764,6 +764,358 @@ __global__ __launch_bounds__(64 * 16 / MB, 1) void gram_planes_kernel(const u32x
     }
 }
 
+// ---- the f16x2 tile kernel on v_mfma_f32_16x16x32_f16 (round 6) ------------------------------------------------------------
+// Same workgroup tile (256 x 128), same wave tile (64 x 64), same planes, same LDS-DMA ring, same schedule of workgroups and
+// the same fp32 level-1 / fp64 slab hierarchy as gram_planes_kernel<2, ...> above -- but the matrix instruction is the
+// 16 x 16 x 32 one: per MAC it reads and writes HALF the accumulator registers and twice the operand registers of the
+// 32 x 32 x 16 form, and at the socket's power cap (which is what bounds this kernel: EXPERIMENTS.md G6) that is worth 12-14 % of
+// MFMA throughput on random fp16 data (scripts/ubench/mfma_shapes.hip: 1430 -> 1610 TF with the operands re-read from LDS every
+// step, 1580 -> 1800 TF with them in registers; on all-zero data, where nothing is power-bound, the two shapes tie).
+//
+// A K = 32 step is a SUPER-STAGE: two consecutive 16-column stages of the ring.  The planes are stored as 1 KiB images of
+// (32 rows x 16 columns) per plane: lane l' of an image holds row l' & 31, columns 8 (l' >> 5) .. + 7.  The A / B operand of
+// the 16 x 16 x 32 MFMA wants lane l: row l & 15, k = 8 (l >> 4) .. + 7 of 32.  So lane l reads 16 bytes at
+//       stage (l >> 5) of the pair,  image lane (l & 15) + 16 h + 32 ((l >> 4) & 1)        (h = which half of the 32-row block)
+// -- lanes 0-31 from the first stage's buffer, lanes 32-63 from the second's, one ds_read_b128 -- and the sixteen lanes of
+// every service group of ds_read_b128 land on sixteen different 16-byte slots: conflict-free, no change to the split kernels.
+//
+// Registers: accumulators 64 + level-1 sums 64 + fragments 96 (A of this super-stage 32, A of the next 32, the two halves of B
+// 16 + 16).  The B side is walked in two halves of 32 columns: the first half's 24 MFMAs cover the reads of the second half's
+// B fragments, the second half's 24 MFMAs cover the reads of the NEXT super-stage's A and first-half B fragments.  One
+// workgroup barrier per super-stage (half as many as the 16-column form).
+template <int NBUF, bool DEFER>
+__global__ __launch_bounds__(512, 1) void gram_planes16_kernel(const u32x4* __restrict__ planes, int64_t n_steps,
+                                                            const double* __restrict__ unscale, int64_t rows_pad,
+                                                            double* __restrict__ partial, int n_tiles,
+                                                            const int2* __restrict__ tile_order, int n_chunks,
+                                                            int* __restrict__ tickets, int round_size, int t128,
+                                                            int slab_live0, int n_blocks32,
+                                                            int32_t* __restrict__ device_status,
+                                                            float* __restrict__ chunk_sums,
+                                                            float* __restrict__ ragged_sums, int kspan) {
+    constexpr int PLANES = 2;
+    constexpr int kRbBytes = PLANES * kFragBytes;           // one 32-row block, one stage: [plane][1 KiB]
+    constexpr int kStage = kRowBlocks * kRbBytes;           // 24,576
+    constexpr int NW = 8;
+    constexpr int kPerWave = kRowBlocks * PLANES / NW;      // 3 DMA instructions per wave and stage
+    constexpr int kSuperFlush = kFlushSteps / 2;            // super-stages per 256-column MFMA chain
+    constexpr int kSuperChunk = kChunkSteps / 2;            // super-stages per 8192-column chunk
+    static_assert(kRowBlocks * PLANES % NW == 0 && NBUF == 6, "ring arithmetic below");
+    typedef f16x8 frag_t;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];   // [NBUF][12 row blocks][2 planes][1 KiB]
+
+    // workgroup -> (tile, span of chunks): exactly gram_planes_kernel's mapping
+    const int xcd = blockIdx.x & 7;
+    const int seq = blockIdx.x >> 3;
+    const int base = n_tiles >> 3, rem = n_tiles & 7;
+    const int mine = base + (xcd < rem ? 1 : 0);
+    const int first = xcd * base + (xcd < rem ? xcd : rem);
+    const int n_spans = DEFER ? (n_chunks + kspan - 1) / kspan : n_chunks;
+    const int span = mine > 0 ? seq / mine : n_spans;
+    const int chunk = DEFER ? span * kspan : span;
+    int* done = tickets + n_tiles + xcd;
+    {
+        const int round = round_size > 0 ? seq / round_size : 0;
+        if (round > 0 && threadIdx.x == 0) {
+            unsigned spins = 0;
+            while (__hip_atomic_load(done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < round * round_size) {
+                __builtin_amdgcn_s_sleep(16);
+                if (++spins > (1u << 20)) break;   // only speed depends on the gate
+            }
+        }
+        __syncthreads();
+        if (span >= n_spans) {
+            if (threadIdx.x == 0) __hip_atomic_fetch_add(done, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            return;
+        }
+    }
+    const int t_list = first + (seq - span * mine);
+    const int2 tt = tile_order[t_list];
+    const int bi = __builtin_amdgcn_readfirstlane(tt.x);   // 256-row block of the A side
+    const int tj = __builtin_amdgcn_readfirstlane(tt.y);   // 128-row block of the B side
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 1, wc = wave & 1;
+    const int ti = 2 * bi + wr / 2;                    // this wave's slab row
+    const int row_in_slab = (wr % 2) * 64;             // and where its 64 x 64 sub-tile starts inside it
+    // live 32 x 32 blocks of the sub-tile (bit m32 * 2 + n32): the rule of gram_planes_kernel
+    unsigned live_blocks = 0;
+    if (tj <= ti && ti < t128 && n_blocks32 < 0) {
+        live_blocks = 15u;
+    } else if (tj <= ti && ti < t128) {
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int n = 0; n < 2; ++n) {
+                const int rblk = ti * 4 + row_in_slab / 32 + m, cblk = tj * 4 + wc * 2 + n;
+                if (rblk < n_blocks32 && cblk <= rblk) live_blocks |= 1u << (m * 2 + n);
+            }
+    }
+    const bool live_wave = live_blocks != 0;
+
+    const int step0 = chunk * kChunkSteps;
+    int n_stages = static_cast<int>(n_steps) - step0;       // even: n_steps counts whole 32-column pairs, chunks are even
+    {
+        const int span_steps = DEFER ? kspan * kChunkSteps : kChunkSteps;
+        if (n_stages > span_steps) n_stages = span_steps;
+    }
+    const int n_super = n_stages / 2;
+
+    // LDS-DMA: piece q = wave + 8 i of a stage (row block q / 2, plane q % 2)
+    int64_t piece_off[kPerWave];
+#pragma unroll
+    for (int i = 0; i < kPerWave; ++i) {
+        const int q = wave + NW * i;
+        const int rbl = q / PLANES, piece = q % PLANES;
+        const int64_t rb = rbl < 8 ? static_cast<int64_t>(bi) * 8 + rbl : static_cast<int64_t>(tj) * 4 + (rbl - 8);
+        piece_off[i] = (((rb * n_steps + step0) * PLANES + piece) * 64) * 16;
+    }
+    const unsigned char* lane_base = reinterpret_cast<const unsigned char*>(planes) + lane * 16;
+    auto dma = [&](int s) __attribute__((always_inline)) {
+        unsigned char* dst = lds + (s % NBUF) * kStage + wave * kFragBytes;
+#pragma unroll
+        for (int i = 0; i < kPerWave; ++i)
+            __builtin_amdgcn_global_load_lds(
+                (const __attribute__((address_space(1))) void*)(lane_base + piece_off[i] + static_cast<int64_t>(s) * (PLANES * kFragBytes)),
+                (__attribute__((address_space(3))) void*)(dst + i * NW * kFragBytes), 16, 0, 0);
+    };
+
+    f32x4 acc[4][4], acc2[4][4];     // [16-row block][16-column block]
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int n = 0; n < 4; ++n)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                acc[m][n][e] = 0.0f;
+                acc2[m][n][e] = 0.0f;
+            }
+
+    // this lane's byte offset inside a 32-row block's stage image pair: which stage of the pair, which image lane
+    const int lane_in_image = (lane & 15) + 32 * ((lane >> 4) & 1);
+    const int pair_half = lane >> 5;                         // 0: the first stage of the super-stage, 1: the second
+    // fragment (row block rb32 of the stage image, half h of it, plane p) of super-stage sp
+    auto frag_at = [&](int sp, int rb32, int h, int p) __attribute__((always_inline)) -> frag_t {
+        // (NBUF = 6 is even: the two stages of a super-stage sit in buffers 2 (sp % 3) and 2 (sp % 3) + 1)
+        const unsigned char* at = lds + (2 * (sp % (NBUF / 2)) + pair_half) * kStage + rb32 * kRbBytes + p * kFragBytes +
+                                  (lane_in_image + 16 * h) * 16;
+        return *reinterpret_cast<const frag_t*>(at);
+    };
+    struct AFrags { frag_t v[2][4]; };     // [plane h, m][16-row block of the wave's 64 rows]
+    struct BFrags { frag_t v[2][2]; };     // [plane][16-column block of one 32-column half]
+    auto read_a = [&](int sp, AFrags& a, auto mask_c) __attribute__((always_inline)) {
+        constexpr unsigned MASK = decltype(mask_c)::value;
+#pragma unroll
+        for (int p = 0; p < 2; ++p)
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+                if (((MASK >> ((m / 2) * 2)) & 3u) != 0) a.v[p][m] = frag_at(sp, 2 * wr + m / 2, m % 2, p);
+    };
+    auto read_b = [&](int sp, int half, BFrags& b, auto mask_c) __attribute__((always_inline)) {
+        constexpr unsigned MASK = decltype(mask_c)::value;
+        // (the caller passes a compile-time `half`)
+#pragma unroll
+        for (int p = 0; p < 2; ++p)
+#pragma unroll
+            for (int n = 0; n < 2; ++n) b.v[p][n] = frag_at(sp, 8 + 2 * wc + half, n, p);
+        (void)MASK;
+    };
+    // the 24 MFMAs of one 32-column half: m h' + h m' + h h' per 16 x 16 block, term-major
+    auto multiply_half = [&](const AFrags& a, const BFrags& b, auto half_c, auto mask_c) __attribute__((always_inline)) {
+        constexpr unsigned MASK = decltype(mask_c)::value;
+        constexpr int HALF = decltype(half_c)::value;
+        constexpr int pa[3] = {1, 0, 0};
+        constexpr int pb[3] = {0, 1, 0};
+#pragma unroll
+        for (int t = 0; t < 3; ++t)
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+#pragma unroll
+                for (int n = 0; n < 2; ++n)
+                    if (((MASK >> ((m / 2) * 2 + HALF)) & 1u) != 0)
+                        acc[m][2 * HALF + n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a.v[pa[t]][m], b.v[pb[t]][n], acc[m][2 * HALF + n], 0, 0, 0);
+    };
+    // element (i, j) of the wave's sub-tile that acc[m][n][e] holds: i = 16 m + 4 (lane >> 4) + e, j = 16 n + (lane & 15)
+    auto store_chunk = [&](int c, auto mask_c) __attribute__((always_inline)) {
+        constexpr unsigned MASK = decltype(mask_c)::value;
+        const int sel = wr / 2;
+        int lane_o = lane, c_o = c;
+        asm volatile("" : "+v"(lane_o));      // (the addresses are formed here, not hoisted out of the K loop)
+        asm volatile("" : "+s"(c_o));
+        float* out = chunk_sums + ((static_cast<int64_t>(c_o) * n_tiles + t_list) * 2 + sel) * (kSlab * kSlab) +
+                     (row_in_slab + 4 * (lane_o >> 4)) * kSlab + wc * 64 + (lane_o & 15);
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int n = 0; n < 4; ++n) {
+                if (((MASK >> ((m / 2) * 2 + n / 2)) & 1u) == 0) continue;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) out[(16 * m + e) * kSlab + 16 * n] = acc2[m][n][e];
+            }
+    };
+    auto flush = [&](int sp, auto mask_c) __attribute__((always_inline)) {
+        if ((sp + 1) % kSuperFlush == 0) {
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+#pragma unroll
+                for (int n = 0; n < 4; ++n)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        acc2[m][n][e] += acc[m][n][e];
+                        acc[m][n][e] = 0.0f;
+                    }
+            if constexpr (DEFER) {
+                if ((sp + 1) % kSuperChunk == 0 && sp + 1 < n_super) {   // a chunk of the span ends here and another follows
+                    store_chunk(chunk + (sp + 1) / kSuperChunk - 1, mask_c);
+#pragma unroll
+                    for (int m = 0; m < 4; ++m)
+#pragma unroll
+                        for (int n = 0; n < 4; ++n)
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) acc2[m][n][e] = 0.0f;
+                    wait_vmcnt<0>();   // stores count in vmcnt like the ring's loads: nothing of either kind crosses the boundary
+                }
+            }
+        }
+    };
+
+    // ---- the ring: six stages = three super-stages; the DMA runs two super-stages ahead of the one being multiplied
+    for (int a = 0; a < NBUF && a < n_stages; ++a) dma(a);
+    {
+        const int issued = n_stages < NBUF ? n_stages : NBUF;
+        wait_vmcnt_dyn((issued > 2 ? issued - 2 : 0) * kPerWave);   // stages 0 and 1 have landed
+    }
+    asm volatile("s_barrier" ::: "memory");
+    auto k_loop = [&](auto mask_c) __attribute__((always_inline)) {
+        constexpr unsigned MASK = decltype(mask_c)::value;
+        constexpr bool kLive = MASK != 0;
+        constexpr std::integral_constant<int, 0> h0{};
+        constexpr std::integral_constant<int, 1> h1{};
+        AFrags a0, a1;
+        BFrags b0, b1;
+        if (kLive && n_super > 0) {
+            read_a(0, a0, mask_c);
+            if ((MASK & 5u) != 0) read_b(0, 0, b0, mask_c);
+        }
+        // one super-stage: cur A in `a`, next A goes to `an`
+        auto super = [&](int sp, AFrags& a, AFrags& an) __attribute__((always_inline)) {
+            if (kLive) {
+                if ((MASK & 10u) != 0) read_b(sp, 1, b1, mask_c);            // the second half's B: under the first half's MFMAs
+                if ((MASK & 5u) != 0) multiply_half(a, b0, h0, mask_c);
+            }
+            // stages 2 sp + 2, 2 sp + 3 must have landed before anybody reads them; of my requests only the stages behind them
+            // may still be outstanding (returns are in issue order)
+            {
+                const int last = 2 * sp + 5 < n_stages - 1 ? 2 * sp + 5 : n_stages - 1;   // the last stage requested so far
+                const int ahead = last - (2 * sp + 3);
+                if (2 * sp + 7 < n_stages) wait_vmcnt<2 * kPerWave>();                   // steady state: two stages may be in flight
+                else wait_vmcnt_dyn((ahead > 0 ? ahead : 0) * kPerWave);
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // everybody has read super-stage sp; sp + 1 has landed
+            if (2 * sp + NBUF < n_stages) dma(2 * sp + NBUF);
+            if (2 * sp + NBUF + 1 < n_stages) dma(2 * sp + NBUF + 1);
+            if (kLive) {
+                if (sp + 1 < n_super) {
+                    read_a(sp + 1, an, mask_c);                               // under the second half's MFMAs
+                    if ((MASK & 5u) != 0) read_b(sp + 1, 0, b0, mask_c);
+                }
+                if ((MASK & 10u) != 0) multiply_half(a, b1, h1, mask_c);
+                flush(sp, mask_c);
+            }
+        };
+        int sp = 0;
+        for (; sp + 1 < n_super; sp += 2) {
+            super(sp, a0, a1);
+            super(sp + 1, a1, a0);
+        }
+        if (sp < n_super) super(sp, a0, a1);
+    };
+    switch (live_blocks) {
+        case 0u: k_loop(std::integral_constant<unsigned, 0u>{}); break;
+        case 1u: k_loop(std::integral_constant<unsigned, 1u>{}); break;
+        case 3u: k_loop(std::integral_constant<unsigned, 3u>{}); break;
+        case 13u: k_loop(std::integral_constant<unsigned, 13u>{}); break;
+        default: live_blocks = 15u; k_loop(std::integral_constant<unsigned, 15u>{}); break;
+    }
+    auto block_live = [&](int m, int n) __attribute__((always_inline)) { return ((live_blocks >> ((m / 2) * 2 + n / 2)) & 1u) != 0; };
+
+    if constexpr (DEFER) {
+        if (live_wave) {
+            const int sel = wr / 2;
+            const bool unflushed = (n_super % kSuperFlush) != 0;
+            const int last_chunk = chunk + (n_stages - 1) / kChunkSteps;
+            float* out = chunk_sums + ((static_cast<int64_t>(last_chunk) * n_tiles + t_list) * 2 + sel) * (kSlab * kSlab);
+            float* rag = ragged_sums + (static_cast<int64_t>(t_list) * 2 + sel) * (kSlab * kSlab);
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+#pragma unroll
+                for (int n = 0; n < 4; ++n) {
+                    if (!block_live(m, n)) continue;
+                    const int j = wc * 64 + 16 * n + (lane & 15);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int i = row_in_slab + 16 * m + 4 * (lane >> 4) + e;
+                        out[i * kSlab + j] = acc2[m][n][e];
+                        if (unflushed) rag[i * kSlab + j] = acc[m][n][e];
+                    }
+                }
+        }
+        __syncthreads();
+        if (tid == 0) __hip_atomic_fetch_add(done, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return;
+    }
+    // epilogue of the in-kernel form: chunks of a tile add into its slabs in chunk order (gram.hip's ticket protocol)
+    bool lost = false;
+    if (chunk > 0) {
+        if (tid == 0) {
+            unsigned spins = 0;
+            while (__hip_atomic_load(tickets + t_list, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != chunk) {
+                __builtin_amdgcn_s_sleep(8);
+                if (++spins > (1u << 26)) {
+                    lost = true;
+                    break;
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        }
+        lost = __syncthreads_or(lost ? 1 : 0) != 0;
+    }
+    if (lost) {
+        if (tid == 0) atomicOr(device_status, kStatusLostTicket);
+    } else if (live_wave) {
+        const bool slab_live = chunk > 0 || slab_live0 != 0;
+        double* out = partial + (static_cast<int64_t>(ti) * (ti + 1) / 2 + tj) * (kSlab * kSlab);
+        const double* un = unscale + static_cast<int64_t>(chunk) * rows_pad;
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int n = 0; n < 4; ++n) {
+                if (!block_live(m, n)) continue;
+                const int j = wc * 64 + 16 * n + (lane & 15);
+                const double uj = un[static_cast<int64_t>(tj) * kSlab + j];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int i = row_in_slab + 16 * m + 4 * (lane >> 4) + e;
+                    double v = static_cast<double>(acc2[m][n][e]);
+                    v += static_cast<double>(acc[m][n][e]);
+                    v *= un[static_cast<int64_t>(ti) * kSlab + i] * uj;   // powers of two: exact
+                    if (slab_live) v += out[i * kSlab + j];
+                    out[i * kSlab + j] = v;
+                }
+            }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __hip_atomic_store(tickets + t_list, chunk + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_fetch_add(done, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
 // The deferred slab update: slab entry (i, j) of every tile of the launch += its chunks' sums in chunk order -- per chunk
 // v = (double)level-1 sum (+ (double)unflushed chain), v *= 2^-shift_i 2^-shift_j, slab = v + slab: the fp64 operations of
 // the in-kernel update, in its order.  One workgroup per (tile, slab, quarter of its rows); a thread owns four consecutive
@@ -907,7 +1259,11 @@ int launch_gram_planes(byz_ctx* ctx, const float* G, int64_t n_rows, int64_t n_c
                              int, int, int32_t*, float*, float*, int);
     // BYZ_GRAM_DEFER=0: round 4's in-kernel slab update (the same-box A/B and the bitwise comparison of the tests)
     bool defer = f16 && env_int("BYZ_GRAM_DEFER", 1) != 0;
-    kernel_t kernel = defer ? &gram_planes_kernel<2, 6, 0, 2, true> : f16 ? &gram_planes_kernel<2, 6, 0> : &gram_planes_kernel<3, 4, 0>;
+    // BYZ_GRAM_MFMA=32: the f16x2 tile kernel on v_mfma_f32_32x32x16_f16 (rounds 2-5; the same-box A/B) instead of 16x16x32
+    const bool shape16 = f16 && env_int("BYZ_GRAM_MFMA", 16) != 32;
+    kernel_t kernel = !f16 ? &gram_planes_kernel<3, 4, 0>
+                      : shape16 ? (defer ? &gram_planes16_kernel<6, true> : &gram_planes16_kernel<6, false>)
+                                : (defer ? &gram_planes_kernel<2, 6, 0, 2, true> : &gram_planes_kernel<2, 6, 0>);
     int nbuf = f16 ? 6 : 4;
     const int threads = kThreads;
 #ifdef BYZ_GRAM_DEBUG_VARIANTS
@@ -942,7 +1298,7 @@ int launch_gram_planes(byz_ctx* ctx, const float* G, int64_t n_rows, int64_t n_c
         BYZ_HIP(hipMemGetInfo(&free_now, &total_now));
         if (want > ctx->gram_chunk_sums.bytes && want - ctx->gram_chunk_sums.bytes > free_now / 2) {
             defer = false;
-            kernel = &gram_planes_kernel<2, 6, 0>;
+            kernel = shape16 ? &gram_planes16_kernel<6, false> : &gram_planes_kernel<2, 6, 0>;
         }
     }
     if (defer) {
