@@ -401,7 +401,8 @@ __global__ __launch_bounds__(64 * 16 / MB, 1) void gram_planes_kernel(const u32x
                                                                   int slab_live0, int n_blocks32,
                                                                   int32_t* __restrict__ device_status,
                                                                   float* __restrict__ chunk_sums,
-                                                                  float* __restrict__ ragged_sums, int kspan) {
+                                                                  float* __restrict__ ragged_sums, int kspan, int pin) {
+    (void)pin;   // (gram_planes16_kernel's knob: one launch signature for both kernels)
     constexpr int kRbBytes = PLANES * kFragBytes;           // one 32-row block, one stage: [plane][1 KiB]
     constexpr int kStage = kRowBlocks * kRbBytes;           // 36,864 (bf16x3) / 24,576 (f16x2)
     constexpr int NW = 16 / MB;                             // waves of the workgroup
@@ -792,7 +793,7 @@ __global__ __launch_bounds__(512, 1) void gram_planes16_kernel(const u32x4* __re
                                                             int slab_live0, int n_blocks32,
                                                             int32_t* __restrict__ device_status,
                                                             float* __restrict__ chunk_sums,
-                                                            float* __restrict__ ragged_sums, int kspan) {
+                                                            float* __restrict__ ragged_sums, int kspan, int pin) {
     constexpr int PLANES = 2;
     constexpr int kRbBytes = PLANES * kFragBytes;           // one 32-row block, one stage: [plane][1 KiB]
     constexpr int kStage = kRowBlocks * kRbBytes;           // 24,576
@@ -873,13 +874,15 @@ __global__ __launch_bounds__(512, 1) void gram_planes16_kernel(const u32x4* __re
         piece_off[i] = (((rb * n_steps + step0) * PLANES + piece) * 64) * 16;
     }
     const unsigned char* lane_base = reinterpret_cast<const unsigned char*>(planes) + lane * 16;
-    auto dma = [&](int s) __attribute__((always_inline)) {
+    auto dma_piece = [&](int s, int i) __attribute__((always_inline)) {   // (i: a compile-time piece number after unrolling)
         unsigned char* dst = lds + (s % NBUF) * kStage + wave * kFragBytes;
+        __builtin_amdgcn_global_load_lds(
+            (const __attribute__((address_space(1))) void*)(lane_base + piece_off[i] + static_cast<int64_t>(s) * (PLANES * kFragBytes)),
+            (__attribute__((address_space(3))) void*)(dst + i * NW * kFragBytes), 16, 0, 0);
+    };
+    auto dma = [&](int s) __attribute__((always_inline)) {
 #pragma unroll
-        for (int i = 0; i < kPerWave; ++i)
-            __builtin_amdgcn_global_load_lds(
-                (const __attribute__((address_space(1))) void*)(lane_base + piece_off[i] + static_cast<int64_t>(s) * (PLANES * kFragBytes)),
-                (__attribute__((address_space(3))) void*)(dst + i * NW * kFragBytes), 16, 0, 0);
+        for (int i = 0; i < kPerWave; ++i) dma_piece(s, i);
     };
 
     f32x4 acc[4][4], acc2[4][4];     // [16-row block][16-column block]
@@ -1025,7 +1028,44 @@ __global__ __launch_bounds__(512, 1) void gram_planes16_kernel(const u32x4* __re
                 flush(sp, mask_c);
             }
         };
+        // The steady state of a FULL wave (all sixteen blocks live, both stages of super-stage sp + 3 still to be requested),
+        // with the instructions behind the barrier in a PINNED order (BYZ_GRAM_PIN, `pin`): six groups of {one DMA piece, two
+        // fragment reads of super-stage sp + 1, four MFMAs of this super-stage's second half}.  Left to itself hipcc issues the
+        // six DMA pieces and the twelve reads first -- both waves of every SIMD at once, right behind the barrier, with the
+        // matrix pipe idle -- and the 24 MFMAs behind them.
+        auto super_pinned = [&](int sp, AFrags& a, AFrags& an) __attribute__((always_inline)) {
+            read_b(sp, 1, b1, mask_c);
+            multiply_half(a, b0, h0, mask_c);
+            wait_vmcnt<2 * kPerWave>();
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            constexpr int pa[3] = {1, 0, 0};
+            constexpr int pb[3] = {0, 1, 0};
+#pragma unroll
+            for (int g = 0; g < 6; ++g) {
+                dma_piece(2 * sp + NBUF + g / 3, g % 3);
+#pragma unroll
+                for (int r = 2 * g; r < 2 * g + 2; ++r) {
+                    if (r < 8) an.v[r / 4][r % 4] = frag_at(sp + 1, 2 * wr + (r % 4) / 2, (r % 4) % 2, r / 4);
+                    else b0.v[(r - 8) / 2][(r - 8) % 2] = frag_at(sp + 1, 8 + 2 * wc + 0, (r - 8) % 2, (r - 8) / 2);
+                }
+#pragma unroll
+                for (int q = 4 * g; q < 4 * g + 4; ++q) {
+                    const int t = q / 8, m = (q % 8) / 2, n = q % 2;
+                    acc[m][2 + n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a.v[pa[t]][m], b1.v[pb[t]][n], acc[m][2 + n], 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            flush(sp, mask_c);
+        };
         int sp = 0;
+        if constexpr (MASK == 15u) {
+            if (pin != 0) {
+                for (; 2 * (sp + 1) + NBUF + 1 < n_stages && sp + 2 < n_super; sp += 2) {
+                    super_pinned(sp, a0, a1);
+                    super_pinned(sp + 1, a1, a0);
+                }
+            }
+        }
         for (; sp + 1 < n_super; sp += 2) {
             super(sp, a0, a1);
             super(sp + 1, a1, a0);
@@ -1256,7 +1296,7 @@ int launch_gram_planes(byz_ctx* ctx, const float* G, int64_t n_rows, int64_t n_c
     int* tickets = ctx->gram_tickets.as<int>();
     u32x4* planes = ctx->gram_planes.as<u32x4>();
     typedef void (*kernel_t)(const u32x4*, int64_t, const double*, int64_t, double*, int, const int2*, int, int*, int, int,
-                             int, int, int32_t*, float*, float*, int);
+                             int, int, int32_t*, float*, float*, int, int);
     // BYZ_GRAM_DEFER=0: round 4's in-kernel slab update (the same-box A/B and the bitwise comparison of the tests)
     bool defer = f16 && env_int("BYZ_GRAM_DEFER", 1) != 0;
     // BYZ_GRAM_MFMA=32: the f16x2 tile kernel on v_mfma_f32_32x32x16_f16 (rounds 2-5; the same-box A/B) instead of 16x16x32
@@ -1368,7 +1408,7 @@ int launch_gram_planes(byz_ctx* ctx, const float* G, int64_t n_rows, int64_t n_c
             kernel<<<static_cast<unsigned>(grid), threads, lds_bytes, stream>>>(
                 planes, n_steps, unscale, rows_pad, slabs, static_cast<int>(n_tiles), ctx->plane_order.as<int2>(),
                 static_cast<int>(n_chunks), tickets, round_size, static_cast<int>(t128), sc > 0 ? 1 : 0,
-                n_blocks32, device_status_word(ctx), chunk_sums, ragged_sums, static_cast<int>(kspan));
+                n_blocks32, device_status_word(ctx), chunk_sums, ragged_sums, static_cast<int>(kspan), env_int("BYZ_GRAM_PIN", 1));
             BYZ_TRY(check_launch("gram_planes_kernel"));
         }
         if (defer) {

@@ -209,7 +209,10 @@ def test_columns_layout_looped_over_the_shards_equals_one_gpu(eng, torch, n, d, 
     sel = eng.bulyan_select(dist, n, f, on_device=True)
     out = torch.cat([kern.trimmed_mean(v, 2 * f, row_index=sel) for v in slices])
     got = (torch.from_numpy(dist.numpy()), out.cpu(), sel.numpy().tolist(), idx)
-    check_against_unsharded(torch, want, got, 'columns W=%d' % world, g, f=f if n >= 8000 else None)
+    # (N >= 4000: thousands of picks among scores ~1e-4 apart while the two paths' distances agree to 2e-6 -- different column
+    # splits, hence different roundings -- so the first differing pick, if there is one, must be a near-tie: the rule inside.
+    # Until round 6 only N = 10,000 needed it; with the 16 x 16 x 32 MFMA's roundings N = 4000 parts at pick 579 of 2080.)
+    check_against_unsharded(torch, want, got, 'columns W=%d' % world, g, f=f if n >= 4000 else None)
 
 
 @pytest.mark.parametrize('n,d,world,panel_cols', [(1200, 24640, 3, 8192), (3000, 2 * 16400, 2, 16400), (520, 6000, 8, 2048),
