@@ -1034,22 +1034,26 @@ __global__ __launch_bounds__(512, 1) void gram_planes16_kernel(const u32x4* __re
         // six DMA pieces and the twelve reads first -- both waves of every SIMD at once, right behind the barrier, with the
         // matrix pipe idle -- and the 24 MFMAs behind them.
         auto super_pinned = [&](int sp, AFrags& a, AFrags& an) __attribute__((always_inline)) {
+            constexpr int pa[3] = {1, 0, 0};
+            constexpr int pb[3] = {0, 1, 0};
             read_b(sp, 1, b1, mask_c);
             multiply_half(a, b0, h0, mask_c);
             wait_vmcnt<2 * kPerWave>();
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-            constexpr int pa[3] = {1, 0, 0};
-            constexpr int pb[3] = {0, 1, 0};
+            // (Three other pinned orders -- the four MFMAs in front of the DMA piece, twelve groups of {two MFMAs, a DMA piece
+            // every other group, one read}, the first half pinned as well -- were built with -DBYZ_GRAM_PIN_ORDER and alternated on
+            // one box: 41.3 .. 41.8 ms per launch, all four: profiles/r06o_gram_pin_orders_ab.txt.  What pays is that the DMA
+            // pieces and the reads are spread AT ALL.)
 #pragma unroll
             for (int g = 0; g < 6; ++g) {
                 dma_piece(2 * sp + NBUF + g / 3, g % 3);
 #pragma unroll
-                for (int r = 2 * g; r < 2 * g + 2; ++r) {
+                for (int r = 2 * g; r < 2 * g + 2; ++r) {     // fragment r of super-stage sp + 1: A (8), then B's first half (4)
                     if (r < 8) an.v[r / 4][r % 4] = frag_at(sp + 1, 2 * wr + (r % 4) / 2, (r % 4) % 2, r / 4);
                     else b0.v[(r - 8) / 2][(r - 8) % 2] = frag_at(sp + 1, 8 + 2 * wc + 0, (r - 8) % 2, (r - 8) / 2);
                 }
 #pragma unroll
-                for (int q = 4 * g; q < 4 * g + 4; ++q) {
+                for (int q = 4 * g; q < 4 * g + 4; ++q) {     // MFMA q of the 24 of this super-stage's second half
                     const int t = q / 8, m = (q % 8) / 2, n = q % 2;
                     acc[m][2 + n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a.v[pa[t]][m], b1.v[pb[t]][n], acc[m][2 + n], 0, 0, 0);
                 }
