@@ -1028,45 +1028,104 @@ __global__ __launch_bounds__(512, 1) void gram_planes16_kernel(const u32x4* __re
                 flush(sp, mask_c);
             }
         };
-        // The steady state of a FULL wave (all sixteen blocks live, both stages of super-stage sp + 3 still to be requested),
-        // with the instructions behind the barrier in a PINNED order (BYZ_GRAM_PIN, `pin`): six groups of {one DMA piece, two
+        // The steady state of a FULL wave (all sixteen blocks live, both stages of super-stage sp + 3 still to be requested) with its
+        // instructions in a PINNED order (BYZ_GRAM_PIN=0: the compiler's): behind the barrier six groups of {one DMA piece, two
         // fragment reads of super-stage sp + 1, four MFMAs of this super-stage's second half}.  Left to itself hipcc issues the
         // six DMA pieces and the twelve reads first -- both waves of every SIMD at once, right behind the barrier, with the
-        // matrix pipe idle -- and the 24 MFMAs behind them.
-        auto super_pinned = [&](int sp, AFrags& a, AFrags& an) __attribute__((always_inline)) {
+        // matrix pipe idle -- and the 24 MFMAs behind them (same box: 45.6 -> 42.3 ms per launch at N = 4000, bitwise).
+        // (Three other pinned orders -- the four MFMAs in front of the DMA piece, twelve groups of {two MFMAs, a DMA piece every
+        // other group, one read}, the first half pinned as well -- were alternated on one box: 41.3 .. 41.8 ms, all four:
+        // profiles/r06o_gram_pin_orders_ab.txt.  What pays is that the DMA pieces and the reads are spread AT ALL.)
+        // The steady state runs in TRIPS OF EIGHT super-stages = one 256-column MFMA chain, every position of the chain its own
+        // straight-line code:
+        //   * position 0 starts every block's chain from C = 0 (an inline constant of the MFMA), so the flush at position 7
+        //     does not have to zero the accumulators: 64 of its 128 vector instructions gone;
+        //   * position 7 adds the first half's eight blocks to the level-1 sums INSIDE the six pinned groups behind the barrier
+        //     (their last MFMAs were issued before it) and only the second half's eight behind them;
+        //   * the first half is pinned too: one read of the second half's B per six MFMAs.
+        auto super8 = [&](int sp, AFrags& a, AFrags& an, auto pos_c) __attribute__((always_inline)) {
+            constexpr int POS = decltype(pos_c)::value;
+            constexpr bool FRESH = POS == 0, FLUSHING = POS == 7;
             constexpr int pa[3] = {1, 0, 0};
             constexpr int pb[3] = {0, 1, 0};
-            read_b(sp, 1, b1, mask_c);
-            multiply_half(a, b0, h0, mask_c);
+            const f32x4 zero4 = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                b1.v[g / 2][g % 2] = frag_at(sp, 8 + 2 * wc + 1, g % 2, g / 2);
+#pragma unroll
+                for (int q = 6 * g; q < 6 * g + 6; ++q) {
+                    const int t = q / 8, m = (q % 8) / 2, n = q % 2;
+                    acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a.v[pa[t]][m], b0.v[pb[t]][n], (FRESH && t == 0) ? zero4 : acc[m][n], 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
             wait_vmcnt<2 * kPerWave>();
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-            // (Three other pinned orders -- the four MFMAs in front of the DMA piece, twelve groups of {two MFMAs, a DMA piece
-            // every other group, one read}, the first half pinned as well -- were built with -DBYZ_GRAM_PIN_ORDER and alternated on
-            // one box: 41.3 .. 41.8 ms per launch, all four: profiles/r06o_gram_pin_orders_ab.txt.  What pays is that the DMA
-            // pieces and the reads are spread AT ALL.)
 #pragma unroll
             for (int g = 0; g < 6; ++g) {
                 dma_piece(2 * sp + NBUF + g / 3, g % 3);
 #pragma unroll
-                for (int r = 2 * g; r < 2 * g + 2; ++r) {     // fragment r of super-stage sp + 1: A (8), then B's first half (4)
+                for (int r = 2 * g; r < 2 * g + 2; ++r) {
                     if (r < 8) an.v[r / 4][r % 4] = frag_at(sp + 1, 2 * wr + (r % 4) / 2, (r % 4) % 2, r / 4);
                     else b0.v[(r - 8) / 2][(r - 8) % 2] = frag_at(sp + 1, 8 + 2 * wc + 0, (r - 8) % 2, (r - 8) / 2);
                 }
 #pragma unroll
-                for (int q = 4 * g; q < 4 * g + 4; ++q) {     // MFMA q of the 24 of this super-stage's second half
+                for (int q = 4 * g; q < 4 * g + 4; ++q) {
                     const int t = q / 8, m = (q % 8) / 2, n = q % 2;
-                    acc[m][2 + n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a.v[pa[t]][m], b1.v[pb[t]][n], acc[m][2 + n], 0, 0, 0);
+                    acc[m][2 + n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a.v[pa[t]][m], b1.v[pb[t]][n], (FRESH && t == 0) ? zero4 : acc[m][2 + n], 0, 0, 0);
+                }
+                if constexpr (FLUSHING) {
+                    // blocks (m, n < 2) of the first half: b = 2 m + n, eight of them over the six groups
+#pragma unroll
+                    for (int b = (8 * g) / 6; b < (8 * (g + 1)) / 6; ++b)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) acc2[b / 2][b % 2][e] += acc[b / 2][b % 2][e];
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
-            flush(sp, mask_c);
+            if constexpr (FLUSHING) {
+#pragma unroll
+                for (int m = 0; m < 4; ++m)
+#pragma unroll
+                    for (int n = 2; n < 4; ++n)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) acc2[m][n][e] += acc[m][n][e];
+                if constexpr (DEFER) {
+                    if ((sp + 1) % kSuperChunk == 0) {        // a chunk of the span ends here and another follows (steady state)
+                        store_chunk(chunk + (sp + 1) / kSuperChunk - 1, mask_c);
+#pragma unroll
+                        for (int m = 0; m < 4; ++m)
+#pragma unroll
+                            for (int n = 0; n < 4; ++n)
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) acc2[m][n][e] = 0.0f;
+                        wait_vmcnt<0>();
+                    }
+                }
+            }
         };
         int sp = 0;
         if constexpr (MASK == 15u) {
             if (pin != 0) {
-                for (; 2 * (sp + 1) + NBUF + 1 < n_stages && sp + 2 < n_super; sp += 2) {
-                    super_pinned(sp, a0, a1);
-                    super_pinned(sp + 1, a1, a0);
+                bool any = false;
+                for (; 2 * (sp + 7) + NBUF + 1 < n_stages && sp + 8 < n_super; sp += 8) {
+                    super8(sp + 0, a0, a1, std::integral_constant<int, 0>{});
+                    super8(sp + 1, a1, a0, std::integral_constant<int, 1>{});
+                    super8(sp + 2, a0, a1, std::integral_constant<int, 2>{});
+                    super8(sp + 3, a1, a0, std::integral_constant<int, 3>{});
+                    super8(sp + 4, a0, a1, std::integral_constant<int, 4>{});
+                    super8(sp + 5, a1, a0, std::integral_constant<int, 5>{});
+                    super8(sp + 6, a0, a1, std::integral_constant<int, 6>{});
+                    super8(sp + 7, a1, a0, std::integral_constant<int, 7>{});
+                    any = true;
+                }
+                if (any) {     // the trips leave the accumulators as the last chain left them: what follows starts from zero
+#pragma unroll
+                    for (int m = 0; m < 4; ++m)
+#pragma unroll
+                        for (int n = 0; n < 4; ++n)
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) acc[m][n][e] = 0.0f;
                 }
             }
         }

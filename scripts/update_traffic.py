@@ -20,7 +20,7 @@ CSRC = os.path.join(ROOT, 'attacking_federate_learning_amd', 'csrc')
 
 # bench key -> (kernel name prefix in the raw file, source file, fetch_scale, launches per step, note)
 RULES = {
-    'c4/gram_tile': ('c4/gram_planes_kernel', 'gram_planes.hip', 2.0, 10, 'LDS-DMA pieces of 1 KiB', {'arithmetic': 'f16x2'}),
+    'c4/gram_tile': ('c4/gram_planes', 'gram_planes.hip', 2.0, 10, 'LDS-DMA pieces of 1 KiB', {'arithmetic': 'f16x2'}),   # gram_planes16_kernel since round 6
     'c4/plane_split': ('c4/plane_split_f16_stream_kernel', 'gram_planes.hip', 2.0, 10, 'f32x4 per thread over 128-byte row segments', {}),
     # (until the XCD-contiguous tile order the two 64-byte halves of a line were requested by two L2s and tallied at full size:
     #  raw = algorithmic; now neighbouring tiles meet in one L2 and the counter sees 128-byte requests, tallied at 64)
