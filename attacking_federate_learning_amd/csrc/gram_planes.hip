@@ -401,7 +401,7 @@ __global__ __launch_bounds__(64 * 16 / MB, 1) void gram_planes_kernel(const u32x
                                                                   int slab_live0, int n_blocks32,
                                                                   int32_t* __restrict__ device_status,
                                                                   float* __restrict__ chunk_sums,
-                                                                  float* __restrict__ ragged_sums, int kspan, int pin) {
+                                                                  float* __restrict__ ragged_sums, int kspan, int pin, int map_round) {
     (void)pin;   // (gram_planes16_kernel's knob: one launch signature for both kernels)
     constexpr int kRbBytes = PLANES * kFragBytes;           // one 32-row block, one stage: [plane][1 KiB]
     constexpr int kStage = kRowBlocks * kRbBytes;           // 36,864 (bf16x3) / 24,576 (f16x2)
@@ -793,7 +793,7 @@ __global__ __launch_bounds__(512, 1) void gram_planes16_kernel(const u32x4* __re
                                                             int slab_live0, int n_blocks32,
                                                             int32_t* __restrict__ device_status,
                                                             float* __restrict__ chunk_sums,
-                                                            float* __restrict__ ragged_sums, int kspan, int pin) {
+                                                            float* __restrict__ ragged_sums, int kspan, int pin, int map_round) {
     constexpr int PLANES = 2;
     constexpr int kRbBytes = PLANES * kFragBytes;           // one 32-row block, one stage: [plane][1 KiB]
     constexpr int kStage = kRowBlocks * kRbBytes;           // 24,576
@@ -812,9 +812,18 @@ __global__ __launch_bounds__(512, 1) void gram_planes16_kernel(const u32x4* __re
     const int mine = base + (xcd < rem ? 1 : 0);
     const int first = xcd * base + (xcd < rem ? xcd : rem);
     const int n_spans = DEFER ? (n_chunks + kspan - 1) / kspan : n_chunks;
-    const int span = mine > 0 ? seq / mine : n_spans;
-    const int chunk = DEFER ? span * kspan : span;
+    // map_round > 0 (round 6, the default): the (span, tile) units of the launch form ONE sequence, span-major, and the XCDs take
+    // its runs of `map_round` units in turn -- every round of an XCD is `map_round` CONSECUTIVE tiles of the list on (but for one
+    // round in n_tiles / map_round) ONE chunk, so with the list in bands of four 256-row blocks a round touches 16 row blocks of
+    // 128: the fewest 32 tiles of 256 x 128 can.  (map_round == 0: gram_planes_kernel's mapping -- a contiguous share of the tile
+    // list per XCD, whose rounds straddle two chunks nearly always.)
+    // (map_round < 0: rounds of -map_round units CLAIMED from one counter as the XCDs get to them instead of dealt in turn: an XCD
+    // whose rounds held the cheaper diagonal tiles takes more of them, and the launch ends with every XCD busy.)
+    int span = mine > 0 ? seq / mine : n_spans;
+    int t_in_share = seq - span * mine;
+    const int mr = map_round < 0 ? -map_round : map_round;
     int* done = tickets + n_tiles + xcd;
+    __shared__ int claimed_round;
     {
         const int round = round_size > 0 ? seq / round_size : 0;
         if (round > 0 && threadIdx.x == 0) {
@@ -824,13 +833,39 @@ __global__ __launch_bounds__(512, 1) void gram_planes16_kernel(const u32x4* __re
                 if (++spins > (1u << 20)) break;   // only speed depends on the gate
             }
         }
+        if (map_round < 0 && threadIdx.x == 0) {
+            // the first workgroup of this XCD's round `seq / mr` to get here claims the next run of units for all of them
+            int* slot = tickets + n_tiles + 9 + xcd * static_cast<int>(gridDim.x / (8u * static_cast<unsigned>(mr))) + seq / mr;
+            int v = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (v == 0) {
+                int expected = 0;
+                if (__hip_atomic_compare_exchange_strong(slot, &expected, -1, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+                    v = __hip_atomic_fetch_add(tickets + n_tiles + 8, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1;
+                    __hip_atomic_store(slot, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                } else {
+                    v = expected;
+                }
+            }
+            while (v <= 0) {   // (the claimer is between its exchange and its store: a fetch-add away)
+                __builtin_amdgcn_s_sleep(1);
+                v = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            claimed_round = v - 1;
+        }
         __syncthreads();
+        if (mr > 0) {
+            const int round_global = map_round < 0 ? claimed_round : (seq / mr) * 8 + xcd;
+            const int unit = round_global * mr + seq % mr;
+            span = unit / n_tiles;
+            t_in_share = unit - span * n_tiles - first;
+        }
         if (span >= n_spans) {
             if (threadIdx.x == 0) __hip_atomic_fetch_add(done, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             return;
         }
     }
-    const int t_list = first + (seq - span * mine);
+    const int chunk = DEFER ? span * kspan : span;
+    const int t_list = first + t_in_share;
     const int2 tt = tile_order[t_list];
     const int bi = __builtin_amdgcn_readfirstlane(tt.x);   // 256-row block of the A side
     const int tj = __builtin_amdgcn_readfirstlane(tt.y);   // 128-row block of the B side
@@ -1302,25 +1337,42 @@ int launch_gram_planes(byz_ctx* ctx, const float* G, int64_t n_rows, int64_t n_c
     const int64_t t128 = ceil_div(n_rows, kSlab);
     const int64_t t256 = ceil_div(t128, 2);
     const int64_t rows_pad = t256 * kWgRows;
-    // tile list: 8 x 8 super-blocks of slabs = 4 x 8 workgroup tiles, an XCD's resident workgroups share few row blocks
-    if (ctx->plane_order_T != t128 || ctx->plane_order_share != share_count * 65536 + share_index) {
+    // BYZ_GRAM_MFMA=32: the f16x2 tile kernel on v_mfma_f32_32x32x16_f16 (rounds 2-5; the same-box A/B) instead of 16x16x32
+    const bool shape16 = f16 && env_int("BYZ_GRAM_MFMA", 16) != 32;
+    // The tile list.  BYZ_GRAM_ORDER=1 (the 16x16x32 kernel's default): bands of four 256-row blocks, inside a band column block
+    // by column block -- ANY 32 consecutive tiles are (4 or 5) x (8 or 9) tiles on at most ~17 row blocks of 128, and the kernel
+    // hands out runs of 32 consecutive (chunk, tile) units to the XCDs in turn.  BYZ_GRAM_ORDER=0 (rounds 2-5, and the other
+    // kernels): 8 x 8 super-blocks of slabs = 4 x 8 workgroup tiles, a contiguous share of the list per XCD -- the rounds of an XCD
+    // then straddle two chunks and two or three super-blocks: 106 GB through the fabric per 1M-column launch at N = 4000 if every
+    // line were shared perfectly inside a round, against 70 GB for the bands (scripts/gram_order_footprint.py; EXPERIMENTS.md G8).
+    const int order_mode = shape16 && env_int("BYZ_GRAM_ORDER", 1) != 0 ? 1 : 0;
+    const int64_t order_key = static_cast<int64_t>(order_mode) * (1ll << 40) + share_count * 65536 + share_index;
+    if (ctx->plane_order_T != t128 || ctx->plane_order_share != order_key) {
         ctx->plane_order_host.clear();
-        const int64_t S = ceil_div(t128, 8);
         int64_t position = 0;
-        for (int64_t I = 0; I < S; ++I)
-            for (int64_t J = 0; J <= I; ++J)
-                for (int64_t bi = I * 4; bi < I * 4 + 4 && bi < t256; ++bi)
-                    for (int64_t tj = J * 8; tj < J * 8 + 8 && tj <= 2 * bi + 1 && tj < t128; ++tj) {
-                        if (position++ % share_count != share_index) continue;
-                        ctx->plane_order_host.push_back(static_cast<int32_t>(bi));
-                        ctx->plane_order_host.push_back(static_cast<int32_t>(tj));
-                    }
+        auto push = [&](int64_t bi, int64_t tj) {
+            if (position++ % share_count != share_index) return;
+            ctx->plane_order_host.push_back(static_cast<int32_t>(bi));
+            ctx->plane_order_host.push_back(static_cast<int32_t>(tj));
+        };
+        if (order_mode == 1) {
+            for (int64_t b0 = 0; b0 < t256; b0 += 4)
+                for (int64_t tj = 0; tj < t128 && tj <= 2 * (b0 + 3) + 1; ++tj)
+                    for (int64_t bi = b0; bi < b0 + 4 && bi < t256; ++bi)
+                        if (tj <= 2 * bi + 1) push(bi, tj);
+        } else {
+            const int64_t S = ceil_div(t128, 8);
+            for (int64_t I = 0; I < S; ++I)
+                for (int64_t J = 0; J <= I; ++J)
+                    for (int64_t bi = I * 4; bi < I * 4 + 4 && bi < t256; ++bi)
+                        for (int64_t tj = J * 8; tj < J * 8 + 8 && tj <= 2 * bi + 1 && tj < t128; ++tj) push(bi, tj);
+        }
         BYZ_TRY(ctx->plane_order.ensure(ctx->plane_order_host.size() * sizeof(int32_t) + 16));
         BYZ_HIP(hipMemcpyAsync(ctx->plane_order.ptr, ctx->plane_order_host.data(),
                                ctx->plane_order_host.size() * sizeof(int32_t), hipMemcpyHostToDevice, stream));
         BYZ_HIP(hipStreamSynchronize(stream));
         ctx->plane_order_T = t128;
-        ctx->plane_order_share = share_count * 65536 + share_index;
+        ctx->plane_order_share = order_key;
     }
     const int64_t n_tiles = static_cast<int64_t>(ctx->plane_order_host.size() / 2);
     if (owned_host != nullptr)
@@ -1359,11 +1411,9 @@ int launch_gram_planes(byz_ctx* ctx, const float* G, int64_t n_rows, int64_t n_c
     int* tickets = ctx->gram_tickets.as<int>();
     u32x4* planes = ctx->gram_planes.as<u32x4>();
     typedef void (*kernel_t)(const u32x4*, int64_t, const double*, int64_t, double*, int, const int2*, int, int*, int, int,
-                             int, int, int32_t*, float*, float*, int, int);
+                             int, int, int32_t*, float*, float*, int, int, int);
     // BYZ_GRAM_DEFER=0: round 4's in-kernel slab update (the same-box A/B and the bitwise comparison of the tests)
     bool defer = f16 && env_int("BYZ_GRAM_DEFER", 1) != 0;
-    // BYZ_GRAM_MFMA=32: the f16x2 tile kernel on v_mfma_f32_32x32x16_f16 (rounds 2-5; the same-box A/B) instead of 16x16x32
-    const bool shape16 = f16 && env_int("BYZ_GRAM_MFMA", 16) != 32;
     kernel_t kernel = !f16 ? &gram_planes_kernel<3, 4, 0>
                       : shape16 ? (defer ? &gram_planes16_kernel<6, true> : &gram_planes16_kernel<6, false>)
                                 : (defer ? &gram_planes_kernel<2, 6, 0, 2, true> : &gram_planes_kernel<2, 6, 0>);
@@ -1449,9 +1499,7 @@ int launch_gram_planes(byz_ctx* ctx, const float* G, int64_t n_rows, int64_t n_c
             }
             BYZ_TRY(check_launch("plane_split_kernel"));
         }
-        BYZ_HIP(hipMemsetAsync(tickets, 0, static_cast<size_t>(n_tiles + 8) * sizeof(int), stream));
         {
-            KernelTimer t(ctx, BYZ_K_GRAM, stream);
             // chunks per workgroup (DEFER only): BYZ_GRAM_KSPAN as given, else kDefaultSpan -- but never so many that the launch
             // has fewer than ~8 workgroups per CU (the tail of the last round would cost more than the turnover saves)
             int64_t kspan = 1;
@@ -1463,7 +1511,23 @@ int launch_gram_planes(byz_ctx* ctx, const float* G, int64_t n_rows, int64_t n_c
                     while (kspan > 1 && 8 * per_xcd * ceil_div(n_chunks, kspan) < static_cast<int64_t>(ctx->num_cus) * 8) kspan /= 2;
                 }
             }
-            const int64_t grid = 8 * per_xcd * ceil_div(n_chunks, kspan);
+            // (order_mode 1: whole rounds of `map_round` units, dealt to the XCDs in turn)
+            const int run = order_mode == 1 ? (round_size > 0 ? round_size : ctx->num_cus / 8) : 0;
+            const int64_t n_units = n_tiles * ceil_div(n_chunks, kspan);
+            const int64_t rounds_per_xcd = run > 0 ? ceil_div(ceil_div(n_units, run), 8) : 0;
+            const int64_t grid = run > 0 ? 8 * run * rounds_per_xcd : 8 * per_xcd * ceil_div(n_chunks, kspan);
+            // BYZ_GRAM_CLAIM=0: the XCDs take the runs in turn; default: every round of an XCD CLAIMS the next run from one counter.
+            // The XCDs of one chip do not run at one speed: dealt in turn, the launch waits for its slowest XCD with the others
+            // idle (same box, N = 4000: 41.4 -> 39.1 ms per launch; N = 10,000: 100.8 -> 98.6; profiles/r06w_*)
+            const bool claim = run > 0 && env_int("BYZ_GRAM_CLAIM", 1) != 0;
+            const int map_round = claim ? -run : run;
+            // tickets: [n_tiles] chunk order of a tile (in-kernel update), [8] workgroups done per XCD, [1] runs claimed,
+            // [8][rounds_per_xcd] the run each round of an XCD claimed (+ 1; 0: not yet)
+            const size_t ticket_ints = static_cast<size_t>(n_tiles + 9 + 8 * rounds_per_xcd);
+            BYZ_TRY(ctx->gram_tickets.ensure(ticket_ints * sizeof(int)));
+            tickets = ctx->gram_tickets.as<int>();
+            BYZ_HIP(hipMemsetAsync(tickets, 0, ticket_ints * sizeof(int), stream));
+            KernelTimer t(ctx, BYZ_K_GRAM, stream);
             if (grid > 0x7fffffff) {
                 set_error("gram: grid too large");
                 return BYZ_E_UNSUPPORTED;
@@ -1471,7 +1535,8 @@ int launch_gram_planes(byz_ctx* ctx, const float* G, int64_t n_rows, int64_t n_c
             kernel<<<static_cast<unsigned>(grid), threads, lds_bytes, stream>>>(
                 planes, n_steps, unscale, rows_pad, slabs, static_cast<int>(n_tiles), ctx->plane_order.as<int2>(),
                 static_cast<int>(n_chunks), tickets, round_size, static_cast<int>(t128), sc > 0 ? 1 : 0,
-                n_blocks32, device_status_word(ctx), chunk_sums, ragged_sums, static_cast<int>(kspan), env_int("BYZ_GRAM_PIN", 1));
+                n_blocks32, device_status_word(ctx), chunk_sums, ragged_sums, static_cast<int>(kspan), env_int("BYZ_GRAM_PIN", 1),
+                map_round);
             BYZ_TRY(check_launch("gram_planes_kernel"));
         }
         if (defer) {

@@ -152,6 +152,24 @@ def test_gram_with_skipped_blocks_is_bitwise_the_slab_granular_gram(eng, monkeyp
         monkeypatch.delenv('BYZ_GRAM_PLANE_MB', raising=False)
         assert torch.equal(spanned, lean), (span, plane_mb, float((spanned - lean).abs().max()))
     monkeypatch.delenv('BYZ_GRAM_KSPAN')
+    # round 6: the tile list in bands with rounds of consecutive (chunk, tile) units dealt to the XCDs in turn (the default)
+    # against rounds 2-5's super-block list with a contiguous share per XCD (BYZ_GRAM_ORDER=0) -- which workgroup computes which
+    # (tile, chunk) changes, nothing else: bitwise; also with spans, no round gate, the in-kernel update and several super-chunks
+    # (BYZ_GRAM_CLAIM=0: the XCDs take their runs of units in turn instead of claiming them from one counter)
+    for env in ({}, {'BYZ_GRAM_KSPAN': '3'}, {'BYZ_GRAM_ROUND': '0'}, {'BYZ_GRAM_DEFER': '0', 'BYZ_GRAM_PLANE_MB': '300'},
+                {'BYZ_GRAM_ROUND': '5', 'BYZ_GRAM_PLANE_MB': '300'}, {'BYZ_GRAM_CLAIM': '0'},
+                {'BYZ_GRAM_CLAIM': '0', 'BYZ_GRAM_DEFER': '0', 'BYZ_GRAM_PLANE_MB': '300'},
+                {'BYZ_GRAM_CLAIM': '0', 'BYZ_GRAM_ROUND': '0', 'BYZ_GRAM_KSPAN': '2'}):
+        for order in ('0', '1'):
+            monkeypatch.setenv('BYZ_GRAM_ORDER', order)
+            for k, v in env.items():
+                monkeypatch.setenv(k, v)
+            ordered = eng.gram(g).clone()
+            eng.check()
+            for k in env:
+                monkeypatch.delenv(k)
+            assert torch.equal(ordered, lean), (order, env, float((ordered - lean).abs().max()))
+    monkeypatch.delenv('BYZ_GRAM_ORDER')
     # the last rows and the diagonal against fp64
     rows = torch.tensor([0, 1, 31, 32, 63, 64, 127, 128, n - 33, n - 32, n - 2, n - 1], device='cuda')
     want = g[rows].double() @ g.double().T
