@@ -8,7 +8,8 @@ from attacking_federate_learning_amd.engine import Engine
 eng = Engine(0)
 var = sys.argv[1]
 values = sys.argv[2].split(',')
-shapes = [(1000, 1 << 18, 200), (2080, 1 << 17, 1920), (5200, 1 << 16, 4800)]
+scale = int(os.environ.get('TM_AB_SCALE', '1'))   # (wider matrices: more tiles per launch)
+shapes = [(1000, scale << 18, 200), (2080, scale << 17, 1920), (5200, scale << 16, 4800)]
 for rows, cols, corrupted in shapes:
     buf = eng.to_device(np.random.default_rng(rows).standard_normal((rows, cols), dtype=np.float32))
     res = {v: [] for v in values}
