@@ -689,10 +689,13 @@ __device__ unsigned long long g_rescore_clock[14];
 // this row that hold nothing but marks.  The winners of the picks so far are every central row's NEAREST neighbours, so the
 // front of a contender's table fills with marks as the loop goes (up to ten batches at N = 10,000) -- and a mark never
 // becomes live again, so a batch found empty once is skipped, unfetched, by every later re-score of the row (round 6).
-template <bool CLOCKS>
+// EXTRA (the speculative loop, bulyan_spec_kernel): `egone` is a bitmap over the POSITIONS of this row's table (LDS, the wave's own;
+// bit p set: the entry at position p is gone although the table does not say so yet -- the winners of the earlier picks of a batch that
+// is still being verified).  A lane's eight entries start at a multiple of eight: one byte of it.
+template <bool CLOCKS, bool EXTRA = false>
 __device__ __forceinline__ float reference_score_marked(const float* sorted_val, int n, int u, int take, int lane,
                                                         float* __restrict__ head, int head_chunks, bool& ok,
-                                                        uint16_t* __restrict__ front) {
+                                                        uint16_t* __restrict__ front, const uint8_t* __restrict__ egone = nullptr) {
     constexpr bool clocks = CLOCKS;   // (development: a compile-time switch -- what is compiled into this loop costs even when it never runs)
     typedef uint32_t u32x4u __attribute__((ext_vector_type(4), aligned(4)));
     typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -720,11 +723,17 @@ __device__ __forceinline__ float reference_score_marked(const float* sorted_val,
         uint32_t xb[8];
         uint32_t cnt = 0, top = 0;
         const int inside = n - r0 - 8 * lane;   // entries of this lane that lie inside the row (<= 0 .. >= 8)
+        uint32_t eb = 0, lm = 0;                // (EXTRA) this lane's byte of the bitmap; its live entries
+        if (EXTRA) {
+            eb = inside > 0 ? egone[(r0 >> 3) + lane] : 0u;
+            if (__ballot(eb != 0u) != 0ull) in_front = false;   // (a batch that is empty only on the bitmap's word is not remembered as empty)
+        }
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            const bool live = j < inside && b.x[j] != kGoneBits;
+            const bool live = j < inside && b.x[j] != kGoneBits && !(EXTRA && ((eb >> j) & 1u) != 0u);
             xb[j] = live ? b.x[j] : 0u;
             cnt += live ? 1u : 0u;
+            if (EXTRA) lm |= (live ? 1u : 0u) << j;
             top = xb[j] > top ? xb[j] : top;
         }
         negative = negative || top > kGoneBits;   // a sign bit on a live entry
@@ -742,7 +751,7 @@ __device__ __forceinline__ float reference_score_marked(const float* sorted_val,
             int room = take - got - static_cast<int>(incl - cnt);   // live entries of this lane that still belong to it
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                if (xb[j] != 0u || (j < inside && b.x[j] == 0u)) {   // live (a live +0.0 counts)
+                if (EXTRA ? ((lm >> j) & 1u) != 0u : (xb[j] != 0u || (j < inside && b.x[j] == 0u))) {   // live (a live +0.0 counts)
                     if (room <= 0) xb[j] = 0u;   // past the prefix: + 0.0 (exact)
                     --room;
                 }
@@ -1077,6 +1086,402 @@ __global__ __launch_bounds__(kGridThreads) void bulyan_grid_kernel(
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------
+// The same loop, SPECULATIVE (round 6).  bulyan_grid_kernel spends two thirds of a contested pick waiting for ONE wave per
+// contender to form the reference's sequential fp32 sum, and most picks are contested -- yet the exact (fp64) minimum is the
+// reference's winner in all but a handful of picks per loop.  So a BATCH of up to 16 picks is decided optimistically: a contested
+// pick takes the row with the smallest exact score at once and only remembers who its contenders were.  Behind the batch every
+// (contested pick, contender) pair is scored the reference's way IN PARALLEL -- all four waves of every workgroup, pairs of different
+// picks side by side -- in the state of ITS pick: the table of ascending values carries the marks of the picks before the batch, a
+// bitmap over the row's positions (the wave's own, in LDS) those of the batch's earlier winners.  One exchange carries the
+// workgroups' best contender of every contested pick; every workgroup finds the reference's winner of each and the first pick
+// whose optimistic winner was not it.  None: the batch is committed (selection, marks).  Otherwise every row goes back to its
+// snapshot of the batch's start, replays the picks in front of the wrong one (no decisions: the O(1) updates), takes the
+// reference's winner there, commits that much, and the next batch starts behind it.  Every contested pick that is committed was
+// decided by the reference's arithmetic in the reference's state, every other one by the proof of the band: the selection is
+// bulyan_grid_kernel's, pick for pick.
+constexpr int kSpecMax = 16;                       // picks per batch at most
+constexpr int kSpecTable = 1024;                   // (pick, twin class) -> leader, hashed
+
+struct SpecVerdict {
+    int k_bad;      // first pick of the batch whose optimistic winner is not the reference's (-1: none)
+    int winner;     // the reference's winner there (-1: no row scores below 1e20)
+    int timeout;
+};
+
+__global__ __launch_bounds__(kGridThreads) void bulyan_spec_kernel(
+    const float* __restrict__ dist, int n, int theta, int drop, int users_count, int corrupted,
+    const uint16_t* __restrict__ sorted_idx, const uint16_t* __restrict__ rank_t, float* sorted_val,
+    const double* __restrict__ row_total, const double* __restrict__ row_top, const int32_t* __restrict__ cls,
+    unsigned long long* __restrict__ xchg, float band_scale, int32_t* __restrict__ selection,
+    int32_t* __restrict__ status, int32_t* __restrict__ rescored, int head_chunks, int skip_front, int batch_picks,
+    int32_t* __restrict__ spec_stats) {
+    __shared__ __attribute__((aligned(16))) float rescore_stage[kGridThreads / 64][512];
+    __shared__ Candidate slots[kGridThreads / 64];
+    __shared__ double second_slots[kGridThreads / 64];
+    __shared__ uint32_t removed[kMaxSelectRows / 32];
+    __shared__ __attribute__((aligned(16))) uint32_t egone[kGridThreads / 64][kMaxSelectRows / 32];   // per wave: see reference_score_marked<EXTRA>
+    __shared__ GridDecision decision;
+    __shared__ int decision_contested;
+    __shared__ unsigned long long leader_of[kSpecTable];
+    __shared__ uint16_t items[kGridThreads * kSpecMax];
+    __shared__ int n_items;
+    __shared__ Candidate wave_bests[kGridThreads / 64][kSpecMax];
+    __shared__ int winners[kSpecMax];
+    __shared__ SpecVerdict verdict;
+    __shared__ int true_row[kSpecMax];
+    __shared__ uint16_t front_batches[kGridThreads];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n_wgs = gridDim.x, wg = blockIdx.x;
+    const int u = wg * kGridThreads + tid;
+    for (int i = tid; i < kMaxSelectRows / 32; i += kGridThreads) {
+        removed[i] = 0u;
+#pragma unroll
+        for (int w = 0; w < kGridThreads / 64; ++w) egone[w][i] = 0u;
+    }
+    front_batches[tid] = 0;
+
+    bool alive = u < n;
+    double tot = alive ? row_total[u] : 0.0;
+    double top = (alive && drop > 0) ? row_top[u] : 0.0;
+    int bad = alive ? static_cast<int>(row_top[n + u]) : 0;   // live non-finite distances of this row
+    int ptr = n - 1 - drop;
+    const int my_class = alive ? cls[u] : 0;
+    const int my_pos = visit_position(u);
+    int n_rescored = 0, n_batches = 0, n_rollbacks = 0, n_wasted = 0;
+    if (alive) sorted_val[static_cast<int64_t>(u) * n + rank_t[static_cast<int64_t>(u) * n + u]] = __uint_as_float(kGoneBits);
+    auto take_at = [&](int t) __attribute__((always_inline)) -> int {
+        const int live_entries = n - t - 1;
+        const int keep = users_count - t - corrupted;
+        return keep >= 0 ? (keep < live_entries ? keep : live_entries) : (live_entries + keep > 0 ? live_entries + keep : 0);
+    };
+    __syncthreads();
+
+    // exchange slots: [parity][kind A, B, (R of bulyan_grid_kernel: unused)][workgroup], then [parity][pick of the batch][workgroup]
+    auto slot = [&](int parity, int kind) { return xchg + (parity * 3 + kind) * kGridMaxWgs; };
+    auto batch_slot = [&](int parity, int k) { return xchg + (6 + parity * kSpecMax + k) * kGridMaxWgs; };
+    const unsigned long long none_a = (static_cast<unsigned long long>(kInfBits) << 32) | (static_cast<unsigned long long>(kNoRow) << 18);
+
+    // step 4 of bulyan_grid_kernel without the mark: the winner leaves every row's sums
+    auto remove_winner = [&](int w) __attribute__((always_inline)) {
+        if (tid == 0) removed[w >> 5] |= 1u << (w & 31);
+        __syncthreads();
+        if (alive) {
+            if (u == w) {
+                alive = false;
+            } else {
+                const float dwf = dist[static_cast<int64_t>(w) * n + u];   // symmetric: d[w][u] == d[u][w]
+                const bool dw_finite = __builtin_fabsf(dwf) <= 3.4028234663852886e38f;
+                const double dw = dw_finite ? static_cast<double>(dwf) : 0.0;
+                if (!dw_finite) --bad;
+                const int r = rank_t[static_cast<int64_t>(w) * n + u];                          // rank of column w inside row u
+                tot -= dw;
+                if (drop > 0 && r >= ptr) {
+                    top -= dw;
+                    int p = ptr - 1;
+                    const uint16_t* order = sorted_idx + static_cast<int64_t>(u) * n;
+                    while (p >= 0) {
+                        const int col = order[p];
+                        if (!((removed[col >> 5] >> (col & 31)) & 1u)) break;
+                        --p;
+                    }
+                    if (p >= 0) {
+                        const float joins = dist[static_cast<int64_t>(u) * n + order[p]];
+                        if (__builtin_fabsf(joins) <= 3.4028234663852886e38f) top += static_cast<double>(joins);
+                    }
+                    ptr = p;
+                }
+            }
+        }
+    };
+
+    int result = (n < 2 && theta > 0) ? 1 : 0;
+    int t = 0;
+    uint32_t seq = 0;        // decisions exchanged so far, discarded ones included: what the granules' tags count
+    uint32_t batch_seq = 0;  // batches verified so far
+    while (t < theta && result == 0) {
+        // ---- the batch's start: every row's snapshot
+        const bool s_alive = alive;
+        const double s_tot = tot, s_top = top;
+        const int s_bad = bad, s_ptr = ptr;
+        const int t0 = t;
+        const int kmax = theta - t0 < batch_picks ? theta - t0 : batch_picks;
+        uint32_t cmask = 0;       // picks of this batch at which this row is a contender
+        uint32_t contested = 0;   // (uniform) picks of this batch that more than one twin class contends for
+        int n_done = 0, pending = 0;
+        for (int k = 0; k < kmax; ++k, ++seq) {
+            const int tt = t0 + k;
+            const uint32_t tag = ((seq >> 1) & 7u) + 1u;
+            const uint32_t tag18 = (seq + 1u) & 0x3ffffu;
+            const int parity = static_cast<int>(seq & 1u);
+            const int take = take_at(tt);
+            // ---- 1. the workgroup's best row, and its best score outside that row's twin class (bulyan_grid_kernel)
+            const double score = tot - top;
+            const bool candidate = alive && bad <= drop && score < static_cast<double>(kKrumInit);   // false for NaN
+            Candidate c{static_cast<double>(kKrumInit), 0x7fffffff, -1, -1};
+            if (candidate) c = Candidate{score, my_pos, u, my_class};
+            const Candidate best = block_best(c, slots);
+            const int best_class = best.cls;
+            double second = (candidate && my_class != best_class) ? score : __builtin_inf();
+            second = wave_min_d(second);
+            if (lane == 0) second_slots[wave] = second;
+            __syncthreads();
+            if (wave == 0) {
+                // ---- 2. publish, gather, decide
+                double sec = second_slots[0];
+#pragma unroll
+                for (int w = 1; w < kGridThreads / 64; ++w) sec = fmin(sec, second_slots[w]);
+                const float a_lb = best.row >= 0 ? float_below(best.score) : __builtin_inff();
+                const float b_lb = float_below(sec);
+                unsigned long long ga = best.row >= 0
+                    ? (static_cast<unsigned long long>(__float_as_uint(a_lb)) << 32) | (static_cast<unsigned long long>(best.row) << 18) |
+                      (static_cast<unsigned long long>(best_class) << 4)
+                    : none_a;
+                unsigned long long gb = static_cast<unsigned long long>(__float_as_uint(b_lb)) << 32;
+                bool ok = true;
+                if (n_wgs > 1) {
+                    if (lane == 0) {
+                        granule_store(slot(parity, 0) + wg, ga | tag);
+                        granule_store(slot(parity, 1) + wg, gb | tag18);
+                    }
+                    unsigned long long va = none_a, vb = static_cast<unsigned long long>(kInfBits) << 32;
+                    ok = gather_granule_pair(slot(parity, 0), slot(parity, 1), n_wgs, tag, tag18, lane, va, vb);
+                    ga = va;
+                    gb = vb;
+                } else if (lane != 0) {
+                    ga = none_a;
+                    gb = static_cast<unsigned long long>(kInfBits) << 32;
+                }
+                const float a = __uint_as_float(static_cast<uint32_t>(ga >> 32));
+                const float b = __uint_as_float(static_cast<uint32_t>(gb >> 32));
+                const int a_row = static_cast<int>((ga >> 18) & 0x3fffu);
+                const int a_cls = static_cast<int>((ga >> 4) & 0x3fffu);
+                const float m1 = wave_min_f(a);
+                GridDecision d{0, -1, 0.0};
+                int is_contested = 0;
+                if (!ok) {
+                    d.mode = 3;
+                } else if (!(m1 < __builtin_inff())) {
+                    d.mode = 2;
+                } else {
+                    const double u24 = 5.9604644775390625e-08;
+                    const double band = (band_scale >= 0.0f ? static_cast<double>(band_scale) * 1.1 * u24 * static_cast<double>(take + 1)
+                                                            : -static_cast<double>(band_scale) * u24 * sqrt(static_cast<double>(take + 1))) + 1e-9;
+                    const double ub = double_above(m1);
+                    const double thr = ub + fabs(ub) * (take <= 1 ? 1e-12 : band);
+                    d.threshold = thr;
+                    const bool in_a = static_cast<double>(a) <= thr;
+                    const bool in_b = static_cast<double>(b) <= thr;
+                    const unsigned long long first = __ballot(a == m1);
+                    const int lead_cls = __builtin_amdgcn_readlane(a_cls, __builtin_ctzll(first));
+                    const bool one_class = __ballot(in_b) == 0ull && __ballot(in_a && a_cls != lead_cls) == 0ull;
+                    // one class in the band: its earliest member, proven.  Otherwise, OPTIMISTICALLY, the smallest exact score
+                    // (the earliest of the workgroups whose best rounds down to the same float): verified behind the batch
+                    const int pos = wave_min_i((one_class ? in_a : a == m1) ? visit_position(a_row) : 0x7fffffff);
+                    d.winner = pos == 0 ? 1 : (pos == 1 ? 0 : pos);   // visit_position is its own inverse
+                    is_contested = one_class ? 0 : 1;
+                }
+                if (lane == 0) {
+                    decision = d;
+                    decision_contested = is_contested;
+                }
+            }
+            __syncthreads();
+            const GridDecision d = decision;
+            if (d.mode == 3) {
+                result = 2;
+                break;
+            }
+            if (d.mode == 2) {   // no row scores below 1e20 at this pick -- if the picks before it stand
+                pending = 1;
+                ++seq;   // (this decision's granules are in the slots: the next decision must not take them for its own)
+                break;
+            }
+            if (decision_contested != 0) {
+                contested |= 1u << k;
+                if (candidate && score <= d.threshold) cmask |= 1u << k;
+            }
+            if (tid == 0) winners[k] = d.winner;
+            remove_winner(d.winner);
+            ++n_done;
+        }
+        if (result != 0) break;
+        contested &= (1u << n_done) - 1u;
+        cmask &= contested;
+
+        // ---- 3. every (contested pick, contender) pair of the batch in the reference's arithmetic, in the state of its pick
+        int k_bad = -1, w_true = -1;
+        if (contested != 0u) {
+            for (int i = tid; i < kSpecTable; i += kGridThreads) leader_of[i] = ~0ull;
+            if (tid == 0) n_items = 0;
+            if (tid < (kGridThreads / 64) * kSpecMax)
+                (&wave_bests[0][0])[tid] = Candidate{static_cast<double>(kKrumInit), 0x7fffffff, -1, -1};
+            __syncthreads();
+            // one contender per (pick, twin class) and workgroup: the class's earliest local member (twins score alike)
+            for (uint32_t m = cmask; m != 0u; m &= m - 1u) {
+                const int k = __builtin_ctz(m);
+                const unsigned long long key = (static_cast<unsigned long long>(my_pos) << 32) | (static_cast<uint32_t>(k) << 16) | static_cast<uint32_t>(my_class);
+                atomicMin(&leader_of[(static_cast<uint32_t>(my_class) * 16u + static_cast<uint32_t>(k)) & (kSpecTable - 1)], key);
+            }
+            __syncthreads();
+            for (uint32_t m = cmask; m != 0u; m &= m - 1u) {
+                const int k = __builtin_ctz(m);
+                const uint32_t low = (static_cast<uint32_t>(k) << 16) | static_cast<uint32_t>(my_class);
+                const unsigned long long key = (static_cast<unsigned long long>(my_pos) << 32) | low;
+                const unsigned long long held = leader_of[(static_cast<uint32_t>(my_class) * 16u + static_cast<uint32_t>(k)) & (kSpecTable - 1)];
+                // a (pick, class) that lost its slot to another one scores every member: redundant, never wrong
+                if (static_cast<uint32_t>(held) != low || held == key) items[atomicAdd(&n_items, 1)] = static_cast<uint16_t>((k << 8) | tid);
+            }
+            __syncthreads();
+            const int n_it = n_items;
+            uint32_t* const my_bits = egone[wave];
+            for (int i = wave; i < n_it; i += kGridThreads / 64) {
+                const int it = __builtin_amdgcn_readfirstlane(static_cast<int>(items[i]));
+                const int k = it >> 8;
+                const int lt = it & 255;
+                const int row = wg * kGridThreads + lt;
+                // the batch's earlier winners are gone from this row in the state of pick k: their positions, on the wave's bitmap
+                int pos_gone = -1;
+                if (lane < k) {
+                    pos_gone = rank_t[static_cast<int64_t>(winners[lane]) * n + row];
+                    atomicOr(&my_bits[pos_gone >> 5], 1u << (pos_gone & 31));
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                bool done = false;
+                float s32 = reference_score_marked<false, true>(sorted_val, n, row, take_at(t0 + k), lane, rescore_stage[wave], head_chunks, done,
+                                                                skip_front != 0 ? &front_batches[lt] : nullptr,
+                                                                reinterpret_cast<const uint8_t*>(my_bits));
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                __builtin_amdgcn_wave_barrier();
+                if (pos_gone >= 0) my_bits[pos_gone >> 5] = 0u;
+                if (!done) {
+                    // (a sign bit on a live entry: the literal chain, with liveness from a bitmap of the columns in the state of pick k)
+                    for (int j = lane; j < kMaxSelectRows / 32; j += 64) my_bits[j] = removed[j];
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                    __builtin_amdgcn_wave_barrier();
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                    if (lane >= k && lane < n_done) {
+                        const int w = winners[lane];
+                        atomicAnd(&my_bits[w >> 5], ~(1u << (w & 31)));
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                    __builtin_amdgcn_wave_barrier();
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                    s32 = reference_score_plain(sorted_val, sorted_idx, my_bits, n, row, take_at(t0 + k), lane, rescore_stage[wave]);
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                    __builtin_amdgcn_wave_barrier();
+                    for (int j = lane; j < kMaxSelectRows / 32; j += 64) my_bits[j] = 0u;
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                __builtin_amdgcn_wave_barrier();
+                if (s32 < kKrumInit && lane == 0) {
+                    const Candidate o{static_cast<double>(s32), visit_position(row), row, 0};
+                    if (better(o, wave_bests[wave][k])) wave_bests[wave][k] = o;
+                }
+            }
+            __syncthreads();
+            {
+                const uint32_t btag = (batch_seq + 1u) & 0x3ffffu;
+                const int bpar = static_cast<int>(batch_seq & 1u);
+                if (wave == 0) {
+                    if (lane == 0) n_rescored += n_it;
+                    // lane k: the workgroup's best contender of pick k, published for everybody
+                    const bool mine_k = lane < n_done && ((contested >> lane) & 1u) != 0u;
+                    Candidate local{static_cast<double>(kKrumInit), 0x7fffffff, -1, -1};
+                    if (mine_k) {
+#pragma unroll
+                        for (int w = 0; w < kGridThreads / 64; ++w)
+                            if (better(wave_bests[w][lane], local)) local = wave_bests[w][lane];
+                    }
+                    if (n_wgs > 1) {
+                        const unsigned long long gr = local.row >= 0
+                            ? (static_cast<unsigned long long>(__float_as_uint(static_cast<float>(local.score))) << 32) |
+                              (static_cast<unsigned long long>(local.row) << 18)
+                            : none_a;
+                        if (mine_k) granule_store(batch_slot(bpar, lane) + wg, gr | btag);
+                    } else if (mine_k) {
+                        true_row[lane] = local.row;
+                    }
+                }
+                if (n_wgs > 1) {
+                    // wave w gathers the picks w, w + 4, ...: the reference's winner of each (-1: none below 1e20; -2: timed out)
+                    for (int k = wave; k < n_done; k += kGridThreads / 64) {
+                        if (((contested >> k) & 1u) == 0u) continue;
+                        unsigned long long mine = none_a;
+                        const bool ok = gather_granules(batch_slot(bpar, k), n_wgs, 0x3ffffu, btag, lane, none_a, mine);
+                        const int r_row = static_cast<int>((mine >> 18) & 0x3fffu);
+                        Candidate g{static_cast<double>(kKrumInit), 0x7fffffff, -1, -1};
+                        if (r_row != static_cast<int>(kNoRow))
+                            g = Candidate{static_cast<double>(__uint_as_float(static_cast<uint32_t>(mine >> 32))), visit_position(r_row), r_row, 0};
+                        g = wave_best(g);
+                        if (lane == 0) true_row[k] = ok ? g.row : -2;
+                    }
+                }
+                __syncthreads();
+                if (tid == 0) {
+                    SpecVerdict v{-1, -1, 0};
+                    for (int k = 0; k < n_done && v.k_bad < 0 && v.timeout == 0; ++k) {
+                        if (((contested >> k) & 1u) == 0u) continue;
+                        if (true_row[k] == -2) {
+                            v.timeout = 1;
+                        } else if (true_row[k] != winners[k]) {
+                            v.k_bad = k;
+                            v.winner = true_row[k];
+                        }
+                    }
+                    verdict = v;
+                }
+                __syncthreads();
+            }
+            ++batch_seq;
+            if (verdict.timeout != 0) {
+                result = 2;
+                break;
+            }
+            k_bad = verdict.k_bad;
+            w_true = verdict.winner;
+        }
+        if (k_bad >= 0) {
+            // ---- back to the snapshot; the picks in front of the wrong one again (their winners stand), then the reference's winner
+            ++n_rollbacks;
+            n_wasted += n_done - k_bad;
+            alive = s_alive, tot = s_tot, top = s_top, bad = s_bad, ptr = s_ptr;
+            __syncthreads();
+            if (tid == 0) {
+                for (int k = 0; k < n_done; ++k) removed[winners[k] >> 5] &= ~(1u << (winners[k] & 31));
+                if (w_true >= 0) winners[k_bad] = w_true;
+            }
+            __syncthreads();
+            n_done = w_true >= 0 ? k_bad + 1 : k_bad;
+            pending = w_true >= 0 ? 0 : 1;
+            for (int k = 0; k < n_done; ++k) remove_winner(winners[k]);
+        }
+        // ---- commit: the selection, and the winners' marks in the rows that go on
+        __syncthreads();
+        for (int k = 0; k < n_done; ++k) {
+            const int w = winners[k];
+            if (wg == 0 && tid == 0) selection[t0 + k] = w;
+            if (alive) sorted_val[static_cast<int64_t>(u) * n + rank_t[static_cast<int64_t>(w) * n + u]] = __uint_as_float(kGoneBits);
+        }
+        t = t0 + n_done;
+        ++n_batches;
+        if (pending != 0) result = 1;
+        __syncthreads();   // (winners[] is rewritten by the next batch)
+    }
+    if (tid == 0) {
+        if (result != 0) atomicMax(status, result);
+        if (n_rescored) atomicAdd(rescored, n_rescored);
+        if (wg == 0 && spec_stats != nullptr) {
+            spec_stats[0] = n_batches;
+            spec_stats[1] = n_rollbacks;
+            spec_stats[2] = n_wasted;
+        }
+    }
+}
+
 }  // namespace
 
 int64_t select_max_rows() { return kMaxSelectRows; }
@@ -1129,7 +1534,9 @@ int launch_bulyan_loop(byz_ctx* ctx, const float* dist, int64_t n, int64_t theta
     BYZ_REQUIRE(dist && selection_dev && status_dev && n > 0 && theta >= 0 && theta <= n,
                 "bulyan loop: bad arguments (n=%lld theta=%lld)", (long long)n, (long long)theta);
     BYZ_TRY(ctx->twin_class.ensure(static_cast<size_t>(2 * n) * sizeof(int32_t)));
-    BYZ_TRY(ctx->xchg.ensure(static_cast<size_t>(2 * 3 * kGridMaxWgs) * sizeof(unsigned long long)));
+    // granules: [2][A, B, R][64 workgroups], then the speculative loop's [2][16 picks of a batch][64], then its three counters
+    constexpr size_t kGranules = static_cast<size_t>(2 * 3 + 2 * kSpecMax) * kGridMaxWgs;
+    BYZ_TRY(ctx->xchg.ensure((kGranules + 2) * sizeof(unsigned long long)));
     int32_t* cls_tmp = ctx->twin_class.as<int32_t>();
     int32_t* cls = cls_tmp + n;
     // which arithmetic decides a pick whose contenders lie within rounding of each other (see bulyan_grid_kernel):
@@ -1156,7 +1563,7 @@ int launch_bulyan_loop(byz_ctx* ctx, const float* dist, int64_t n, int64_t theta
         const unsigned long long zero[14] = {0};
         BYZ_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_rescore_clock), zero, sizeof(zero)));
     }
-    BYZ_HIP(hipMemsetAsync(ctx->xchg.ptr, 0, static_cast<size_t>(2 * 3 * kGridMaxWgs) * sizeof(unsigned long long), stream));
+    BYZ_HIP(hipMemsetAsync(ctx->xchg.ptr, 0, (kGranules + 2) * sizeof(unsigned long long), stream));
     BYZ_HIP(hipMemsetAsync(status_dev, 0, 3 * sizeof(int32_t), stream));   // status, rows re-scored, (unused)
     KernelTimer t(ctx, BYZ_K_BULYAN_LOOP, stream);
     twin_class_kernel<<<static_cast<unsigned>(ceil_div(n, 4)), 256, 0, stream>>>(dist, (int)n, cls_tmp);
@@ -1164,6 +1571,29 @@ int launch_bulyan_loop(byz_ctx* ctx, const float* dist, int64_t n, int64_t theta
     twin_class_fix_kernel<<<static_cast<unsigned>(ceil_div(n, 256)), 256, 0, stream>>>(cls_tmp, (int)n, cls);
     BYZ_TRY(check_launch("twin_class_fix_kernel"));
     const unsigned n_wgs = static_cast<unsigned>(ceil_div(n, kGridThreads));   // <= 64: all resident, they wait for each other
+    // BYZ_BULYAN_BATCH=<k>: picks decided optimistically before their contested ones are verified together (bulyan_spec_kernel;
+    // default 16, at most 16); 0: bulyan_grid_kernel, every contested pick re-scored before the next one (rounds 2-5; also taken for
+    // BYZ_BULYAN_RESCORE=plain and BYZ_BULYAN_CLOCKS).  The same selection, pick for pick.
+    int batch = 16;
+    if (const char* e = std::getenv("BYZ_BULYAN_BATCH")) batch = std::atoi(e);
+    if (batch > kSpecMax) batch = kSpecMax;
+    if (batch >= 1 && rescore_mode == 1 && !clocks) {
+        int32_t* stats = reinterpret_cast<int32_t*>(ctx->xchg.as<unsigned long long>() + kGranules);
+        bulyan_spec_kernel<<<n_wgs, kGridThreads, 0, stream>>>(
+            dist, (int)n, (int)theta, (int)drop_count, (int)users_count, (int)corrupted, ctx->sorted_idx.as<uint16_t>(),
+            ctx->rank_t.as<uint16_t>(), ctx->sorted_val.as<float>(), ctx->row_total.as<double>(), ctx->row_top.as<double>(), cls,
+            ctx->xchg.as<unsigned long long>(), band_scale, selection_dev, status_dev, status_dev + 1, head_chunks, skip_front, batch, stats);
+        BYZ_TRY(check_launch("bulyan_spec_kernel"));
+        if (const char* e = std::getenv("BYZ_BULYAN_STATS"); e != nullptr && std::atoi(e) != 0) {
+            int32_t host[4] = {0, 0, 0, 0};
+            BYZ_HIP(hipStreamSynchronize(stream));
+            BYZ_HIP(hipMemcpy(host, stats, 3 * sizeof(int32_t), hipMemcpyDeviceToHost));
+            BYZ_HIP(hipMemcpy(host + 3, status_dev + 1, sizeof(int32_t), hipMemcpyDeviceToHost));
+            std::fprintf(stderr, "bulyan (speculative, batches of %d): %d picks in %d batches, %d rolled back (%d picks decided again), %d re-scores\n",
+                         batch, (int)theta, host[0], host[1], host[2], host[3]);
+        }
+        return BYZ_OK;
+    }
     auto* kernel = clocks ? &bulyan_grid_kernel<true> : &bulyan_grid_kernel<false>;
     kernel<<<n_wgs, kGridThreads, 0, stream>>>(
         dist, (int)n, (int)theta, (int)drop_count, (int)users_count, (int)corrupted, ctx->sorted_idx.as<uint16_t>(),
