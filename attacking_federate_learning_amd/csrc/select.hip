@@ -1101,7 +1101,7 @@ __global__ __launch_bounds__(kGridThreads) void bulyan_grid_kernel(
 // reference's winner there, commits that much, and the next batch starts behind it.  Every contested pick that is committed was
 // decided by the reference's arithmetic in the reference's state, every other one by the proof of the band: the selection is
 // bulyan_grid_kernel's, pick for pick.
-constexpr int kSpecMax = 16;                       // picks per batch at most
+constexpr int kSpecMax = 32;                       // picks per batch at most (the masks below are 32 bits wide)
 constexpr int kSpecTable = 1024;                   // (pick, twin class) -> leader, hashed
 
 struct SpecVerdict {
@@ -1307,7 +1307,7 @@ __global__ __launch_bounds__(kGridThreads) void bulyan_spec_kernel(
             ++n_done;
         }
         if (result != 0) break;
-        contested &= (1u << n_done) - 1u;
+        contested &= n_done >= 32 ? ~0u : (1u << n_done) - 1u;
         cmask &= contested;
 
         // ---- 3. every (contested pick, contender) pair of the batch in the reference's arithmetic, in the state of its pick
@@ -1322,14 +1322,14 @@ __global__ __launch_bounds__(kGridThreads) void bulyan_spec_kernel(
             for (uint32_t m = cmask; m != 0u; m &= m - 1u) {
                 const int k = __builtin_ctz(m);
                 const unsigned long long key = (static_cast<unsigned long long>(my_pos) << 32) | (static_cast<uint32_t>(k) << 16) | static_cast<uint32_t>(my_class);
-                atomicMin(&leader_of[(static_cast<uint32_t>(my_class) * 16u + static_cast<uint32_t>(k)) & (kSpecTable - 1)], key);
+                atomicMin(&leader_of[(static_cast<uint32_t>(my_class) * 32u + static_cast<uint32_t>(k)) & (kSpecTable - 1)], key);
             }
             __syncthreads();
             for (uint32_t m = cmask; m != 0u; m &= m - 1u) {
                 const int k = __builtin_ctz(m);
                 const uint32_t low = (static_cast<uint32_t>(k) << 16) | static_cast<uint32_t>(my_class);
                 const unsigned long long key = (static_cast<unsigned long long>(my_pos) << 32) | low;
-                const unsigned long long held = leader_of[(static_cast<uint32_t>(my_class) * 16u + static_cast<uint32_t>(k)) & (kSpecTable - 1)];
+                const unsigned long long held = leader_of[(static_cast<uint32_t>(my_class) * 32u + static_cast<uint32_t>(k)) & (kSpecTable - 1)];
                 // a (pick, class) that lost its slot to another one scores every member: redundant, never wrong
                 if (static_cast<uint32_t>(held) != low || held == key) items[atomicAdd(&n_items, 1)] = static_cast<uint16_t>((k << 8) | tid);
             }
@@ -1534,7 +1534,7 @@ int launch_bulyan_loop(byz_ctx* ctx, const float* dist, int64_t n, int64_t theta
     BYZ_REQUIRE(dist && selection_dev && status_dev && n > 0 && theta >= 0 && theta <= n,
                 "bulyan loop: bad arguments (n=%lld theta=%lld)", (long long)n, (long long)theta);
     BYZ_TRY(ctx->twin_class.ensure(static_cast<size_t>(2 * n) * sizeof(int32_t)));
-    // granules: [2][A, B, R][64 workgroups], then the speculative loop's [2][16 picks of a batch][64], then its three counters
+    // granules: [2][A, B, R][64 workgroups], then the speculative loop's [2][32 picks of a batch][64], then its three counters
     constexpr size_t kGranules = static_cast<size_t>(2 * 3 + 2 * kSpecMax) * kGridMaxWgs;
     BYZ_TRY(ctx->xchg.ensure((kGranules + 2) * sizeof(unsigned long long)));
     int32_t* cls_tmp = ctx->twin_class.as<int32_t>();
@@ -1572,9 +1572,12 @@ int launch_bulyan_loop(byz_ctx* ctx, const float* dist, int64_t n, int64_t theta
     BYZ_TRY(check_launch("twin_class_fix_kernel"));
     const unsigned n_wgs = static_cast<unsigned>(ceil_div(n, kGridThreads));   // <= 64: all resident, they wait for each other
     // BYZ_BULYAN_BATCH=<k>: picks decided optimistically before their contested ones are verified together (bulyan_spec_kernel;
-    // default 16, at most 16); 0: bulyan_grid_kernel, every contested pick re-scored before the next one (rounds 2-5; also taken for
+    // default 24 from 1000 rows, at most 32); 0: bulyan_grid_kernel, every contested pick re-scored before the next one (rounds 2-5; also taken for
     // BYZ_BULYAN_RESCORE=plain and BYZ_BULYAN_CLOCKS).  The same selection, pick for pick.
-    int batch = 16;
+    // (measured, same box, N = 4000 / N = 10,000 on hard data: batches of 8: 15.8 / 101.0 ms, 16: 14.0 / 102.2, 24: 13.55 / 103.4, 32: 13.47 / 103.5;
+    // a batch that grows behind a batch that stood and halves behind a roll-back: 13.7 / 102.6 -- not kept.  Below ~1000 rows few picks
+    // are contested and the batches' bookkeeping costs more than it saves: N = 300: 0.49 -> 0.58 ms, N = 700: 1.40 -> 1.52; N = 1000: 2.18 -> 2.08)
+    int batch = n >= 1000 ? 24 : 0;
     if (const char* e = std::getenv("BYZ_BULYAN_BATCH")) batch = std::atoi(e);
     if (batch > kSpecMax) batch = kSpecMax;
     if (batch >= 1 && rescore_mode == 1 && !clocks) {
