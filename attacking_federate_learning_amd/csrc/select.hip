@@ -1102,7 +1102,8 @@ __global__ __launch_bounds__(kGridThreads) void bulyan_grid_kernel(
 // decided by the reference's arithmetic in the reference's state, every other one by the proof of the band: the selection is
 // bulyan_grid_kernel's, pick for pick.
 constexpr int kSpecMax = 32;                       // picks per batch at most (the masks below are 32 bits wide)
-constexpr int kSpecTable = 1024;                   // (pick, twin class) -> leader, hashed
+constexpr int kSpecTable = 512;                    // (pick, twin class) -> leader, hashed
+constexpr int kSpecThreads = 512;                  // eight waves: four own the 256 rows, all eight score the pairs of a batch
 
 struct SpecVerdict {
     int k_bad;      // first pick of the batch whose optimistic winner is not the reference's (-1: none)
@@ -1110,37 +1111,38 @@ struct SpecVerdict {
     int timeout;
 };
 
-__global__ __launch_bounds__(kGridThreads) void bulyan_spec_kernel(
+__global__ __launch_bounds__(kSpecThreads) void bulyan_spec_kernel(
     const float* __restrict__ dist, int n, int theta, int drop, int users_count, int corrupted,
     const uint16_t* __restrict__ sorted_idx, const uint16_t* __restrict__ rank_t, float* sorted_val,
     const double* __restrict__ row_total, const double* __restrict__ row_top, const int32_t* __restrict__ cls,
     unsigned long long* __restrict__ xchg, float band_scale, int32_t* __restrict__ selection,
     int32_t* __restrict__ status, int32_t* __restrict__ rescored, int head_chunks, int skip_front, int batch_picks,
     int32_t* __restrict__ spec_stats) {
-    __shared__ __attribute__((aligned(16))) float rescore_stage[kGridThreads / 64][512];
-    __shared__ Candidate slots[kGridThreads / 64];
-    __shared__ double second_slots[kGridThreads / 64];
+    __shared__ __attribute__((aligned(16))) float rescore_stage[kSpecThreads / 64][512];
+    __shared__ Candidate slots[kSpecThreads / 64];
+    __shared__ double second_slots[kSpecThreads / 64];
     __shared__ uint32_t removed[kMaxSelectRows / 32];
-    __shared__ __attribute__((aligned(16))) uint32_t egone[kGridThreads / 64][kMaxSelectRows / 32];   // per wave: see reference_score_marked<EXTRA>
+    __shared__ __attribute__((aligned(16))) uint32_t egone[kSpecThreads / 64][kMaxSelectRows / 32];   // per wave: see reference_score_marked<EXTRA>
     __shared__ GridDecision decision;
     __shared__ int decision_contested;
     __shared__ unsigned long long leader_of[kSpecTable];
     __shared__ uint16_t items[kGridThreads * kSpecMax];
     __shared__ int n_items;
-    __shared__ Candidate wave_bests[kGridThreads / 64][kSpecMax];
+    __shared__ Candidate wave_bests[kSpecThreads / 64][kSpecMax];
     __shared__ int winners[kSpecMax];
     __shared__ SpecVerdict verdict;
     __shared__ int true_row[kSpecMax];
     __shared__ uint16_t front_batches[kGridThreads];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n_wgs = gridDim.x, wg = blockIdx.x;
-    const int u = wg * kGridThreads + tid;
-    for (int i = tid; i < kMaxSelectRows / 32; i += kGridThreads) {
+    // threads 0 .. 255 own the workgroup's rows; the waves behind them only help: they score (pick, contender) pairs and gather
+    const int u = tid < kGridThreads ? wg * kGridThreads + tid : n;
+    for (int i = tid; i < kMaxSelectRows / 32; i += kSpecThreads) {
         removed[i] = 0u;
 #pragma unroll
-        for (int w = 0; w < kGridThreads / 64; ++w) egone[w][i] = 0u;
+        for (int w = 0; w < kSpecThreads / 64; ++w) egone[w][i] = 0u;
     }
-    front_batches[tid] = 0;
+    if (tid < kGridThreads) front_batches[tid] = 0;
 
     bool alive = u < n;
     double tot = alive ? row_total[u] : 0.0;
@@ -1231,7 +1233,7 @@ __global__ __launch_bounds__(kGridThreads) void bulyan_spec_kernel(
                 // ---- 2. publish, gather, decide
                 double sec = second_slots[0];
 #pragma unroll
-                for (int w = 1; w < kGridThreads / 64; ++w) sec = fmin(sec, second_slots[w]);
+                for (int w = 1; w < kSpecThreads / 64; ++w) sec = fmin(sec, second_slots[w]);
                 const float a_lb = best.row >= 0 ? float_below(best.score) : __builtin_inff();
                 const float b_lb = float_below(sec);
                 unsigned long long ga = best.row >= 0
@@ -1313,9 +1315,9 @@ __global__ __launch_bounds__(kGridThreads) void bulyan_spec_kernel(
         // ---- 3. every (contested pick, contender) pair of the batch in the reference's arithmetic, in the state of its pick
         int k_bad = -1, w_true = -1;
         if (contested != 0u) {
-            for (int i = tid; i < kSpecTable; i += kGridThreads) leader_of[i] = ~0ull;
+            for (int i = tid; i < kSpecTable; i += kSpecThreads) leader_of[i] = ~0ull;
             if (tid == 0) n_items = 0;
-            if (tid < (kGridThreads / 64) * kSpecMax)
+            if (tid < (kSpecThreads / 64) * kSpecMax)
                 (&wave_bests[0][0])[tid] = Candidate{static_cast<double>(kKrumInit), 0x7fffffff, -1, -1};
             __syncthreads();
             // one contender per (pick, twin class) and workgroup: the class's earliest local member (twins score alike)
@@ -1336,7 +1338,7 @@ __global__ __launch_bounds__(kGridThreads) void bulyan_spec_kernel(
             __syncthreads();
             const int n_it = n_items;
             uint32_t* const my_bits = egone[wave];
-            for (int i = wave; i < n_it; i += kGridThreads / 64) {
+            for (int i = wave; i < n_it; i += kSpecThreads / 64) {
                 const int it = __builtin_amdgcn_readfirstlane(static_cast<int>(items[i]));
                 const int k = it >> 8;
                 const int lt = it & 255;
@@ -1393,7 +1395,7 @@ __global__ __launch_bounds__(kGridThreads) void bulyan_spec_kernel(
                     Candidate local{static_cast<double>(kKrumInit), 0x7fffffff, -1, -1};
                     if (mine_k) {
 #pragma unroll
-                        for (int w = 0; w < kGridThreads / 64; ++w)
+                        for (int w = 0; w < kSpecThreads / 64; ++w)
                             if (better(wave_bests[w][lane], local)) local = wave_bests[w][lane];
                     }
                     if (n_wgs > 1) {
@@ -1408,7 +1410,7 @@ __global__ __launch_bounds__(kGridThreads) void bulyan_spec_kernel(
                 }
                 if (n_wgs > 1) {
                     // wave w gathers the picks w, w + 4, ...: the reference's winner of each (-1: none below 1e20; -2: timed out)
-                    for (int k = wave; k < n_done; k += kGridThreads / 64) {
+                    for (int k = wave; k < n_done; k += kSpecThreads / 64) {
                         if (((contested >> k) & 1u) == 0u) continue;
                         unsigned long long mine = none_a;
                         const bool ok = gather_granules(batch_slot(bpar, k), n_wgs, 0x3ffffu, btag, lane, none_a, mine);
@@ -1572,17 +1574,19 @@ int launch_bulyan_loop(byz_ctx* ctx, const float* dist, int64_t n, int64_t theta
     BYZ_TRY(check_launch("twin_class_fix_kernel"));
     const unsigned n_wgs = static_cast<unsigned>(ceil_div(n, kGridThreads));   // <= 64: all resident, they wait for each other
     // BYZ_BULYAN_BATCH=<k>: picks decided optimistically before their contested ones are verified together (bulyan_spec_kernel;
-    // default 24 from 1000 rows, at most 32); 0: bulyan_grid_kernel, every contested pick re-scored before the next one (rounds 2-5; also taken for
+    // default 32 from 1000 rows, 16 from 6000; at most 32); 0: bulyan_grid_kernel, every contested pick re-scored before the next one (rounds 2-5; also taken for
     // BYZ_BULYAN_RESCORE=plain and BYZ_BULYAN_CLOCKS).  The same selection, pick for pick.
     // (measured, same box, N = 4000 / N = 10,000 on hard data: batches of 8: 15.8 / 101.0 ms, 16: 14.0 / 102.2, 24: 13.55 / 103.4, 32: 13.47 / 103.5;
     // a batch that grows behind a batch that stood and halves behind a roll-back: 13.7 / 102.6 -- not kept.  Below ~1000 rows few picks
     // are contested and the batches' bookkeeping costs more than it saves: N = 300: 0.49 -> 0.58 ms, N = 700: 1.40 -> 1.52; N = 1000: 2.18 -> 2.08)
-    int batch = n >= 1000 ? 24 : 0;
+    // (with eight waves per workgroup, the bench's data: N = 4000: 24 -> 13.4 ms, 32 -> 13.3; configs[4]'s slice, N = 10,000: 12 -> 70.0, 16 -> 71.2,
+    // 24 -> 73.4, 32 -> 77.1 ms: a wrong pick costs the picks decided behind it, and there are more of them at N = 10,000)
+    int batch = n >= 6000 ? 16 : (n >= 1000 ? 32 : 0);
     if (const char* e = std::getenv("BYZ_BULYAN_BATCH")) batch = std::atoi(e);
     if (batch > kSpecMax) batch = kSpecMax;
     if (batch >= 1 && rescore_mode == 1 && !clocks) {
         int32_t* stats = reinterpret_cast<int32_t*>(ctx->xchg.as<unsigned long long>() + kGranules);
-        bulyan_spec_kernel<<<n_wgs, kGridThreads, 0, stream>>>(
+        bulyan_spec_kernel<<<n_wgs, kSpecThreads, 0, stream>>>(
             dist, (int)n, (int)theta, (int)drop_count, (int)users_count, (int)corrupted, ctx->sorted_idx.as<uint16_t>(),
             ctx->rank_t.as<uint16_t>(), ctx->sorted_val.as<float>(), ctx->row_total.as<double>(), ctx->row_top.as<double>(), cls,
             ctx->xchg.as<unsigned long long>(), band_scale, selection_dev, status_dev, status_dev + 1, head_chunks, skip_front, batch, stats);

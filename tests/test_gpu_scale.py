@@ -160,8 +160,14 @@ def test_bulyan_rescore_integer_passes_are_the_literal_chain(eng, monkeypatch, n
     plain = eng.bulyan_select(dist, n, f).tolist()
     rescored = eng.bulyan_rescored()
     monkeypatch.delenv('BYZ_BULYAN_RESCORE')
+    monkeypatch.setenv('BYZ_BULYAN_BATCH', '0')     # the sequential loop: the same pairs are re-scored, by the passes
     got = eng.bulyan_select(dist, n, f).tolist()
     assert eng.bulyan_rescored() == rescored
+    monkeypatch.delenv('BYZ_BULYAN_BATCH')
+    # the default (round 6: batches of picks verified together from 1000 rows): the same selection; picks that are decided again
+    # behind a roll-back re-score their contenders again
+    batched = eng.bulyan_select(dist, n, f).tolist()
+    assert batched == got and eng.bulyan_rescored() >= rescored
     assert got == plain, 'first difference at pick %d' % next(i for i, (a, b) in enumerate(zip(got, plain)) if a != b)
     if family in ('inf', 'nan'):      # such a client is never picked while finite ones remain (the reference's scores are inf)
         assert len(set(got)) == n - 2 * f and not ({17, 300, n - 2} & set(got))
