@@ -104,6 +104,7 @@ struct byz_ctx {
     byz::Buffer gram_chunk_sums; // pre-split Gram, f16x2: the fp32 level-1 sums of every (chunk, tile) of a launch (deferred slab update)
     byz::Buffer plane_unscale;   // pre-split Gram, f16x2: 2^-shift of every (chunk, row) of the super-chunk (fp64)
     byz::Buffer plane_order;     // pre-split Gram: (256-row block, 128-row block) of every workgroup tile
+    byz::Buffer spec_owner;      // speculative Bulyan loop: the row every (workgroup, thread) slot owns
     byz::Buffer split_redo;      // pre-split Gram: (chunk, row block) pairs whose sampled scale did not hold (count first)
     std::vector<int32_t> plane_order_host;
     int64_t plane_order_T = -1;

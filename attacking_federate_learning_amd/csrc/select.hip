@@ -1105,6 +1105,66 @@ constexpr int kSpecMax = 32;                       // picks per batch at most (t
 constexpr int kSpecTable = 512;                    // (pick, twin class) -> leader, hashed
 constexpr int kSpecThreads = 512;                  // eight waves: four own the 256 rows, all eight score the pairs of a batch
 
+// Which row a slot (workgroup g, thread i) of the speculative loop owns.  The rows that are not the root of their twin class (the
+// attack's copies: one class, a quarter of the rows) fill the slots from the front, in index order -- a class is scored once per workgroup
+// that holds members, so it should sit in few.  All other rows are dealt over the slots behind them thread index by thread index,
+// workgroup by workgroup, in the order of their first scores (T - Top, ties by index): the rows that contend are neighbours in that order.
+// Slots without a row hold n.
+__global__ __launch_bounds__(kGridThreads) void spec_owner_kernel(const double* __restrict__ row_total, const double* __restrict__ row_top,
+                                                                  const int32_t* __restrict__ cls, int n, int drop, int n_wgs,
+                                                                  int32_t* __restrict__ owner) {
+    __shared__ double tile[kGridThreads];
+    __shared__ int copy[kGridThreads];
+    const int tid = threadIdx.x;
+    const int u = blockIdx.x * kGridThreads + tid;
+    auto first_score = [&](int v) -> double {
+        if (v >= n) return __builtin_inf();
+        const double s = row_total[v] - (drop > 0 ? row_top[v] : 0.0);
+        return s == s ? s : __builtin_inf();
+    };
+    const double su = first_score(u);
+    const bool u_copy = u < n && cls[u] != u;
+    int rank = 0, copies = 0, copies_before = 0;
+    for (int v0 = 0; v0 < n; v0 += kGridThreads) {
+        tile[tid] = first_score(v0 + tid);
+        copy[tid] = (v0 + tid < n && cls[v0 + tid] != v0 + tid) ? 1 : 0;
+        __syncthreads();
+        const int m = n - v0 < kGridThreads ? n - v0 : kGridThreads;
+        for (int j = 0; j < m; ++j) {
+            const double sv = tile[j];
+            const int cj = copy[j];
+            copies += cj;
+            copies_before += (cj != 0 && v0 + j < u) ? 1 : 0;
+            rank += (cj == 0 && (sv < su || (sv == su && v0 + j < u))) ? 1 : 0;   // among the rows that are dealt
+        }
+        __syncthreads();
+    }
+    if (u >= n) return;
+    if (u_copy) {
+        owner[copies_before] = u;
+        return;
+    }
+    // the copies hold workgroups 0 .. q - 1 and threads 0 .. rem - 1 of workgroup q
+    const int q = copies / kGridThreads, rem = copies % kGridThreads;
+    const int narrow = n_wgs - q - 1, wide = n_wgs - q;   // workgroups with thread i free: i < rem, i >= rem
+    const int first_part = rem * narrow;
+    int wg, local;
+    if (rank < first_part) {
+        local = rank / narrow;
+        wg = q + 1 + rank % narrow;
+    } else {
+        const int r = rank - first_part;
+        local = rem + r / wide;
+        wg = q + r % wide;
+    }
+    owner[wg * kGridThreads + local] = u;
+}
+
+__global__ __launch_bounds__(kGridThreads) void spec_identity_kernel(int n, int32_t* __restrict__ owner) {
+    const int u = blockIdx.x * kGridThreads + threadIdx.x;
+    if (u < n) owner[u] = u;
+}
+
 struct SpecVerdict {
     int k_bad;      // first pick of the batch whose optimistic winner is not the reference's (-1: none)
     int winner;     // the reference's winner there (-1: no row scores below 1e20)
@@ -1117,7 +1177,7 @@ __global__ __launch_bounds__(kSpecThreads) void bulyan_spec_kernel(
     const double* __restrict__ row_total, const double* __restrict__ row_top, const int32_t* __restrict__ cls,
     unsigned long long* __restrict__ xchg, float band_scale, int32_t* __restrict__ selection,
     int32_t* __restrict__ status, int32_t* __restrict__ rescored, int head_chunks, int skip_front, int batch_picks,
-    int32_t* __restrict__ spec_stats) {
+    int32_t* __restrict__ spec_stats, const int32_t* __restrict__ owner) {
     __shared__ __attribute__((aligned(16))) float rescore_stage[kSpecThreads / 64][512];
     __shared__ Candidate slots[kSpecThreads / 64];
     __shared__ double second_slots[kSpecThreads / 64];
@@ -1136,7 +1196,9 @@ __global__ __launch_bounds__(kSpecThreads) void bulyan_spec_kernel(
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n_wgs = gridDim.x, wg = blockIdx.x;
     // threads 0 .. 255 own the workgroup's rows; the waves behind them only help: they score (pick, contender) pairs and gather
-    const int u = tid < kGridThreads ? wg * kGridThreads + tid : n;
+    // (which row a slot owns: spec_owner_kernel deals the rows to the workgroups in the order of their first scores, so that the rows
+    // that contend -- the central ones, neighbours in that order -- are spread over all workgroups)
+    const int u = tid < kGridThreads ? owner[wg * kGridThreads + tid] : n;
     for (int i = tid; i < kMaxSelectRows / 32; i += kSpecThreads) {
         removed[i] = 0u;
 #pragma unroll
@@ -1342,7 +1404,7 @@ __global__ __launch_bounds__(kSpecThreads) void bulyan_spec_kernel(
                 const int it = __builtin_amdgcn_readfirstlane(static_cast<int>(items[i]));
                 const int k = it >> 8;
                 const int lt = it & 255;
-                const int row = wg * kGridThreads + lt;
+                const int row = __builtin_amdgcn_readfirstlane(owner[wg * kGridThreads + lt]);
                 // the batch's earlier winners are gone from this row in the state of pick k: their positions, on the wave's bitmap
                 int pos_gone = -1;
                 if (lane < k) {
@@ -1586,10 +1648,23 @@ int launch_bulyan_loop(byz_ctx* ctx, const float* dist, int64_t n, int64_t theta
     if (batch > kSpecMax) batch = kSpecMax;
     if (batch >= 1 && rescore_mode == 1 && !clocks) {
         int32_t* stats = reinterpret_cast<int32_t*>(ctx->xchg.as<unsigned long long>() + kGranules);
+        BYZ_TRY(ctx->spec_owner.ensure(static_cast<size_t>(n_wgs) * kGridThreads * sizeof(int32_t)));
+        int32_t* owner = ctx->spec_owner.as<int32_t>();
+        BYZ_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(owner), static_cast<int>(n), static_cast<size_t>(n_wgs) * kGridThreads, stream));
+        // BYZ_BULYAN_DEAL=0: slot (g, i) owns row 256 g + i (the comparison)
+        const char* deal_env = std::getenv("BYZ_BULYAN_DEAL");
+        if (deal_env == nullptr || std::atoi(deal_env) != 0) {
+            spec_owner_kernel<<<n_wgs, kGridThreads, 0, stream>>>(ctx->row_total.as<double>(), ctx->row_top.as<double>(), cls, (int)n,
+                                                                  (int)drop_count, (int)n_wgs, owner);
+        } else {
+            spec_identity_kernel<<<n_wgs, kGridThreads, 0, stream>>>((int)n, owner);
+        }
+        BYZ_TRY(check_launch("spec_owner_kernel"));
         bulyan_spec_kernel<<<n_wgs, kSpecThreads, 0, stream>>>(
             dist, (int)n, (int)theta, (int)drop_count, (int)users_count, (int)corrupted, ctx->sorted_idx.as<uint16_t>(),
             ctx->rank_t.as<uint16_t>(), ctx->sorted_val.as<float>(), ctx->row_total.as<double>(), ctx->row_top.as<double>(), cls,
-            ctx->xchg.as<unsigned long long>(), band_scale, selection_dev, status_dev, status_dev + 1, head_chunks, skip_front, batch, stats);
+            ctx->xchg.as<unsigned long long>(), band_scale, selection_dev, status_dev, status_dev + 1, head_chunks, skip_front, batch, stats,
+            owner);
         BYZ_TRY(check_launch("bulyan_spec_kernel"));
         if (const char* e = std::getenv("BYZ_BULYAN_STATS"); e != nullptr && std::atoi(e) != 0) {
             int32_t host[4] = {0, 0, 0, 0};

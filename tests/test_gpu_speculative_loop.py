@@ -75,6 +75,11 @@ def test_batches_select_what_the_sequential_loop_selects(eng, monkeypatch, n, di
     assert got['0'] == want
     for b in BATCHES:
         assert got[b] == want, (b, next(i for i, (x, y) in enumerate(zip(got[b], want)) if x != y))
+    # which workgroup owns which row (dealt in the order of the first scores, the twins' copies in front: the default; row 256 g + i
+    # to thread i of workgroup g: BYZ_BULYAN_DEAL=0) changes who scores a pair, not the selection
+    monkeypatch.setenv('BYZ_BULYAN_DEAL', '0')
+    assert selections(eng, monkeypatch, dist, n, f, batches=('24',))['24'] == want
+    monkeypatch.delenv('BYZ_BULYAN_DEAL')
     eng.check()
 
 
