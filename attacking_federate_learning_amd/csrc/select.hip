@@ -1103,7 +1103,6 @@ __global__ __launch_bounds__(kGridThreads) void bulyan_grid_kernel(
 // bulyan_grid_kernel's, pick for pick.
 constexpr int kSpecMax = 32;                       // picks per batch at most (the masks below are 32 bits wide)
 constexpr int kSpecTable = 512;                    // (pick, twin class) -> leader, hashed
-constexpr int kSpecThreads = 512;                  // eight waves: four own the 256 rows, all eight score the pairs of a batch
 
 // Which row a slot (workgroup g, thread i) of the speculative loop owns.  The rows that are not the root of their twin class (the
 // attack's copies: one class, a quarter of the rows) fill the slots from the front, in index order -- a class is scored once per workgroup
@@ -1171,6 +1170,9 @@ struct SpecVerdict {
     int timeout;
 };
 
+// kSpecThreads: 256 (the four waves that own the 256 rows) or 512 (four more that only score pairs and gather: from 6000 rows, where the
+// verification is what a batch waits for -- N = 10,000: 68 -> 61 ms; they cost every pick 0.6 us at its barriers -- N = 4000: 12.6 -> 13.1 ms).
+template <int kSpecThreads>
 __global__ __launch_bounds__(kSpecThreads) void bulyan_spec_kernel(
     const float* __restrict__ dist, int n, int theta, int drop, int users_count, int corrupted,
     const uint16_t* __restrict__ sorted_idx, const uint16_t* __restrict__ rank_t, float* sorted_val,
@@ -1660,7 +1662,8 @@ int launch_bulyan_loop(byz_ctx* ctx, const float* dist, int64_t n, int64_t theta
             spec_identity_kernel<<<n_wgs, kGridThreads, 0, stream>>>((int)n, owner);
         }
         BYZ_TRY(check_launch("spec_owner_kernel"));
-        bulyan_spec_kernel<<<n_wgs, kSpecThreads, 0, stream>>>(
+        auto* spec = n >= 6000 ? &bulyan_spec_kernel<512> : &bulyan_spec_kernel<256>;
+        spec<<<n_wgs, n >= 6000 ? 512 : 256, 0, stream>>>(
             dist, (int)n, (int)theta, (int)drop_count, (int)users_count, (int)corrupted, ctx->sorted_idx.as<uint16_t>(),
             ctx->rank_t.as<uint16_t>(), ctx->sorted_val.as<float>(), ctx->row_total.as<double>(), ctx->row_top.as<double>(), cls,
             ctx->xchg.as<unsigned long long>(), band_scale, selection_dev, status_dev, status_dev + 1, head_chunks, skip_front, batch, stats,
