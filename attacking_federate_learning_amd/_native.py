@@ -6,7 +6,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # BYZ_LIBRARY: another build of the same ABI (the sanitized one, build_native.py --sanitize)
 LIB_PATH = os.environ.get('BYZ_LIBRARY') or os.path.join(_HERE, 'libbyzagg.so')
 
-OK, E_INVALID, E_PRECONDITION, E_HIP, E_UNSUPPORTED, E_NO_WINNER = 0, -1, -2, -3, -4, -5
+OK, E_INVALID, E_PRECONDITION, E_HIP, E_UNSUPPORTED, E_NO_WINNER, E_COLLECTIVE = 0, -1, -2, -3, -4, -5, -6
 
 KERNELS = ('column_stats', 'gram_tile', 'gram_reduce', 'distances', 'row_sort', 'krum_argmin',
            'bulyan_loop', 'trimmed_mean', 'misc', 'plane_split')
@@ -47,6 +47,10 @@ _PROTOTYPES = {
     'byz_bulyan_select_dev': [c_vp, c_vp, c_i64, c_i64, c_i64, c_vp, c_vp],
     'byz_krum_bulyan_select_dev': [c_vp, c_vp, c_i64, c_i64, c_i64, _P(c_i32), c_vp, c_vp],
     'byz_bulyan_dev': [c_vp, c_vp, c_i64, c_i64, c_i64, c_i64, c_i64, c_vp, c_vp, c_vp],
+    # (the byz_allreduce_f64_fn callback and its `user` word are passed as plain pointers: ALLREDUCE_F64_FN builds the callback)
+    'byz_pairwise_distances_sharded_dev': [c_vp, c_vp, c_i64, c_i64, c_i64, c_vp, c_vp, c_vp, c_vp],
+    'byz_krum_sharded_dev': [c_vp, c_vp, c_i64, c_i64, c_i64, c_i64, c_i64, c_int, c_vp, c_vp, c_vp, _P(c_i32), c_vp],
+    'byz_bulyan_sharded_dev': [c_vp, c_vp, c_i64, c_i64, c_i64, c_i64, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp],
     'byz_drift_attack_dev': [c_vp, c_vp, c_i64, c_i64, c_i64, c_f32, c_vp, c_vp, c_vp, c_int, c_vp],
     'byz_column_chain_dev': [c_vp, c_vp, c_i64, c_i64, c_i64, c_vp, c_vp, c_vp, c_vp],
     'byz_column_finish_dev': [c_vp, c_vp, c_vp, c_i64, c_f32, c_i64, c_vp, c_vp, c_vp, c_vp],
@@ -70,6 +74,9 @@ _PROTOTYPES = {
     'byz_selftest_lane_exchange_dev': [c_vp, c_vp, _P(c_i32), c_vp],
 }
 _RESTYPES = {'byz_last_error': ctypes.c_char_p, 'byz_kernel_name': ctypes.c_char_p, 'byz_ctx_destroy': None}
+
+# int (*byz_allreduce_f64_fn)(void* user, double* buf_dev, int64_t count, void* stream)
+ALLREDUCE_F64_FN = ctypes.CFUNCTYPE(c_int, c_vp, c_vp, c_i64, c_vp)
 
 EXPORTED_SYMBOLS = tuple(_PROTOTYPES)
 

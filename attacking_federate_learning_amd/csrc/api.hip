@@ -512,6 +512,108 @@ int byz_bulyan_dev(byz_ctx* ctx, const float* G, int64_t n_rows, int64_t n_cols,
     return launch_trimmed_mean(ctx, G, theta, n_cols, ld, sel, keep, out, s);
 }
 
+// ---- multi-GPU, columns layout: the one exchange of the path through the host's all-reduce -------------------
+namespace {
+
+int reduce_over_ranks(byz_allreduce_f64_fn allreduce, void* user, double* buf, int64_t count, void* stream, const char* what) {
+    const int rc = allreduce(user, buf, count, stream);
+    if (rc != 0) {
+        set_error("%s: the caller's all-reduce returned %d", what, rc);
+        return BYZ_E_COLLECTIVE;
+    }
+    return BYZ_OK;
+}
+
+// dist (n x n) from the column slices of all ranks: Gram of the local slice -> all-reduce -> distances -> the near-duplicate
+// pairs of the all-reduced Gram re-evaluated on the difference (per-rank sums over the local columns -> all-reduce -> apply).
+// The sequence of sharded.py's global_distances + engine.distances_from_gram, in one call.
+int sharded_distances(byz_ctx* ctx, const float* G, int64_t n_rows, int64_t n_cols, int64_t ld, byz_allreduce_f64_fn allreduce,
+                      void* user, float* dist, void* stream) {
+    hipStream_t s = as_stream(stream);
+    BYZ_TRY(ctx->gram.ensure(static_cast<size_t>(n_rows) * n_rows * sizeof(double)));
+    double* gram = ctx->gram.as<double>();
+    BYZ_TRY(launch_gram(ctx, G, n_rows, n_cols, ld, gram, s));
+    // rows that are identical in THIS slice need not be identical in the others: what launch_gram's duplicate search proved
+    // holds for the local columns only, and the all-reduced Gram is an external one as far as the distances are concerned
+    ctx->row_map_rows = 0;
+    BYZ_TRY(reduce_over_ranks(allreduce, user, gram, n_rows * n_rows, stream, "sharded distances (Gram)"));
+    BYZ_TRY(launch_distances_from_gram(ctx, gram, n_rows, dist, s, nullptr, 0, 0));
+    int32_t words[32];
+    BYZ_TRY(read_small(ctx, words, s));   // (the same all-reduced Gram on every rank: the same count, the same list)
+    const int64_t count = words[17];
+    if (count > ctx->near_pair_capacity) {
+        set_error("distances: %lld near-duplicate pairs exceed the list capacity %lld (BYZ_NEAR_PAIR_CAPACITY)", (long long)count,
+                  (long long)ctx->near_pair_capacity);
+        return BYZ_E_UNSUPPORTED;
+    }
+    if (count > 0) {
+        double* sq = ctx->near_sq.as<double>();
+        BYZ_TRY(launch_near_pair_sqdist(ctx, G, n_cols, ld, nullptr, sq, s));
+        BYZ_TRY(reduce_over_ranks(allreduce, user, sq, count, stream, "sharded distances (near pairs)"));
+        BYZ_TRY(launch_near_pair_apply(ctx, sq, n_rows, dist, s));
+    }
+    return BYZ_OK;
+}
+
+}  // namespace
+
+int byz_pairwise_distances_sharded_dev(byz_ctx* ctx, const float* G, int64_t n_rows, int64_t n_cols, int64_t ld,
+                                       byz_allreduce_f64_fn allreduce, void* user, float* dist, void* stream) {
+    BYZ_TRY(enter(ctx));
+    BYZ_TRY(check_matrix(G, n_rows, n_cols, ld, "pairwise_distances_sharded"));
+    BYZ_REQUIRE(dist && allreduce, "pairwise_distances_sharded: null output or null all-reduce");
+    return sharded_distances(ctx, G, n_rows, n_cols, ld, allreduce, user, dist, stream);
+}
+
+int byz_krum_sharded_dev(byz_ctx* ctx, const float* G, int64_t n_rows, int64_t n_cols, int64_t ld, int64_t users_count,
+                         int64_t corrupted_count, int check_assert, byz_allreduce_f64_fn allreduce, void* user, float* out_row,
+                         int32_t* index_host, void* stream) {
+    BYZ_TRY(enter(ctx));
+    BYZ_TRY(check_matrix(G, n_rows, n_cols, ld, "krum_sharded"));
+    BYZ_REQUIRE(allreduce, "krum_sharded: null all-reduce");
+    if (check_assert && !(users_count >= 2 * corrupted_count + 1)) {  // defences.py:25
+        set_error("('users_count>=2*corrupted_count + 3', %lld, %lld)", (long long)users_count, (long long)corrupted_count);
+        return BYZ_E_PRECONDITION;
+    }
+    hipStream_t s = as_stream(stream);
+    BYZ_TRY(ensure_distance_workspaces(ctx, n_rows));
+    BYZ_TRY(sharded_distances(ctx, G, n_rows, n_cols, ld, allreduce, user, ctx->dist.as<float>(), stream));
+    int32_t* winner = ctx->small.as<int32_t>();
+    BYZ_TRY(krum_select(ctx, ctx->dist.as<float>(), n_rows, users_count, corrupted_count, winner, s));
+    if (out_row) BYZ_TRY(launch_copy_row(ctx, G, ld, n_rows, n_cols, winner, out_row, s));
+    if (index_host) {
+        int32_t words[32];
+        BYZ_TRY(read_small(ctx, words, s));
+        *index_host = words[0];
+    }
+    return BYZ_OK;
+}
+
+int byz_bulyan_sharded_dev(byz_ctx* ctx, const float* G, int64_t n_rows, int64_t n_cols, int64_t ld, int64_t users_count,
+                           int64_t corrupted_count, byz_allreduce_f64_fn allreduce, void* user, float* out,
+                           int32_t* selection_out, void* stream) {
+    BYZ_TRY(enter(ctx));
+    BYZ_TRY(check_matrix(G, n_rows, n_cols, ld, "bulyan_sharded"));
+    BYZ_REQUIRE(out && allreduce, "bulyan_sharded: null output or null all-reduce");
+    if (!(users_count >= 4 * corrupted_count + 3)) {  // defences.py:56
+        set_error("bulyan: users_count >= 4*corrupted_count + 3 violated (%lld, %lld)", (long long)users_count,
+                  (long long)corrupted_count);
+        return BYZ_E_PRECONDITION;
+    }
+    hipStream_t s = as_stream(stream);
+    const int64_t theta = users_count - 2 * corrupted_count;
+    BYZ_TRY(ensure_distance_workspaces(ctx, n_rows));
+    BYZ_TRY(ctx->selection.ensure(static_cast<size_t>(n_rows) * sizeof(int32_t)));
+    BYZ_TRY(sharded_distances(ctx, G, n_rows, n_cols, ld, allreduce, user, ctx->dist.as<float>(), stream));
+    int32_t* sel = ctx->selection.as<int32_t>();
+    BYZ_TRY(bulyan_select(ctx, ctx->dist.as<float>(), n_rows, users_count, corrupted_count, sel, s));
+    if (selection_out)
+        BYZ_HIP(hipMemcpyAsync(selection_out, sel, static_cast<size_t>(theta) * sizeof(int32_t), hipMemcpyDeviceToDevice, s));
+    // defences.py:70 on the local columns of the selected rows
+    const int64_t keep = python_prefix_len(theta, theta - 2 * corrupted_count - 1);
+    return launch_trimmed_mean(ctx, G, theta, n_cols, ld, sel, keep, out, s);
+}
+
 int byz_drift_attack_dev(byz_ctx* ctx, float* G, int64_t n_rows, int64_t n_cols, int64_t ld, float num_std,
                          float* drift, float* mean, float* stdev, int write_back, void* stream) {
     BYZ_TRY(enter(ctx));

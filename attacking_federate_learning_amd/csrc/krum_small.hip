@@ -419,12 +419,15 @@ __device__ unsigned long long g_rows_stamps[kMaxRows * kRowStamps];
 
 constexpr uint32_t kScoreSentinel = 0xffc0dead;   // "no score yet": K1 writes it, K2's rows overwrite it (never a published score)
 constexpr int kGroups = 16;                       // thread groups of the slab sums (32 threads x 4 columns each)
-constexpr int kMaxPerGroup = 256 / kGroups;       // K1 launches at most 256 workgroups
+constexpr int kMaxPerGroup = 256 / kGroups;       // K1 launches at most 256 workgroups: at most 16 slabs per group
 
 // TIMING (BYZ_KRUM_SMALL_TIMING): the phase stamps.  A template parameter: as a flag in device memory it was a dependent scalar
 // load at the head of a 10 us kernel.
-template <bool TIMING>
+// PG: slabs per thread group, a multiple of 4 with 16 PG >= n_slabs (the loads of a group are all issued before its first add:
+// with fewer slabs than 256 the shorter forms issue fewer of them).
+template <bool TIMING, int PG>
 __global__ __launch_bounds__(kThreads, 1) void small_rows_kernel(RowsArgs p) {
+    static_assert(PG % 4 == 0 && PG >= 4 && PG <= kMaxPerGroup, "slabs per group");
     __shared__ double part[2][kGroups][kMaxRows];   // [row entries | diagonal][group][column]
     __shared__ double red[kThreads];
     __shared__ double c_row[kMaxRows], c_diag[kMaxRows];
@@ -440,12 +443,12 @@ __global__ __launch_bounds__(kThreads, 1) void small_rows_kernel(RowsArgs p) {
     // ---- 1. the row of the Gram and the diagonal
     {
         const int jq = tid & 31, grp = tid >> 5;
-        f32x4 rv[kMaxPerGroup], dv[kMaxPerGroup];
+        f32x4 rv[PG], dv[PG];
         const int jq_read = 4 * jq < n ? jq : 0;     // columns past n: the lane repeats lane 0's request (no extra bytes)
         const float* row_src = p.slabs + static_cast<int64_t>(i) * kMaxRows + 4 * jq_read;
         const float* diag_src = p.diag_slabs + 4 * jq_read;
 #pragma unroll
-        for (int k = 0; k < kMaxPerGroup; ++k) {
+        for (int k = 0; k < PG; ++k) {
             const int g = grp + kGroups * k;
             const int gg = g < p.n_slabs ? g : 0;      // a clamped, unconditional load; discarded below
             rv[k] = *reinterpret_cast<const f32x4*>(row_src + static_cast<int64_t>(gg) * kSlabFloats);
@@ -457,7 +460,7 @@ __global__ __launch_bounds__(kThreads, 1) void small_rows_kernel(RowsArgs p) {
         // Slabs past the last are zeros.  The order is the same for every entry of every row: symmetry and ties are kept.
         double rs[4] = {0.0, 0.0, 0.0, 0.0}, ds[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-        for (int k = 0; k < kMaxPerGroup; ++k) {
+        for (int k = 0; k < PG; ++k) {
             if (!(grp + kGroups * k < p.n_slabs)) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
@@ -467,7 +470,7 @@ __global__ __launch_bounds__(kThreads, 1) void small_rows_kernel(RowsArgs p) {
             }
         }
 #pragma unroll
-        for (int k = 0; k < kMaxPerGroup; k += 4) {
+        for (int k = 0; k < PG; k += 4) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 rs[e] += static_cast<double>(__fadd_rn(__fadd_rn(rv[k][e], rv[k + 1][e]), __fadd_rn(rv[k + 2][e], rv[k + 3][e])));
@@ -755,7 +758,11 @@ static int small_round(byz_ctx* ctx, const float* G, int64_t n_rows, int64_t n_c
     const int n = static_cast<int>(n_rows);
     const int64_t n_slices = ceil_div(n_cols, kSlice);
     // one workgroup per CU at most; the grid is sized so that everybody gets the same number of slices (+- 1)
-    const int grid = static_cast<int>(ceil_div(n_slices, ceil_div(n_slices, ctx->num_cus < 256 ? ctx->num_cus : 256)));
+    // BYZ_KRUM_SMALL_GRID (experiments): a cap on K1's workgroups below 256 -- fewer, longer-lived workgroups, fewer slabs for K2
+    int cap = env_int("BYZ_KRUM_SMALL_GRID", 256);
+    cap = cap < 1 ? 1 : (cap > 256 ? 256 : cap);
+    if (ctx->num_cus < cap) cap = ctx->num_cus;
+    const int grid = static_cast<int>(ceil_div(n_slices, ceil_div(n_slices, cap)));
     const int64_t per = ceil_div(n_slices, grid);   // (per - 1) * grid < n_slices: only a workgroup's last slice can be ragged or missing
     // one full 128 x 128 slab per workgroup, then one compact diagonal per workgroup
     const size_t slab_floats = static_cast<size_t>(grid) * kSlabFloats;
@@ -820,8 +827,16 @@ static int small_round(byz_ctx* ctx, const float* G, int64_t n_rows, int64_t n_c
         p.out_row = out_row;
         p.status = device_status_word(ctx);
         const bool stamps = env_int("BYZ_KRUM_SMALL_TIMING", 0) != 0;
-        if (stamps) small_rows_kernel<true><<<static_cast<unsigned>(n), kThreads, 0, stream>>>(p);
-        else small_rows_kernel<false><<<static_cast<unsigned>(n), kThreads, 0, stream>>>(p);
+        const int pg = 4 * static_cast<int>(ceil_div(p.n_slabs, 4 * kGroups));   // 4, 8, 12 or 16 slabs per thread group
+#define BYZ_K2(TM)                                                                                 \
+    switch (pg) {                                                                                 \
+        case 4: small_rows_kernel<TM, 4><<<static_cast<unsigned>(n), kThreads, 0, stream>>>(p); break;   \
+        case 8: small_rows_kernel<TM, 8><<<static_cast<unsigned>(n), kThreads, 0, stream>>>(p); break;   \
+        case 12: small_rows_kernel<TM, 12><<<static_cast<unsigned>(n), kThreads, 0, stream>>>(p); break; \
+        default: small_rows_kernel<TM, 16><<<static_cast<unsigned>(n), kThreads, 0, stream>>>(p); break; \
+    }
+        if (stamps) { BYZ_K2(true) } else { BYZ_K2(false) }
+#undef BYZ_K2
         BYZ_TRY(check_launch("small_rows_kernel"));
         if (stamps) {
             static unsigned long long host[kMaxRows * kRowStamps];

@@ -40,7 +40,8 @@ enum {
     BYZ_E_PRECONDITION = -2, /* the reference would raise AssertionError                       */
     BYZ_E_HIP = -3,          /* a HIP runtime call failed                                      */
     BYZ_E_UNSUPPORTED = -4,  /* size beyond what this build supports (see byz_limits)          */
-    BYZ_E_NO_WINNER = -5     /* Krum found no score < 1e20 (reference: index -1 / KeyError)    */
+    BYZ_E_NO_WINNER = -5,    /* Krum found no score < 1e20 (reference: index -1 / KeyError)    */
+    BYZ_E_COLLECTIVE = -6    /* the caller's all-reduce (byz_allreduce_f64_fn) reported failure */
 };
 
 typedef struct byz_ctx byz_ctx;
@@ -163,6 +164,38 @@ int byz_bulyan_rescored(const byz_ctx* ctx, int64_t* rows_host);
 int byz_bulyan_dev(byz_ctx* ctx, const float* G_dev, int64_t n_rows, int64_t n_cols, int64_t ld,
                    int64_t users_count, int64_t corrupted_count, float* out_dev,
                    int32_t* selection_dev, void* stream);
+
+/* ---- multi-GPU, columns layout: one context per GPU, the HOST owns the communicator ---- */
+/* SURVEY.md 8(e)'s "cheaper equivalent": every rank holds ALL n_rows clients over its own slice of the      */
+/* columns (G_local: n_rows x n_cols_local).  The path has ONE exchange: the n_rows x n_rows fp64 Gram of    */
+/* the slices is summed over the ranks (plus, when clients nearly coincide, the short list of squared        */
+/* differences of byz_near_pairs_*); the selection then runs replicated on every rank and the trimmed mean   */
+/* on the local columns, so out_local is this rank's slice of the reference's result.  The library links no  */
+/* collective library: the host passes its own in-place SUM all-reduce over the ranks, which must enqueue on */
+/* `stream` and return 0 --                                                                                   */
+/*     ncclAllReduce(buf, buf, count, ncclDouble, ncclSum, comm, (hipStream_t)stream)   (RCCL over xGMI)      */
+/* with `comm` from ncclCommInitRank (one process per GPU) or ncclCommInitAll (one thread per GPU) reached     */
+/* through `user`.  Every rank makes the same calls in the same order (the pair count is read from the same    */
+/* all-reduced Gram on every rank).  A failing callback makes the call return BYZ_E_COLLECTIVE.  What          */
+/* attacking_federate_learning_amd/sharded.py composes in Python over torch.distributed, for hosts without it. */
+/* no_defense, trimmed_mean and the drift attack are independent per column: call the single-GPU entry         */
+/* points on the local slice.                                                                                  */
+typedef int (*byz_allreduce_f64_fn)(void* user, double* buf_dev, int64_t count, void* stream);
+int byz_pairwise_distances_sharded_dev(byz_ctx* ctx, const float* G_local_dev, int64_t n_rows,
+                                       int64_t n_cols_local, int64_t ld, byz_allreduce_f64_fn allreduce,
+                                       void* user, float* dist_dev, void* stream);
+/* defences.krum over the slices: *index_host is the reference's index (the same on every rank),              */
+/* out_row_local_dev (optional) this rank's n_cols_local columns of the winning row.                           */
+int byz_krum_sharded_dev(byz_ctx* ctx, const float* G_local_dev, int64_t n_rows, int64_t n_cols_local,
+                         int64_t ld, int64_t users_count, int64_t corrupted_count, int check_assert,
+                         byz_allreduce_f64_fn allreduce, void* user, float* out_row_local_dev,
+                         int32_t* index_host, void* stream);
+/* defences.bulyan over the slices: out_local_dev = this rank's n_cols_local columns of the aggregate,         */
+/* selection_dev (optional) the theta selected clients in selection order (the same on every rank).            */
+int byz_bulyan_sharded_dev(byz_ctx* ctx, const float* G_local_dev, int64_t n_rows, int64_t n_cols_local,
+                           int64_t ld, int64_t users_count, int64_t corrupted_count,
+                           byz_allreduce_f64_fn allreduce, void* user, float* out_local_dev,
+                           int32_t* selection_dev, void* stream);
 
 /* ---- malicious.Attack.attack / DriftAttack._attack_grads (malicious.py:10-36) ---------- */
 /* Column mean and population std over the n_rows rows of G (the malicious clients' honest  */

@@ -58,7 +58,7 @@ def test_ctypes_table_matches_the_header_argument_by_argument():
 
     def c_kind(decl):
         base = decl.rsplit(' ', 1)[0] if ' ' in decl else decl
-        if '*' in decl:
+        if '*' in decl or base.endswith('_fn'):    # (a callback typedef, e.g. byz_allreduce_f64_fn, is a function pointer)
             return 'pointer'
         if 'int64_t' in base:
             return 'int64'
