@@ -876,6 +876,8 @@ def compact_line(detail, budget=LINE_BUDGET):
                                        'higher_is_better', 'scaling', 'vs_baseline', 'dtype', 'data')}
     line['value'], line['ms_per_step'] = sig(line['value'], 6), sig(line['ms_per_step'], 6)
     line['dtype'] = clip(line['dtype'], 120)
+    if detail.get('rehearsal'):
+        line['rehearsal'] = detail['rehearsal']
     cfg = detail.get('config') or {}
     line['config'] = {k: (clip(v, 220) if isinstance(v, str) else v) for k, v in cfg.items()
                       if k in ('workload', 'clients', 'params', 'corrupted', 'layout', 'params_per_gpu')}
@@ -1001,14 +1003,19 @@ def main(argv=None):
     import torch.distributed as dist
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs an MI355X: the aggregation path has no CPU implementation')
-    plan, why = launch_plan(args.gpus, os.environ, torch.cuda.device_count())
+    # BYZ_BENCH_ONE_DEVICE=1: a REHEARSAL of the N-rank run on a box with one GPU -- every rank on GPU 0, the collectives over gloo
+    # (RCCL refuses two ranks on one device).  It exercises everything of the W > 1 path but RCCL itself (the launcher, the rank
+    # count, the barriers and the max-over-ranks clock, the sharded workload, the side leg and its watchdog); its line says
+    # `rehearsal` and is NOT a multi-GPU measurement.
+    one_device = os.environ.get('BYZ_BENCH_ONE_DEVICE') == '1'
+    plan, why = launch_plan(args.gpus, os.environ, args.gpus if one_device else torch.cuda.device_count())
     if plan == 'fail':
         raise SystemExit('bench: ' + why)
     if plan == 'spawn':
         raise SystemExit(spawn_ranks(args.gpus, own_argv))
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
-    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    local_rank = 0 if one_device else int(os.environ.get('LOCAL_RANK', '0'))
     torch.cuda.set_device(local_rank)
     device = torch.device('cuda', local_rank)
     os.environ.setdefault('BYZ_DEVICE', str(local_rank))
@@ -1017,7 +1024,10 @@ def main(argv=None):
         os.environ.setdefault('MASTER_PORT', '29511')
         os.environ.setdefault('RANK', '0')
         os.environ.setdefault('WORLD_SIZE', '1')
-        dist.init_process_group('nccl', device_id=device)
+        if one_device:
+            dist.init_process_group('gloo')
+        else:
+            dist.init_process_group('nccl', device_id=device)
     # n_gpus is what the collective library says, never what the command line says
     n_gpus = dist.get_world_size() if dist.is_initialized() else 1
     seen = ranks_seen(torch, dist, device)
@@ -1056,6 +1066,9 @@ def main(argv=None):
         'kernels': kernel_table(per_kernel, args.steps),
         'collectives': collectives_table(agg, args.steps),
     }
+    if one_device:
+        line['rehearsal'] = ('BYZ_BENCH_ONE_DEVICE=1: %d rank(s) share GPU 0, collectives over gloo -- a rehearsal of the launch '
+                             'path, NOT a multi-GPU measurement' % world)
     if hasattr(wl, 'verify'):
         line['verified_after_timing'] = wl.verify()
     if world == 1 and isinstance(wl, BulyanSharded) and wl.layout == 'columns':
@@ -1093,7 +1106,7 @@ def main(argv=None):
             if rank == 0 and args.detail_file:
                 try:
                     line['other_layout'] = {'side_leg': 'timeout', 'layout': 'clients' if wl.layout == 'columns' else 'columns',
-                                            'seconds': float(os.environ.get('BYZ_BENCH_SIDE_LEG_SECONDS', '240'))}
+                                            'seconds': float(os.environ.get('BYZ_BENCH_SIDE_LEG_SECONDS', '150'))}
                     with open(args.detail_file, 'w') as fh:
                         json.dump(line, fh, indent=1)
                 except (OSError, TypeError, ValueError):
@@ -1103,7 +1116,7 @@ def main(argv=None):
             except OSError:
                 pass
             os._exit(0)
-        watchdog = threading.Timer(float(os.environ.get('BYZ_BENCH_SIDE_LEG_SECONDS', '240')), give_up)
+        watchdog = threading.Timer(float(os.environ.get('BYZ_BENCH_SIDE_LEG_SECONDS', '150')), give_up)
         watchdog.daemon = True
         watchdog.start()
         rec, _ = side_leg()

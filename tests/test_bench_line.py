@@ -182,3 +182,38 @@ def test_gpu_bench_prints_one_parsable_line(tmp_path):
     assert line['cpu_baseline']['value'] > 0 and line['others']
     assert len(proc.stdout) + len(proc.stderr) < 8000, (len(proc.stdout), len(proc.stderr))
     assert os.path.isfile(path)
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(900)
+def test_gpu_bench_rehearses_the_multi_rank_run_on_one_device(tmp_path):
+    """`bench.py --gpus 2` end to end on the ONE GPU there is (BYZ_BENCH_ONE_DEVICE=1: both ranks on GPU 0, collectives over
+    gloo): the self-spawn under torch.distributed.run, the rank count through the collective library, the barriers and the
+    max-over-ranks clock, the column-sharded workload with its Gram all-reduce, rank 0's one line LAST on stdout -- everything
+    of the W > 1 path but RCCL itself -- and then the side leg's watchdog: the other layout's point-to-point gathers do not
+    complete over gloo, the headline must be out already, the exit status 0 and the detail file marked."""
+    path = str(tmp_path / 'detail.json')
+    env = dict(os.environ, BYZ_BENCH_ONE_DEVICE='1', BYZ_BENCH_SIDE_LEG_SECONDS='20')
+    env.pop('WORLD_SIZE', None)
+    proc = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '2', '--warmup', '1',
+                           '--clients', '1000', '--params', '300000', '--detail-file', path],
+                          capture_output=True, text=True, timeout=880, env=env)
+    assert proc.returncode == 0, proc.stderr[-3000:]
+    out_lines = [ln for ln in proc.stdout.splitlines() if ln.strip()]
+    assert len(out_lines[-1]) < 4096
+    line = json.loads(out_lines[-1])
+    for key in CONTRACT_KEYS:
+        assert key in line, key
+    assert line['cpu_baseline'] is None          # (the CPU baseline is rank 0's at N = 1 only)
+    assert abs(line['roofline']['frac'] - line['roofline']['achieved'] / line['roofline']['peak']) < 1e-3 * line['roofline']['frac']
+    assert line['n_gpus'] == 2 and line['ranks_seen'] == 2 and line['steps'] == 2
+    assert 'NOT a multi-GPU measurement' in line['rehearsal']
+    assert line['config']['params_per_gpu'] == 150000 and line['scaling'] == 'strong'
+    assert line['collectives_ms']['allreduce_gram'] > 0
+    assert line['verified_after_timing']['selection_distinct'] == 1000 - 2 * 240
+    detail = json.load(open(path))
+    leg = detail.get('other_layout') or {}
+    # the leg either ran (a record or an error text) or was ended by the watchdog; a hang must have left its marker
+    assert leg.get('layout') == 'clients'
+    if leg.get('side_leg') == 'timeout':
+        assert 'ended by the watchdog' in proc.stderr
