@@ -185,3 +185,20 @@ def test_host_library_under_address_and_ub_sanitizers(tmp_path):
     assert proc.returncode == 0, proc.stderr[-2000:]
     assert 'sanitized calls done' in proc.stdout
     assert 'AddressSanitizer' not in proc.stderr and 'runtime error' not in proc.stderr, proc.stderr[-2000:]
+
+
+def test_the_header_is_plain_c_and_the_c_host_example_compiles():
+    """include/byzagg.h is a C header (not C++): it must pass `gcc -std=c99 -pedantic`; and the C host of INTEGRATION.md 5b
+    (examples/shard_columns.c, which needs HIP's and RCCL's headers) must at least compile here, without warnings."""
+    import subprocess
+    probe = '#include "byzagg.h"\nint main(void) { return byz_abi_version() == BYZ_ABI_VERSION ? 0 : 1; }\n'
+    proc = subprocess.run(['gcc', '-std=c99', '-Wall', '-Wextra', '-pedantic', '-fsyntax-only', '-I', os.path.join(ROOT, 'include'),
+                           '-x', 'c', '-'], input=probe, capture_output=True, text=True)
+    assert proc.returncode == 0 and not proc.stderr.strip(), proc.stderr
+    rocm = os.environ.get('ROCM_PATH', '/opt/rocm')
+    if not os.path.isfile(os.path.join(rocm, 'include', 'rccl', 'rccl.h')):
+        pytest.skip('rccl/rccl.h not installed')
+    proc = subprocess.run(['gcc', '-std=c99', '-Wall', '-Wextra', '-fsyntax-only', '-D__HIP_PLATFORM_AMD__',
+                           '-I', os.path.join(ROOT, 'include'), '-I', os.path.join(rocm, 'include'),
+                           os.path.join(ROOT, 'examples', 'shard_columns.c')], capture_output=True, text=True)
+    assert proc.returncode == 0 and not proc.stderr.strip(), proc.stderr[-2000:]

@@ -20,12 +20,16 @@ The inputs carry the attack's identical rows (malicious.py:26-27) and an honest 
 resolves it, the Gram identity does not), so both exchanges of the path happen.
 """
 import ctypes
+import os
+import subprocess
 import threading
 
 import numpy as np
 import pytest
 
 pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def attacked_matrix(n, d, f, seed):
@@ -279,3 +283,31 @@ def test_a_failing_all_reduce_is_reported(eng):
         rank.eng.synchronize()
     finally:
         rank.close()
+
+
+def c_host_command(out_path):
+    """The build line of examples/shard_columns.c (its header comment), or None where RCCL's header is not installed."""
+    rocm = os.environ.get('ROCM_PATH', '/opt/rocm')
+    if not os.path.isfile(os.path.join(rocm, 'include', 'rccl', 'rccl.h')):
+        return None
+    lib_dir = os.path.join(ROOT, 'attacking_federate_learning_amd')
+    return ['gcc', '-O2', '-std=c99', '-Wall', '-Wextra', '-D__HIP_PLATFORM_AMD__', '-I', os.path.join(ROOT, 'include'),
+            '-I', os.path.join(rocm, 'include'), os.path.join(ROOT, 'examples', 'shard_columns.c'), '-o', out_path,
+            '-L', lib_dir, '-lbyzagg', '-L', os.path.join(rocm, 'lib'), '-lrccl', '-lamdhip64', '-lpthread', '-lm',
+            '-Wl,-rpath,' + lib_dir, '-Wl,-rpath,' + os.path.join(rocm, 'lib')]
+
+
+@pytest.mark.timeout(600)
+def test_the_c_host_example_runs_a_round_without_python(eng, tmp_path):
+    """examples/shard_columns.c: a C program over include/byzagg.h + RCCL (ncclCommInitAll, one thread per GPU, ncclAllReduce
+    behind the callback) -- built with gcc and run with the one GPU there is: every check of the program itself (the sharded
+    Krum index and Bulyan selection are the unsharded ones, the aggregate within 1e-5) must hold."""
+    exe = str(tmp_path / 'shard_columns')
+    cmd = c_host_command(exe)
+    if cmd is None:
+        pytest.skip('rccl/rccl.h not installed')
+    build = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+    assert build.returncode == 0 and not build.stderr.strip(), build.stderr[-2000:]     # no warnings either
+    for args in (['1', '200', '5000', '40'], ['1', '131', '20000', '30'], ['1', '700', '3000', '150']):
+        run = subprocess.run([exe] + args, capture_output=True, text=True, timeout=280)
+        assert run.returncode == 0 and run.stdout.strip().endswith('OK'), (args, run.stdout[-1500:], run.stderr[-1500:])
