@@ -208,6 +208,7 @@ void byz_ctx_destroy(byz_ctx* ctx) {
     ctx->near_partial.release();
     ctx->sorted_idx.release();
     ctx->rank_t.release();
+    ctx->rank_rows.release();
     ctx->sorted_val.release();
     ctx->row_total.release();
     ctx->row_top.release();
@@ -239,6 +240,7 @@ int byz_ctx_reserve(byz_ctx* ctx, int64_t n_rows, int64_t n_cols) {
     BYZ_TRY(ctx->selection.ensure(static_cast<size_t>(n_rows) * sizeof(int32_t)));
     BYZ_TRY(ctx->sorted_idx.ensure(static_cast<size_t>(n_rows) * n_rows * sizeof(uint16_t)));
     BYZ_TRY(ctx->rank_t.ensure(static_cast<size_t>(n_rows) * n_rows * sizeof(uint16_t)));
+    BYZ_TRY(ctx->rank_rows.ensure(static_cast<size_t>(n_rows) * n_rows * sizeof(uint16_t)));
     BYZ_TRY(ctx->row_total.ensure(static_cast<size_t>(n_rows) * sizeof(double)));
     BYZ_TRY(ctx->row_top.ensure(static_cast<size_t>(2 * n_rows) * sizeof(double)));
     BYZ_TRY(ctx->stage_out.ensure(static_cast<size_t>(n_cols) * 3 * sizeof(float)));

@@ -128,6 +128,7 @@ struct byz_ctx {
     byz::Buffer sorted_idx;      // n x n uint16: column index at every ascending rank
     byz::Buffer sorted_val;      // n x n fp32: every row's distances in ascending order (the reference-arithmetic re-score)
     byz::Buffer rank_t;          // n x n uint16: rank_t[w][u] = rank of column w in row u
+    byz::Buffer rank_rows;       // n x n uint16: the same table as the row sort writes it, rank_rows[u][w] (transposed into rank_t)
     byz::Buffer row_total;       // n fp64: sum of a row's finite distances
     byz::Buffer row_top;         // n fp64: sum of a row's largest `drop` finite distances; then n counts of non-finite ones
     byz::Buffer scores;          // n fp32 Krum scores

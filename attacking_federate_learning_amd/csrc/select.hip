@@ -46,13 +46,120 @@ __device__ __forceinline__ int visit_position(int u) { return u == 0 ? 1 : (u ==
 // (defined with the Bulyan re-score below; row_sort_kernel's Krum score uses it too)
 __device__ __forceinline__ float integer_passes(uint32_t (&M)[8], const int (&ex)[8], float s, int lane, unsigned long long& n_passes);
 
-template <bool TABLES>
+// ---- the row sort's bitonic network, register-blocked (round 6) ----------------------------------------------------------
+// The textbook form below (one compare-exchange level per pass over LDS, a barrier behind each) takes log2(n)(log2(n) + 1) / 2
+// passes: 105 at n_pad = 16,384, every one a full round trip of the 128 KB of keys through the LDS pipe -- 200 us per row, 7.9 ms
+// for the 10,000 rows of configs[4].  Here a work item takes 16 keys into registers and runs up to FOUR levels of the network
+// on them before they go back: for the merge of size k = 2^m the levels j = 2^(m-1) .. 1 are cut, from the bottom, into groups
+// of four (j = 8 .. 1 on 16 contiguous keys, j = 128 .. 16 on keys 16 apart, j = 2048 .. 256, ...; the top group takes the
+// levels that are left), and the merges k = 2 .. 16 are one pass: 32 passes instead of 105, the same compare-exchanges, the same
+// network -- the sorted order of the 64-bit keys is unique, so the result is the textbook form's bit for bit.  The direction of
+// a compare-exchange, (index & k) == 0, is uniform per work item from k = 16 on (k lies above every bit in which the item's
+// keys differ) and a compile-time function of the slot for k = 2, 4, 8 inside the first pass.
+// Layout: key i sits at word i + (i >> 4) (one word of padding per 16): a work item's 16 CONTIGUOUS keys then start 17 words
+// apart, so that the 64 lanes of a wave spread over all banks; with keys 16 or more apart the lanes of a wave read consecutive
+// words anyway.
+__device__ __forceinline__ int sort_slot(int i) { return i + (i >> 4); }
+
+__device__ __forceinline__ void compare_exchange(unsigned long long& a, unsigned long long& b, bool up) {
+    const bool swap = (a > b) == up;
+    const unsigned long long lo = swap ? b : a, hi = swap ? a : b;
+    a = lo;
+    b = hi;
+}
+
+// LV levels (strides 2^(LV-1) .. 1 in units of `stride` keys) of the merge of size k on the 2^LV keys base + s * stride
+template <int LV>
+__device__ __forceinline__ void sort_levels(unsigned long long* keys, int base, int stride, int k) {
+    constexpr int E = 1 << LV;
+    unsigned long long r[E];
+#pragma unroll
+    for (int s = 0; s < E; ++s) r[s] = keys[sort_slot(base + s * stride)];
+    const bool up = (base & k) == 0;       // k lies above every bit in which the item's keys differ
+#pragma unroll
+    for (int l = LV - 1; l >= 0; --l) {
+#pragma unroll
+        for (int s = 0; s < E; ++s) {
+            if ((s & (1 << l)) == 0) compare_exchange(r[s], r[s | (1 << l)], up);
+        }
+    }
+#pragma unroll
+    for (int s = 0; s < E; ++s) keys[sort_slot(base + s * stride)] = r[s];
+}
+
+// n_pad >= 256 keys (a power of two) at keys[sort_slot(i)], ascending; every thread of the workgroup calls it
+__device__ __forceinline__ void blocked_bitonic_sort(unsigned long long* keys, int n_pad, int tid, int nt) {
+    const int items = n_pad >> 4;
+    // merges k = 2 .. 16: 16 contiguous keys per item, every level in registers
+    for (int w = tid; w < items; w += nt) {
+        const int base = w << 4;
+        unsigned long long r[16];
+#pragma unroll
+        for (int s = 0; s < 16; ++s) r[s] = keys[sort_slot(base + s)];
+#pragma unroll
+        for (int kb = 1; kb <= 4; ++kb) {          // k = 2^kb
+#pragma unroll
+            for (int l = kb - 1; l >= 0; --l) {
+#pragma unroll
+                for (int s = 0; s < 16; ++s) {
+                    if ((s & (1 << l)) == 0) {
+                        const bool up = kb < 4 ? ((s & (1 << kb)) == 0) : ((base & 16) == 0);
+                        compare_exchange(r[s], r[s | (1 << l)], up);
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int s = 0; s < 16; ++s) keys[sort_slot(base + s)] = r[s];
+    }
+    __syncthreads();
+    for (int m = 5; (1 << m) <= n_pad; ++m) {       // the merge of size k = 2^m: levels j = 2^(m-1) .. 1
+        const int k = 1 << m;
+        int top = m;                                // levels still to do: j = 2^(top-1) .. 1
+        // the top group takes what is left above the groups of four
+        const int first = (m & 3) == 0 ? 4 : (m & 3);
+        {
+            const int lo = top - first;             // this group's smallest stride is 2^lo
+            const int stride = 1 << lo;
+            const int group_items = n_pad >> first;
+            for (int w = tid; w < group_items; w += nt) {
+                const int base = ((w >> lo) << (lo + first)) | (w & (stride - 1));
+                if (first == 4) sort_levels<4>(keys, base, stride, k);
+                else if (first == 3) sort_levels<3>(keys, base, stride, k);
+                else if (first == 2) sort_levels<2>(keys, base, stride, k);
+                else sort_levels<1>(keys, base, stride, k);
+            }
+            __syncthreads();
+            top = lo;
+        }
+        while (top > 0) {                           // groups of four levels: strides 2^(top-1) .. 2^(top-4)
+            const int lo = top - 4;
+            const int stride = 1 << lo;
+            for (int w = tid; w < items; w += nt) {
+                const int base = ((w >> lo) << (lo + 4)) | (w & (stride - 1));
+                sort_levels<4>(keys, base, stride, k);
+            }
+            __syncthreads();
+            top = lo;
+        }
+    }
+}
+
+// BLOCKED: the register-blocked network on the padded layout (n_pad >= 256); otherwise the textbook form
+template <bool TABLES, bool BLOCKED>
 __global__ void row_sort_kernel(const float* __restrict__ dist, int n, int n_pad, int prefix_len, int drop,
                                 float* __restrict__ scores, uint16_t* __restrict__ sorted_idx,
-                                uint16_t* __restrict__ rank_t, double* __restrict__ row_total,
+                                uint16_t* __restrict__ rank_rows, double* __restrict__ row_total,
                                 double* __restrict__ row_top, float* __restrict__ sorted_val) {
-    extern __shared__ __attribute__((aligned(16))) unsigned long long keys[];  // n_pad keys, then scratch
-    double* scratch = reinterpret_cast<double*>(keys + n_pad);                 // blockDim.x doubles
+    extern __shared__ __attribute__((aligned(16))) unsigned long long keys_raw[];  // n_pad keys (+ padding), then scratch
+    const int key_words = BLOCKED ? n_pad + (n_pad >> 4) : n_pad;
+    double* scratch = reinterpret_cast<double*>(keys_raw + key_words);           // blockDim.x doubles
+    // keys[i]: the i-th key, wherever the layout puts it
+    struct KeyArray {
+        unsigned long long* p;
+        __device__ __forceinline__ unsigned long long& operator[](int i) const { return p[BLOCKED ? sort_slot(i) : i]; }
+    };
+    const KeyArray keys{keys_raw};
     const int u = blockIdx.x;
     const int tid = threadIdx.x;
     const int nt = blockDim.x;
@@ -73,19 +180,23 @@ __global__ void row_sort_kernel(const float* __restrict__ dist, int n, int n_pad
     }
     __syncthreads();
 
-    for (int k = 2; k <= n_pad; k <<= 1) {
-        for (int j = k >> 1; j > 0; j >>= 1) {
-            for (int idx = tid; idx < (n_pad >> 1); idx += nt) {
-                const int i = ((idx & ~(j - 1)) << 1) | (idx & (j - 1));
-                const int p = i | j;
-                const unsigned long long a = keys[i], b = keys[p];
-                const bool up = (i & k) == 0;
-                if ((a > b) == up) {
-                    keys[i] = b;
-                    keys[p] = a;
+    if constexpr (BLOCKED) {
+        blocked_bitonic_sort(keys_raw, n_pad, tid, nt);
+    } else {
+        for (int k = 2; k <= n_pad; k <<= 1) {
+            for (int j = k >> 1; j > 0; j >>= 1) {
+                for (int idx = tid; idx < (n_pad >> 1); idx += nt) {
+                    const int i = ((idx & ~(j - 1)) << 1) | (idx & (j - 1));
+                    const int p = i | j;
+                    const unsigned long long a = keys[i], b = keys[p];
+                    const bool up = (i & k) == 0;
+                    if ((a > b) == up) {
+                        keys[i] = b;
+                        keys[p] = a;
+                    }
                 }
+                __syncthreads();
             }
-            __syncthreads();
         }
     }
     // The real neighbours occupy ranks 0 .. n-2 (a NaN with an all-ones payload could tie with the self entry's key; the
@@ -142,24 +253,50 @@ __global__ void row_sort_kernel(const float* __restrict__ dist, int n, int n_pad
         // tot / top are sums over the FINITE distances; the non-finite ones (+inf, NaN: a client whose gradient is not
         // finite) sort last and are counted -- a row's score is finite exactly while they all lie among its `drop` largest
         // entries, which is what the reference's sorted(...)[:k] sum gives for +inf (defences.py:33-34)
+        //
+        // The rank of every column in this row goes out as a ROW (rank_rows[u][c], contiguous) and rank_transpose_kernel turns
+        // the rows into rank_t[c][u] afterwards.  Round 6: written straight into rank_t, the ranks were 2-byte stores n entries
+        // apart -- N^2 of them, every one a partial line that 64 different workgroups touch at different times: 0.38 GB of
+        // fabric writes for 0.13 GB of tables at N = 4000 by the PMC, and what the kernel's time was made of (the sort itself
+        // was a third of it).  The row is staged in LDS over the key array: a thread first takes its keys into registers, and
+        // only when every thread has (and wave 0 has formed the score from the keys) do the ranks overwrite them.
+        constexpr int kMine = 16;                      // n <= 16,384 keys over >= n_pad / 16 threads
+        unsigned long long mine[kMine];
+#pragma unroll
+        for (int i = 0; i < kMine; ++i) {
+            const int r = tid + i * nt;
+            mine[i] = r < n ? keys[r] : ~0ull;
+        }
         double tot = 0.0, top = 0.0, bad = 0.0;
         const int first_top = n - 1 - drop;
-        for (int r = tid; r < n; r += nt) {
-            const unsigned long long key = keys[r];
-            const int c = static_cast<int>(key & 0xffffffffu);
-            sorted_idx[static_cast<int64_t>(u) * n + r] = static_cast<uint16_t>(c);
-            const float v = c == u ? __builtin_inff() : from_ordered_bits(static_cast<uint32_t>(key >> 32));
-            sorted_val[static_cast<int64_t>(u) * n + r] = v == 0.0f ? 0.0f : v;   // never -0.0: that bit pattern marks a removed entry
-            rank_t[static_cast<int64_t>(c) * n + u] = static_cast<uint16_t>(r);
-            if (c != u) {
-                if (__builtin_fabsf(v) <= 3.4028234663852886e38f) {
-                    tot += static_cast<double>(v);
-                    if (r >= first_top) top += static_cast<double>(v);
-                } else {
-                    bad += 1.0;
+#pragma unroll
+        for (int i = 0; i < kMine; ++i) {
+            const int r = tid + i * nt;
+            if (r < n) {
+                const unsigned long long key = mine[i];
+                const int c = static_cast<int>(key & 0xffffffffu);
+                sorted_idx[static_cast<int64_t>(u) * n + r] = static_cast<uint16_t>(c);
+                const float v = c == u ? __builtin_inff() : from_ordered_bits(static_cast<uint32_t>(key >> 32));
+                sorted_val[static_cast<int64_t>(u) * n + r] = v == 0.0f ? 0.0f : v;   // never -0.0: that bit pattern marks a removed entry
+                if (c != u) {
+                    if (__builtin_fabsf(v) <= 3.4028234663852886e38f) {
+                        tot += static_cast<double>(v);
+                        if (r >= first_top) top += static_cast<double>(v);
+                    } else {
+                        bad += 1.0;
+                    }
                 }
             }
         }
+        __syncthreads();     // every key is in a register and the score is formed: the key array is free
+        uint16_t* const rank_row = reinterpret_cast<uint16_t*>(keys_raw);
+#pragma unroll
+        for (int i = 0; i < kMine; ++i) {
+            const int r = tid + i * nt;
+            if (r < n) rank_row[static_cast<int>(mine[i] & 0xffffffffu)] = static_cast<uint16_t>(r);
+        }
+        __syncthreads();
+        for (int c = tid; c < n; c += nt) rank_rows[static_cast<int64_t>(u) * n + c] = rank_row[c];
         // fixed-shape tree: identical sorted rows reduce to identical sums
         scratch[tid] = tot;
         __syncthreads();
@@ -184,6 +321,24 @@ __global__ void row_sort_kernel(const float* __restrict__ dist, int n, int n_pad
             __syncthreads();
         }
         if (tid == 0) row_top[n + u] = scratch[0];   // the count of non-finite entries rides behind the n sums
+    }
+}
+
+// rank_t[c][u] = rank_rows[u][c]: 64 x 64 tiles through LDS, both sides in contiguous runs
+__global__ __launch_bounds__(256) void rank_transpose_kernel(const uint16_t* __restrict__ rank_rows, int n, uint16_t* __restrict__ rank_t) {
+    __shared__ uint16_t tile[64][66];
+    const int u0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int uu = u0 + ty + 4 * i, cc = c0 + tx;
+        if (uu < n && cc < n) tile[ty + 4 * i][tx] = rank_rows[static_cast<int64_t>(uu) * n + cc];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int cc = c0 + ty + 4 * i, uu = u0 + tx;
+        if (uu < n && cc < n) rank_t[static_cast<int64_t>(cc) * n + uu] = tile[tx][ty + 4 * i];
     }
 }
 
@@ -1567,24 +1722,47 @@ int launch_row_sort(byz_ctx* ctx, const float* dist, int64_t n, int64_t prefix_l
     if (want_tables) {
         BYZ_TRY(ctx->sorted_idx.ensure(static_cast<size_t>(n) * n * sizeof(uint16_t)));
         BYZ_TRY(ctx->rank_t.ensure(static_cast<size_t>(n) * n * sizeof(uint16_t)));
+        BYZ_TRY(ctx->rank_rows.ensure(static_cast<size_t>(n) * n * sizeof(uint16_t)));
         BYZ_TRY(ctx->row_total.ensure(static_cast<size_t>(n) * sizeof(double)));
         BYZ_TRY(ctx->row_top.ensure(static_cast<size_t>(2 * n) * sizeof(double)));   // sums, then the counts of non-finite entries
         BYZ_TRY(ctx->sorted_val.ensure(static_cast<size_t>(n) * n * sizeof(float) + 64));   // (+ 64: a re-score reads 8 dwords per lane)
     }
-    const size_t lds = static_cast<size_t>(n_pad) * 8 + static_cast<size_t>(threads) * 8;
+    // BYZ_ROW_SORT_BLOCKED=0: the textbook network (one level per pass over LDS) for every size -- the same-box A/B and the
+    // bitwise comparison (tests/test_gpu_round4.py); default: the register-blocked network from 256 keys
+    static const bool allow_blocked = [] {
+        const char* e = std::getenv("BYZ_ROW_SORT_BLOCKED");
+        return e == nullptr || std::atoi(e) != 0;
+    }();
+    const char* e_now = std::getenv("BYZ_ROW_SORT_BLOCKED");     // (re-read per call: the tests flip it inside one process)
+    const bool blocked = (e_now != nullptr ? std::atoi(e_now) != 0 : allow_blocked) && n_pad >= 256;
+    // the blocked network keeps 16 keys per thread: one thread per work item, so that a CU holds several rows at once below
+    // 16,384 keys (4 at 4096: the network's compare-exchange chains are latency, and four waves per row leave a CU idle)
+    if (blocked) threads = static_cast<int>(n_pad / 16 < 64 ? 64 : n_pad / 16);
+    const size_t key_words = blocked ? static_cast<size_t>(n_pad + (n_pad >> 4)) : static_cast<size_t>(n_pad);
+    const size_t lds = key_words * 8 + static_cast<size_t>(threads) * 8;
     KernelTimer t(ctx, BYZ_K_ROW_SORT, stream);
+#define BYZ_ROW_SORT(TB, BL, ...)                                                                                       \
+    do {                                                                                                                \
+        BYZ_HIP(allow_dynamic_lds(ctx, reinterpret_cast<const void*>(&row_sort_kernel<TB, BL>), static_cast<int>(lds))); \
+        row_sort_kernel<TB, BL><<<static_cast<unsigned>(n), threads, lds, stream>>>(                                     \
+            dist, (int)n, (int)n_pad, (int)prefix_len, (int)drop_count, ctx->scores.as<float>(), __VA_ARGS__);           \
+    } while (0)
     if (want_tables) {
-        BYZ_HIP(allow_dynamic_lds(ctx, reinterpret_cast<const void*>(&row_sort_kernel<true>), static_cast<int>(lds)));
-        row_sort_kernel<true><<<static_cast<unsigned>(n), threads, lds, stream>>>(
-            dist, (int)n, (int)n_pad, (int)prefix_len, (int)drop_count, ctx->scores.as<float>(),
-            ctx->sorted_idx.as<uint16_t>(), ctx->rank_t.as<uint16_t>(), ctx->row_total.as<double>(),
-            ctx->row_top.as<double>(), ctx->sorted_val.as<float>());
+        if (blocked)
+            BYZ_ROW_SORT(true, true, ctx->sorted_idx.as<uint16_t>(), ctx->rank_rows.as<uint16_t>(), ctx->row_total.as<double>(),
+                         ctx->row_top.as<double>(), ctx->sorted_val.as<float>());
+        else
+            BYZ_ROW_SORT(true, false, ctx->sorted_idx.as<uint16_t>(), ctx->rank_rows.as<uint16_t>(), ctx->row_total.as<double>(),
+                         ctx->row_top.as<double>(), ctx->sorted_val.as<float>());
+        BYZ_TRY(check_launch("row_sort_kernel"));
+        const unsigned tiles = static_cast<unsigned>(ceil_div(n, 64));
+        rank_transpose_kernel<<<dim3(tiles, tiles), 256, 0, stream>>>(ctx->rank_rows.as<uint16_t>(), (int)n, ctx->rank_t.as<uint16_t>());
+        return check_launch("rank_transpose_kernel");
     } else {
-        BYZ_HIP(allow_dynamic_lds(ctx, reinterpret_cast<const void*>(&row_sort_kernel<false>), static_cast<int>(lds)));
-        row_sort_kernel<false><<<static_cast<unsigned>(n), threads, lds, stream>>>(
-            dist, (int)n, (int)n_pad, (int)prefix_len, (int)drop_count, ctx->scores.as<float>(), nullptr,
-            nullptr, nullptr, nullptr, nullptr);
+        if (blocked) BYZ_ROW_SORT(false, true, nullptr, nullptr, nullptr, nullptr, nullptr);
+        else BYZ_ROW_SORT(false, false, nullptr, nullptr, nullptr, nullptr, nullptr);
     }
+#undef BYZ_ROW_SORT
     return check_launch("row_sort_kernel");
 }
 
