@@ -61,56 +61,84 @@ __device__ __forceinline__ float integer_passes(uint32_t (&M)[8], const int (&ex
 // words anyway.
 __device__ __forceinline__ int sort_slot(int i) { return i + (i >> 4); }
 
-__device__ __forceinline__ void compare_exchange(unsigned long long& a, unsigned long long& b, bool up) {
-    const bool swap = (a > b) == up;
-    const unsigned long long lo = swap ? b : a, hi = swap ? a : b;
+// Inside the network a key is a DOUBLE: (order-preserving float bits << 16 | column) is an integer below 2^48, exact in a
+// double, and doubles of one sign order like their integers -- so a compare-exchange is v_min_f64 + v_max_f64 (full rate on this
+// part) instead of a 64-bit compare and four selects, which is what bounded the network on 64-bit integer keys (five vector
+// instructions per compare-exchange, 860,000 of them per row at 16,384 keys).  A work item that sorts DESCENDING flips the sign
+// of its keys on the way in and out (one xor per key) and sorts ascending in between.
+__device__ __forceinline__ double key_to_double(uint32_t ordered, uint32_t column) {
+    return static_cast<double>((static_cast<unsigned long long>(ordered) << 16) | column);
+}
+__device__ __forceinline__ unsigned long long double_to_key(double d) {     // -> ordered bits << 32 | column
+    const unsigned long long x = static_cast<unsigned long long>(d);
+    return ((x >> 16) << 32) | (x & 0xffffull);
+}
+__device__ __forceinline__ void compare_exchange_up(double& a, double& b) {
+    double lo, hi;
+    asm("v_min_f64 %0, %1, %2" : "=v"(lo) : "v"(a), "v"(b));
+    asm("v_max_f64 %0, %1, %2" : "=v"(hi) : "v"(a), "v"(b));
     a = lo;
     b = hi;
+}
+__device__ __forceinline__ double flip_sign(double v, bool flip) {
+    return __longlong_as_double(__double_as_longlong(v) ^ (flip ? static_cast<long long>(0x8000000000000000ull) : 0ll));
 }
 
 // LV levels (strides 2^(LV-1) .. 1 in units of `stride` keys) of the merge of size k on the 2^LV keys base + s * stride
 template <int LV>
-__device__ __forceinline__ void sort_levels(unsigned long long* keys, int base, int stride, int k) {
+__device__ __forceinline__ void sort_levels(double* keys, int base, int stride, int k) {
     constexpr int E = 1 << LV;
-    unsigned long long r[E];
+    double r[E];
+    const bool down = (base & k) != 0;       // k lies above every bit in which the item's keys differ
 #pragma unroll
-    for (int s = 0; s < E; ++s) r[s] = keys[sort_slot(base + s * stride)];
-    const bool up = (base & k) == 0;       // k lies above every bit in which the item's keys differ
+    for (int s = 0; s < E; ++s) r[s] = flip_sign(keys[sort_slot(base + s * stride)], down);
 #pragma unroll
     for (int l = LV - 1; l >= 0; --l) {
 #pragma unroll
         for (int s = 0; s < E; ++s) {
-            if ((s & (1 << l)) == 0) compare_exchange(r[s], r[s | (1 << l)], up);
+            if ((s & (1 << l)) == 0) compare_exchange_up(r[s], r[s | (1 << l)]);
         }
     }
 #pragma unroll
-    for (int s = 0; s < E; ++s) keys[sort_slot(base + s * stride)] = r[s];
+    for (int s = 0; s < E; ++s) keys[sort_slot(base + s * stride)] = flip_sign(r[s], down);
 }
 
-// n_pad >= 256 keys (a power of two) at keys[sort_slot(i)], ascending; every thread of the workgroup calls it
-__device__ __forceinline__ void blocked_bitonic_sort(unsigned long long* keys, int n_pad, int tid, int nt) {
+// n_pad >= 256 keys (a power of two) as doubles at keys[sort_slot(i)]: sorted ascending and left as 64-bit integer keys
+// (order-preserving float bits << 32 | column); every thread of the workgroup calls it
+__device__ __forceinline__ void blocked_bitonic_sort(unsigned long long* keys_u64, int n_pad, int tid, int nt) {
+    double* const keys = reinterpret_cast<double*>(keys_u64);
     const int items = n_pad >> 4;
     // merges k = 2 .. 16: 16 contiguous keys per item, every level in registers
     for (int w = tid; w < items; w += nt) {
         const int base = w << 4;
-        unsigned long long r[16];
+        double r[16];
 #pragma unroll
         for (int s = 0; s < 16; ++s) r[s] = keys[sort_slot(base + s)];
 #pragma unroll
-        for (int kb = 1; kb <= 4; ++kb) {          // k = 2^kb
+        for (int kb = 1; kb <= 3; ++kb) {          // k = 2, 4, 8: the direction is a compile-time function of the slot
 #pragma unroll
             for (int l = kb - 1; l >= 0; --l) {
 #pragma unroll
                 for (int s = 0; s < 16; ++s) {
                     if ((s & (1 << l)) == 0) {
-                        const bool up = kb < 4 ? ((s & (1 << kb)) == 0) : ((base & 16) == 0);
-                        compare_exchange(r[s], r[s | (1 << l)], up);
+                        if ((s & (1 << kb)) == 0) compare_exchange_up(r[s], r[s | (1 << l)]);
+                        else compare_exchange_up(r[s | (1 << l)], r[s]);
                     }
                 }
             }
         }
+        const bool down = (base & 16) != 0;        // k = 16
 #pragma unroll
-        for (int s = 0; s < 16; ++s) keys[sort_slot(base + s)] = r[s];
+        for (int s = 0; s < 16; ++s) r[s] = flip_sign(r[s], down);
+#pragma unroll
+        for (int l = 3; l >= 0; --l) {
+#pragma unroll
+            for (int s = 0; s < 16; ++s) {
+                if ((s & (1 << l)) == 0) compare_exchange_up(r[s], r[s | (1 << l)]);
+            }
+        }
+#pragma unroll
+        for (int s = 0; s < 16; ++s) keys[sort_slot(base + s)] = flip_sign(r[s], down);
     }
     __syncthreads();
     for (int m = 5; (1 << m) <= n_pad; ++m) {       // the merge of size k = 2^m: levels j = 2^(m-1) .. 1
@@ -143,6 +171,15 @@ __device__ __forceinline__ void blocked_bitonic_sort(unsigned long long* keys, i
             top = lo;
         }
     }
+    // back to integer keys for everything behind the sort
+    for (int w = tid; w < items; w += nt) {
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+            const int at = sort_slot((w << 4) + s);
+            keys_u64[at] = double_to_key(keys[at]);
+        }
+    }
+    __syncthreads();
 }
 
 // BLOCKED: the register-blocked network on the padded layout (n_pad >= 256); otherwise the textbook form
@@ -176,7 +213,13 @@ __global__ void row_sort_kernel(const float* __restrict__ dist, int n, int n_pad
             const uint32_t ob = (c == u) ? 0xffffffffu : (d != d ? 0xfffffffeu : ordered_bits(d));
             key = (static_cast<unsigned long long>(ob) << 32) | static_cast<unsigned>(c);
         }
-        keys[c] = key;
+        if constexpr (BLOCKED) {
+            // (the network sorts doubles: see key_to_double; a padding key's column is 0xffff, above every real column)
+            const double as_double = key_to_double(static_cast<uint32_t>(key >> 32), c >= n ? 0xffffu : static_cast<uint32_t>(c));
+            keys_raw[sort_slot(c)] = static_cast<unsigned long long>(__double_as_longlong(as_double));
+        } else {
+            keys[c] = key;
+        }
     }
     __syncthreads();
 
