@@ -54,16 +54,26 @@ __global__ __launch_bounds__(256) void row_signature_kernel(const float* __restr
 __global__ __launch_bounds__(256) void candidate_kernel(const uint64_t* __restrict__ signature, int n,
                                                         int32_t* __restrict__ rep, int32_t* __restrict__ mismatch,
                                                         int32_t* __restrict__ candidates, int32_t* __restrict__ n_candidates) {
+    // (Round 6: the signatures of the rows in front pass through LDS a tile at a time and every thread looks at all of a tile.  The
+    // first form walked signature[0 .. i) out of global memory with a break at the first match -- a chain of dependent loads as
+    // long as the row index: 0.37 ms at N = 4000, a millisecond at 10,000, for a kernel that compares n^2 / 2 words.)
+    __shared__ uint64_t tile[256];
     const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
-    const uint64_t mine = signature[i];
+    const uint64_t mine = i < n ? signature[i] : 0ull;
     int r = i;
-    for (int j = 0; j < i; ++j) {
-        if (signature[j] == mine) {
-            r = j;
-            break;
+    const int last = blockIdx.x * 256 + 255;          // the workgroup's largest row index: tiles beyond it hold no row in front
+    for (int j0 = 0; j0 <= last && j0 < n; j0 += 256) {
+        tile[threadIdx.x] = j0 + threadIdx.x < n ? signature[j0 + threadIdx.x] : 0ull;
+        __syncthreads();
+        const int m = n - j0 < 256 ? n - j0 : 256;
+#pragma unroll 8
+        for (int j = 0; j < m; ++j) {
+            const int cand = j0 + j;
+            if (tile[j] == mine && cand < r) r = cand;      // the smallest index with this signature (r starts at i: only rows in front)
         }
+        __syncthreads();
     }
+    if (i >= n) return;
     rep[i] = r;
     mismatch[i] = 0;
     if (r != i) candidates[atomicAdd(n_candidates, 1)] = i;   // the order of the list does not matter

@@ -1307,13 +1307,17 @@ constexpr int kSpecTable = 512;                    // (pick, twin class) -> lead
 // that holds members, so it should sit in few.  All other rows are dealt over the slots behind them thread index by thread index,
 // workgroup by workgroup, in the order of their first scores (T - Top, ties by index): the rows that contend are neighbours in that order.
 // Slots without a row hold n.
+// A workgroup = 64 rows x 4 waves: wave p counts a quarter of every tile of 256 rows for all 64 (round 6's last session: one
+// thread per row walked all n rows alone -- 0.44 ms at N = 4000 on 16 CUs; the counts are integers, any split gives the same).
 __global__ __launch_bounds__(kGridThreads) void spec_owner_kernel(const double* __restrict__ row_total, const double* __restrict__ row_top,
                                                                   const int32_t* __restrict__ cls, int n, int drop, int n_wgs,
                                                                   int32_t* __restrict__ owner) {
+    static_assert(kGridThreads == 256, "four waves per workgroup");
     __shared__ double tile[kGridThreads];
     __shared__ int copy[kGridThreads];
-    const int tid = threadIdx.x;
-    const int u = blockIdx.x * kGridThreads + tid;
+    __shared__ int sums[3][64];
+    const int tid = threadIdx.x, lane = tid & 63, part = tid >> 6;
+    const int u = blockIdx.x * 64 + lane;
     auto first_score = [&](int v) -> double {
         if (v >= n) return __builtin_inf();
         const double s = row_total[v] - (drop > 0 ? row_top[v] : 0.0);
@@ -1322,12 +1326,15 @@ __global__ __launch_bounds__(kGridThreads) void spec_owner_kernel(const double* 
     const double su = first_score(u);
     const bool u_copy = u < n && cls[u] != u;
     int rank = 0, copies = 0, copies_before = 0;
+    if (tid < 64) sums[0][tid] = sums[1][tid] = sums[2][tid] = 0;
     for (int v0 = 0; v0 < n; v0 += kGridThreads) {
         tile[tid] = first_score(v0 + tid);
         copy[tid] = (v0 + tid < n && cls[v0 + tid] != v0 + tid) ? 1 : 0;
         __syncthreads();
         const int m = n - v0 < kGridThreads ? n - v0 : kGridThreads;
-        for (int j = 0; j < m; ++j) {
+        const int j_end = 64 * part + 64 < m ? 64 * part + 64 : m;
+#pragma unroll 8
+        for (int j = 64 * part; j < j_end; ++j) {
             const double sv = tile[j];
             const int cj = copy[j];
             copies += cj;
@@ -1336,7 +1343,14 @@ __global__ __launch_bounds__(kGridThreads) void spec_owner_kernel(const double* 
         }
         __syncthreads();
     }
-    if (u >= n) return;
+    atomicAdd(&sums[0][lane], rank);
+    atomicAdd(&sums[1][lane], copies);
+    atomicAdd(&sums[2][lane], copies_before);
+    __syncthreads();
+    if (part != 0 || u >= n) return;
+    rank = sums[0][lane];
+    copies = sums[1][lane];
+    copies_before = sums[2][lane];
     if (u_copy) {
         owner[copies_before] = u;
         return;
@@ -1772,12 +1786,8 @@ int launch_row_sort(byz_ctx* ctx, const float* dist, int64_t n, int64_t prefix_l
     }
     // BYZ_ROW_SORT_BLOCKED=0: the textbook network (one level per pass over LDS) for every size -- the same-box A/B and the
     // bitwise comparison (tests/test_gpu_round4.py); default: the register-blocked network from 256 keys
-    static const bool allow_blocked = [] {
-        const char* e = std::getenv("BYZ_ROW_SORT_BLOCKED");
-        return e == nullptr || std::atoi(e) != 0;
-    }();
-    const char* e_now = std::getenv("BYZ_ROW_SORT_BLOCKED");     // (re-read per call: the tests flip it inside one process)
-    const bool blocked = (e_now != nullptr ? std::atoi(e_now) != 0 : allow_blocked) && n_pad >= 256;
+    const char* e_blocked = std::getenv("BYZ_ROW_SORT_BLOCKED");     // (read per call: the tests flip it inside one process)
+    const bool blocked = (e_blocked == nullptr || std::atoi(e_blocked) != 0) && n_pad >= 256;
     // the blocked network keeps 16 keys per thread: one thread per work item, so that a CU holds several rows at once below
     // 16,384 keys (4 at 4096: the network's compare-exchange chains are latency, and four waves per row leave a CU idle)
     if (blocked) threads = static_cast<int>(n_pad / 16 < 64 ? 64 : n_pad / 16);
@@ -1877,8 +1887,8 @@ int launch_bulyan_loop(byz_ctx* ctx, const float* dist, int64_t n, int64_t theta
         // BYZ_BULYAN_DEAL=0: slot (g, i) owns row 256 g + i (the comparison)
         const char* deal_env = std::getenv("BYZ_BULYAN_DEAL");
         if (deal_env == nullptr || std::atoi(deal_env) != 0) {
-            spec_owner_kernel<<<n_wgs, kGridThreads, 0, stream>>>(ctx->row_total.as<double>(), ctx->row_top.as<double>(), cls, (int)n,
-                                                                  (int)drop_count, (int)n_wgs, owner);
+            spec_owner_kernel<<<static_cast<unsigned>(ceil_div(n, 64)), kGridThreads, 0, stream>>>(
+                ctx->row_total.as<double>(), ctx->row_top.as<double>(), cls, (int)n, (int)drop_count, (int)n_wgs, owner);
         } else {
             spec_identity_kernel<<<n_wgs, kGridThreads, 0, stream>>>((int)n, owner);
         }
