@@ -207,6 +207,10 @@ void byz_ctx_destroy(byz_ctx* ctx) {
     ctx->near_sq.release();
     ctx->near_partial.release();
     ctx->sorted_idx.release();
+    ctx->large_keys.release();
+    ctx->large_idx.release();
+    ctx->large_rank.release();
+    ctx->large_state.release();
     ctx->rank_t.release();
     ctx->rank_rows.release();
     ctx->sorted_val.release();
@@ -238,9 +242,11 @@ int byz_ctx_reserve(byz_ctx* ctx, int64_t n_rows, int64_t n_cols) {
     BYZ_TRY(ensure_distance_workspaces(ctx, n_rows));
     BYZ_TRY(ctx->scores.ensure(static_cast<size_t>(n_rows) * sizeof(float)));
     BYZ_TRY(ctx->selection.ensure(static_cast<size_t>(n_rows) * sizeof(int32_t)));
-    BYZ_TRY(ctx->sorted_idx.ensure(static_cast<size_t>(n_rows) * n_rows * sizeof(uint16_t)));
-    BYZ_TRY(ctx->rank_t.ensure(static_cast<size_t>(n_rows) * n_rows * sizeof(uint16_t)));
-    BYZ_TRY(ctx->rank_rows.ensure(static_cast<size_t>(n_rows) * n_rows * sizeof(uint16_t)));
+    if (!select_large_applies(n_rows)) {   // (beyond 16,384 rows the selection grows its own tables: large_rows.hip)
+        BYZ_TRY(ctx->sorted_idx.ensure(static_cast<size_t>(n_rows) * n_rows * sizeof(uint16_t)));
+        BYZ_TRY(ctx->rank_t.ensure(static_cast<size_t>(n_rows) * n_rows * sizeof(uint16_t)));
+        BYZ_TRY(ctx->rank_rows.ensure(static_cast<size_t>(n_rows) * n_rows * sizeof(uint16_t)));
+    }
     BYZ_TRY(ctx->row_total.ensure(static_cast<size_t>(n_rows) * sizeof(double)));
     BYZ_TRY(ctx->row_top.ensure(static_cast<size_t>(2 * n_rows) * sizeof(double)));
     BYZ_TRY(ctx->stage_out.ensure(static_cast<size_t>(n_cols) * 3 * sizeof(float)));

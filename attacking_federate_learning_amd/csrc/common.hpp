@@ -132,6 +132,11 @@ struct byz_ctx {
     byz::Buffer row_total;       // n fp64: sum of a row's finite distances
     byz::Buffer row_top;         // n fp64: sum of a row's largest `drop` finite distances; then n counts of non-finite ones
     byz::Buffer scores;          // n fp32 Krum scores
+    // large_rows.hip: more than 16,384 rows
+    byz::Buffer large_keys;      // 64-bit sort keys of one batch of rows / columns
+    byz::Buffer large_idx;       // n x n uint32: column index at every ascending rank
+    byz::Buffer large_rank;      // n x n uint32: rank of column w in row u, [u][w]
+    byz::Buffer large_state;     // the Bulyan loop's per-row state
     bool redo_valid = false;     // the last trimmed mean went through the ring selection (redo_tiles[0] is its count)
     byz::Buffer redo_tiles;      // trimmed mean: tiles the ring selection handed to the general kernel (count first)
     byz::Buffer twin_class;      // 2n int32: twin class of every row (scratch, then final)
@@ -277,9 +282,22 @@ int launch_bulyan_loop(byz_ctx* ctx, const float* dist, int64_t n, int64_t theta
                        int64_t users_count, int64_t corrupted, int32_t* selection_dev, int32_t* status_dev,
                        hipStream_t stream);
 
+// large_rows.hip: beyond the LDS-resident kernels' 16,384 rows (BYZ_SELECT_LARGE=1 / BYZ_TM_LARGE=1 take these paths at any size)
+constexpr int64_t kLargeMaxRows = int64_t{1} << 20;
+bool select_large_applies(int64_t n);
+int segment_sort_u64(byz_ctx* ctx, unsigned long long* keys, int64_t n_segments, int64_t n_pad, hipStream_t stream);
+size_t large_key_scratch_bytes();
+int launch_row_sort_large(byz_ctx* ctx, const float* dist, int64_t n, int64_t prefix_len, int64_t drop_count, bool want_tables,
+                          hipStream_t stream);
+int launch_bulyan_loop_large(byz_ctx* ctx, const float* dist, int64_t n, int64_t theta, int64_t drop_count, int64_t users_count,
+                             int64_t corrupted, int32_t* selection_dev, int32_t* status_dev, hipStream_t stream);
+
 int launch_trimmed_mean(byz_ctx* ctx, const float* G, int64_t n_rows, int64_t n_cols, int64_t ld,
                         const int32_t* row_index, int64_t keep, float* out, hipStream_t stream);
 int64_t trimmed_mean_max_rows();
+bool trimmed_mean_large_applies(int64_t n_rows);
+int launch_trimmed_mean_large(byz_ctx* ctx, const float* G, int64_t n_rows, int64_t n_cols, int64_t ld, const int32_t* row_index,
+                              int64_t keep, float* out, hipStream_t stream);
 // window_lean.hip: the row-split ring selection, first stage of the trimmed mean (round 3)
 int launch_window_lean(byz_ctx* ctx, const float* G, int64_t n_rows, int64_t n_cols, int64_t ld, const int32_t* row_index,
                        int64_t keep, float* out, int32_t* redo, hipStream_t stream);

@@ -944,6 +944,7 @@ int launch_trimmed_mean(byz_ctx* ctx, const float* G, int64_t n_rows, int64_t n_
     BYZ_REQUIRE(ceil_div(n_cols, kCols) <= 0x7fffffff, "trimmed_mean: too many columns");
     KernelTimer t(ctx, BYZ_K_TRIMMED_MEAN, stream);
     ctx->redo_valid = false;
+    if (trimmed_mean_large_applies(n_rows)) return launch_trimmed_mean_large(ctx, G, n_rows, n_cols, ld, row_index, keep, out, stream);
     const int64_t rpl = ceil_div(n_rows, 64);
     if (rpl > 88) return launch_trimmed_mean_sorted(ctx, G, n_rows, n_cols, ld, row_index, keep, out, stream);
     // the ring selection (window_lean.hip) with this file's general kernel behind it: 129 .. 5376 rows

@@ -1762,15 +1762,23 @@ __global__ __launch_bounds__(kSpecThreads) void bulyan_spec_kernel(
 
 }  // namespace
 
-int64_t select_max_rows() { return kMaxSelectRows; }
+int64_t select_max_rows() { return kLargeMaxRows; }
+
+// beyond the LDS-resident row sort and the 64 workgroups of the grid loop: large_rows.hip (BYZ_SELECT_LARGE=1: at every size, the tests)
+bool select_large_applies(int64_t n) {
+    if (n > kMaxSelectRows) return true;
+    const char* e = std::getenv("BYZ_SELECT_LARGE");     // (read per call: the tests flip it inside one process)
+    return e != nullptr && std::atoi(e) != 0;
+}
 
 int launch_row_sort(byz_ctx* ctx, const float* dist, int64_t n, int64_t prefix_len, int64_t drop_count,
                     bool want_tables, hipStream_t stream) {
     BYZ_REQUIRE(dist && n > 0, "row sort: bad arguments");
-    if (n > kMaxSelectRows) {
-        set_error("selection kernels support at most %d rows, got %lld", kMaxSelectRows, (long long)n);
+    if (n > kLargeMaxRows) {
+        set_error("selection kernels support at most %lld rows, got %lld", (long long)kLargeMaxRows, (long long)n);
         return BYZ_E_UNSUPPORTED;
     }
+    if (select_large_applies(n)) return launch_row_sort_large(ctx, dist, n, prefix_len, drop_count, want_tables, stream);
     int64_t n_pad = next_pow2(n);
     if (n_pad < 128) n_pad = 128;
     int threads = static_cast<int>(n_pad / 2);
@@ -1830,6 +1838,8 @@ int launch_bulyan_loop(byz_ctx* ctx, const float* dist, int64_t n, int64_t theta
                        hipStream_t stream) {
     BYZ_REQUIRE(dist && selection_dev && status_dev && n > 0 && theta >= 0 && theta <= n,
                 "bulyan loop: bad arguments (n=%lld theta=%lld)", (long long)n, (long long)theta);
+    if (select_large_applies(n))
+        return launch_bulyan_loop_large(ctx, dist, n, theta, drop_count, users_count, corrupted, selection_dev, status_dev, stream);
     BYZ_TRY(ctx->twin_class.ensure(static_cast<size_t>(2 * n) * sizeof(int32_t)));
     // granules: [2][A, B, R][64 workgroups], then the speculative loop's [2][32 picks of a batch][64], then its three counters
     constexpr size_t kGranules = static_cast<size_t>(2 * 3 + 2 * kSpecMax) * kGridMaxWgs;

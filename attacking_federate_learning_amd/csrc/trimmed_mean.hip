@@ -31,6 +31,8 @@
 
 #include "lane_exchange.hpp"
 
+#include <cstdlib>
+
 namespace byz {
 namespace {
 
@@ -239,6 +241,62 @@ __global__ __launch_bounds__(1024) void trimmed_mean_lds_kernel(const float* __r
     }
 }
 
+// ---- more than 16,384 rows: the columns sorted in global memory (large_rows.hip's segment sort), the same window code ----
+// Keys: order-preserving float bits << 32 | row; padding rows are all-ones keys behind every value, NaN included.
+__device__ __forceinline__ uint32_t ordered_bits(float v) {
+    const uint32_t b = __float_as_uint(v);
+    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+__device__ __forceinline__ float from_ordered_bits(uint32_t o) {     // (branch-free: a select here crashes this compiler's ISel)
+    return __uint_as_float(o ^ (~static_cast<uint32_t>(static_cast<int32_t>(o) >> 31) | 0x80000000u));
+}
+
+// column (c0 + blockIdx.y) of the batch; a column beyond the matrix is filled with zeros (its quad's other columns are real)
+__global__ __launch_bounds__(256) void large_column_keys_kernel(const float* __restrict__ G, int n_rows, int64_t n_pad, int64_t c0,
+                                                                int64_t n_cols, int64_t ld, const int32_t* __restrict__ row_index,
+                                                                unsigned long long* __restrict__ keys) {
+    const int64_t r = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
+    if (r >= n_pad) return;
+    const int64_t c = c0 + blockIdx.y;
+    unsigned long long key = ~0ull;
+    if (r < n_rows) {
+        const int64_t src = row_index ? row_index[r] : r;
+        const float v = c < n_cols ? G[src * ld + c] : 0.0f;
+        key = (static_cast<unsigned long long>(ordered_bits(v)) << 32) | static_cast<unsigned>(r);
+    }
+    keys[static_cast<int64_t>(blockIdx.y) * n_pad + r] = key;
+}
+
+struct SortedKeyQuad {
+    const unsigned long long* base;   // four columns of n_pad sorted keys each
+    int64_t n_pad;
+    __device__ __forceinline__ f32x4 at(int rank) const {
+        return f32x4{from_ordered_bits(static_cast<uint32_t>(base[rank] >> 32)),
+                     from_ordered_bits(static_cast<uint32_t>(base[n_pad + rank] >> 32)),
+                     from_ordered_bits(static_cast<uint32_t>(base[2 * n_pad + rank] >> 32)),
+                     from_ordered_bits(static_cast<uint32_t>(base[3 * n_pad + rank] >> 32))};
+    }
+};
+
+// one wave per quad of columns
+__global__ __launch_bounds__(64) void large_window_kernel(const unsigned long long* __restrict__ keys, int64_t n_pad,
+                                                          const float* __restrict__ G, int64_t ld,
+                                                          const int32_t* __restrict__ row_index, int n_rows, int keep, int64_t c0,
+                                                          int64_t n_cols, float* __restrict__ out) {
+    const int lane = threadIdx.x;
+    const int64_t c = c0 + 4 * static_cast<int64_t>(blockIdx.x);
+    const SortedKeyQuad sorted{keys + 4 * static_cast<int64_t>(blockIdx.x) * n_pad, n_pad};
+    const WindowArgs args{G, ld, row_index, n_rows, keep, c, n_cols < c + 4 ? n_cols : c + 4};
+    window_mean(sorted, args, lane, out);
+    // a NaN anywhere in the column: np.median is NaN and so is everything after it.  By the keys a NaN sorts to one of the
+    // two ends (sign bit set: first, clear: last)
+    if (lane < 4 && c + lane < n_cols) {
+        const uint32_t first = __float_as_uint(from_ordered_bits(static_cast<uint32_t>(sorted.base[lane * n_pad] >> 32)));
+        const uint32_t last = __float_as_uint(from_ordered_bits(static_cast<uint32_t>(sorted.base[lane * n_pad + n_rows - 1] >> 32)));
+        if ((first & 0x7fffffffu) > 0x7f800000u || (last & 0x7fffffffu) > 0x7f800000u) out[c + lane] = __uint_as_float(0x7fc00000u);
+    }
+}
+
 __global__ void lane_selftest_kernel(int32_t* __restrict__ out) {
     const int lane = threadIdx.x & 63;
     const int masks[11] = {1, 2, 3, 4, 7, 8, 15, 16, 31, 32, 63};
@@ -249,7 +307,42 @@ __global__ void lane_selftest_kernel(int32_t* __restrict__ out) {
 
 }  // namespace
 
-int64_t trimmed_mean_max_rows() { return kGeneralMaxRows; }
+int64_t trimmed_mean_max_rows() { return kLargeMaxRows; }
+
+bool trimmed_mean_large_applies(int64_t n_rows) {
+    if (n_rows > kGeneralMaxRows) return true;
+    const char* e = std::getenv("BYZ_TM_LARGE");     // (read per call: the tests flip it inside one process)
+    return e != nullptr && std::atoi(e) != 0;
+}
+
+// defences.py:44-52 for any number of rows: batches of columns, each column's values sorted as 64-bit keys in global memory,
+// the window found from the sorted column exactly as the LDS kernel below finds it
+int launch_trimmed_mean_large(byz_ctx* ctx, const float* G, int64_t n_rows, int64_t n_cols, int64_t ld, const int32_t* row_index,
+                              int64_t keep, float* out, hipStream_t stream) {
+    if (n_rows > kLargeMaxRows) {
+        set_error("trimmed_mean supports at most %lld rows, got %lld", (long long)kLargeMaxRows, (long long)n_rows);
+        return BYZ_E_UNSUPPORTED;
+    }
+    const int64_t n_pad = next_pow2(n_rows < 2 ? 2 : n_rows);
+    int64_t batch = static_cast<int64_t>(large_key_scratch_bytes() / (static_cast<size_t>(n_pad) * 8)) & ~int64_t{3};
+    if (batch < 4) batch = 4;
+    if (batch > 32768) batch = 32768;                       // (the keys kernel's grid.y)
+    const int64_t cols4 = ceil_div(n_cols, 4) * 4;
+    if (batch > cols4) batch = cols4;
+    BYZ_TRY(ctx->large_keys.ensure(static_cast<size_t>(batch) * n_pad * 8));
+    unsigned long long* keys = ctx->large_keys.as<unsigned long long>();
+    for (int64_t c0 = 0; c0 < n_cols; c0 += batch) {
+        const int64_t cols = cols4 - c0 < batch ? cols4 - c0 : batch;     // a multiple of 4
+        large_column_keys_kernel<<<dim3(static_cast<unsigned>(ceil_div(n_pad, 256)), static_cast<unsigned>(cols)), 256, 0, stream>>>(
+            G, (int)n_rows, n_pad, c0, n_cols, ld, row_index, keys);
+        BYZ_TRY(check_launch("large_column_keys_kernel"));
+        BYZ_TRY(segment_sort_u64(ctx, keys, cols, n_pad, stream));
+        large_window_kernel<<<static_cast<unsigned>(cols / 4), 64, 0, stream>>>(keys, n_pad, G, ld, row_index, (int)n_rows, (int)keep, c0,
+                                                                             n_cols, out);
+        BYZ_TRY(check_launch("large_window_kernel"));
+    }
+    return BYZ_OK;
+}
 
 int launch_lane_selftest(byz_ctx* ctx, int32_t* out, int32_t* n_patterns, hipStream_t stream) {
     KernelTimer t(ctx, BYZ_K_MISC, stream);
@@ -260,10 +353,7 @@ int launch_lane_selftest(byz_ctx* ctx, int32_t* out, int32_t* n_patterns, hipStr
 
 int launch_trimmed_mean_sorted(byz_ctx* ctx, const float* G, int64_t n_rows, int64_t n_cols, int64_t ld,
                                const int32_t* row_index, int64_t keep, float* out, hipStream_t stream) {
-    if (n_rows > kGeneralMaxRows) {
-        set_error("trimmed_mean supports at most %d rows, got %lld", kGeneralMaxRows, (long long)n_rows);
-        return BYZ_E_UNSUPPORTED;
-    }
+    if (n_rows > kGeneralMaxRows) return launch_trimmed_mean_large(ctx, G, n_rows, n_cols, ld, row_index, keep, out, stream);
     const int64_t n_pad = next_pow2(n_rows);
     const int vec = n_pad <= 8192 ? 4 : 2;
     const int64_t n_quads = ceil_div(n_cols, vec);
