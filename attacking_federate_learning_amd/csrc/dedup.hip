@@ -3,7 +3,7 @@
 //
 // The Gram costs N^2 D / 2 multiply-adds and nothing else on the path comes close, so the rows are deduplicated first:
 //   1. signature   64-bit hash of 8 KiB sampled from every row (eight 1 KiB segments spread over the columns);
-//   2. candidates  rep[i] = first j <= i with the same signature (N <= 16,384: a scan over an 128 KiB table);
+//   2. candidates  rep[i] = first j <= i with the same signature (the signatures in front pass through LDS a tile at a time);
 //   3. verify      every candidate row is compared with its representative bit for bit over ALL columns; a row that
 //                  differs anywhere is its own representative again (signatures only nominate, they never decide);
 //   4. compact     the unique rows in ascending order, and for every row the position of its representative there.
@@ -158,8 +158,9 @@ __global__ __launch_bounds__(256) void gram_expand_kernel(const double* __restri
                                                           const int32_t* __restrict__ map, int64_t n,
                                                           double* __restrict__ gram) {
     const int64_t j = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
-    const int64_t i = blockIdx.y;
-    if (j < n) gram[i * n + j] = compact[static_cast<int64_t>(map[i]) * n_unique + map[j]];
+    if (j >= n) return;
+    const int64_t mj = map[j];
+    for (int64_t i = blockIdx.y; i < n; i += gridDim.y) gram[i * n + j] = compact[static_cast<int64_t>(map[i]) * n_unique + mj];
 }
 
 }  // namespace
@@ -168,7 +169,7 @@ __global__ __launch_bounds__(256) void gram_expand_kernel(const double* __restri
 // the stream once (the caller sizes the Gram launch with U).
 int find_unique_rows(byz_ctx* ctx, const float* G, int64_t n_rows, int64_t n_cols, int64_t ld, hipStream_t stream,
                      int64_t* n_unique_host) {
-    BYZ_REQUIRE(n_rows <= 16384, "dedup: at most 16384 rows");
+    BYZ_REQUIRE(n_rows < (int64_t{1} << 24), "dedup: too many rows");
     const int n = static_cast<int>(n_rows);
     BYZ_TRY(ctx->row_signature.ensure(static_cast<size_t>(n) * sizeof(uint64_t)));
     BYZ_TRY(ctx->unique_rows.ensure(static_cast<size_t>(n) * sizeof(int32_t)));
@@ -209,7 +210,7 @@ int find_unique_rows(byz_ctx* ctx, const float* G, int64_t n_rows, int64_t n_col
 int launch_gram_expand(byz_ctx* ctx, const double* compact, int64_t n_unique, int64_t n_rows, double* gram,
                        hipStream_t stream) {
     KernelTimer t(ctx, BYZ_K_GRAM_REDUCE, stream);
-    const dim3 grid(static_cast<unsigned>(ceil_div(n_rows, 256)), static_cast<unsigned>(n_rows));
+    const dim3 grid(static_cast<unsigned>(ceil_div(n_rows, 256)), static_cast<unsigned>(n_rows < 32768 ? n_rows : 32768));
     gram_expand_kernel<<<grid, 256, 0, stream>>>(compact, n_unique, ctx->row_map.as<int32_t>(), n_rows, gram);
     return check_launch("gram_expand_kernel");
 }

@@ -1003,7 +1003,7 @@ int launch_gram(byz_ctx* ctx, const float* G, int64_t n_rows, int64_t n_cols, in
     ctx->row_map_rows = 0;
     // Identical rows first (dedup.hip): worth a look once the Gram is compute bound and a 4-byte read-back does not
     // show (N >= 512); used when it removes at least one row of tiles.
-    if (n_rows >= 512 && n_rows <= 16384 && env_int("BYZ_GRAM_DEDUP", 1) != 0) {
+    if (n_rows >= 512 && env_int("BYZ_GRAM_DEDUP", 1) != 0) {
         int64_t n_unique = n_rows;
         BYZ_TRY(find_unique_rows(ctx, G, n_rows, n_cols, ld, stream, &n_unique));
         ctx->row_map_rows = n_rows;   // row_map[i] == row_map[j]  <=>  rows i and j are bitwise identical

@@ -347,21 +347,39 @@ __global__ __launch_bounds__(256) void large_rescore_kernel(int t, int n, int us
         const int64_t row = static_cast<int64_t>(u) * n;
         float s = 0.0f;
         int left = m;
-        for (int r0 = 0; r0 < n && left > 0; r0 += 64) {
-            const int r = r0 + lane;
-            float v = 0.0f;
-            bool live = false;
-            if (r < n) {
-                const int c = static_cast<int>(sorted_idx[row + r]);
-                live = c != u && st.gone[c] == 0;
-                v = sorted_val[row + r];
+        // 256 ranks per step, the next step's columns and values requested before this step's chain of additions: the walk is
+        // two dependent loads per rank (the column, then whether that row is gone) and nothing else covers them
+        constexpr int kAhead = 4;
+        int col[kAhead];
+        float val[kAhead];
+#pragma unroll
+        for (int k = 0; k < kAhead; ++k) {
+            const int r = 64 * k + lane;
+            col[k] = r < n ? static_cast<int>(sorted_idx[row + r]) : u;
+            val[k] = r < n ? sorted_val[row + r] : 0.0f;
+        }
+        for (int r0 = 0; r0 < n && left > 0; r0 += 64 * kAhead) {
+            bool live[kAhead];
+#pragma unroll
+            for (int k = 0; k < kAhead; ++k) live[k] = col[k] != u && st.gone[col[k]] == 0;
+            float v[kAhead];
+#pragma unroll
+            for (int k = 0; k < kAhead; ++k) {
+                v[k] = val[k];
+                const int r = r0 + 64 * (kAhead + k) + lane;
+                col[k] = r < n ? static_cast<int>(sorted_idx[row + r]) : u;
+                val[k] = r < n ? sorted_val[row + r] : 0.0f;
             }
-            const unsigned long long mask = __ballot(live);
-            const int before = __popcll(mask & ((1ull << lane) - 1ull));
-            const float x = live && before < left ? v : 0.0f;     // (s + 0.0 leaves s as it is: s is never -0.0, it starts at +0.0)
-            const int last = 63 - __builtin_clzll(mask | 1ull);
-            for (int l = 0; l <= last; ++l) s = __fadd_rn(s, __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), l)));
-            left -= __popcll(mask);
+#pragma unroll
+            for (int k = 0; k < kAhead; ++k) {
+                const unsigned long long mask = __ballot(live[k]);
+                if (mask == 0ull || left <= 0) continue;
+                const int before = __popcll(mask & ((1ull << lane) - 1ull));
+                const float x = live[k] && before < left ? v[k] : 0.0f;     // (s + 0.0 leaves s as it is: s is never -0.0, it starts at +0.0)
+                const int last = 63 - __builtin_clzll(mask);
+                for (int l = 0; l <= last; ++l) s = __fadd_rn(s, __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), l)));
+                left -= __popcll(mask);
+            }
         }
         if (lane == 0) st.score[u] = s;
     }

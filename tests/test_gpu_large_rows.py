@@ -211,17 +211,25 @@ def test_trimmed_mean_beyond_the_lds_kernels(eng, n, cols, c):
     assert close(eng.trimmed_mean(eng.to_device(g2), n, c).numpy(), faithful.trimmed_mean(g2, n, c))
 
 
-def test_the_defences_end_to_end_beyond_the_lds_kernels(eng):
+@pytest.mark.parametrize('attacked', [False, True])
+def test_the_defences_end_to_end_beyond_the_lds_kernels(eng, attacked):
     """Krum and Bulyan from the gradients at N = 16,640 (defences.py:23-42, :55-70): distances by the Gram kernels, sampled rows
     against fp64; Krum's index and Bulyan's aggregate against the oracle run on the ENGINE's distances (the margin between fp32 and
-    fp64 distances is the subject of tests/test_gpu_scale.py, not of this file)."""
+    fp64 distances is the subject of tests/test_gpu_scale.py, not of this file).  `attacked`: the f malicious rows are ONE vector
+    (malicious.py:18-27) -- found before the Gram (dedup.hip, no row limit since this round), their distances exact zeros."""
     n, d = 16640, 96
     f = int(0.24 * n)
     rng = np.random.default_rng(99)
     g = rng.standard_normal((n, d)).astype(np.float32)
     g *= (1.0 + 0.5 * rng.permutation(n) / n).astype(np.float32)[:, None]
+    if attacked:
+        g[:f] = faithful.drift_vector(g[:f], 1.5)
     gd = eng.to_device(g)
     dist = eng.pairwise_distances(gd).numpy()
+    if attacked:
+        twins = dist[:f, :f].copy()
+        np.fill_diagonal(twins, 0.0)
+        assert not twins.any(), (np.count_nonzero(twins), float(np.abs(twins).max()), float(dist[0, 0]))
     rows = rng.integers(0, n, 6)
     g64 = g.astype(np.float64)
     for u in rows:
