@@ -8,7 +8,7 @@
 //                               order-preserving float bits << 32 | column, the self entry last, a NaN behind +inf), the Krum
 //                               score as the SEQUENTIAL fp32 sum of the first `prefix_len` sorted values; for Bulyan the sorted
 //                               values, the sorted columns, the rank of every column and two fp64 sums per row
-//   launch_bulyan_loop_large    defences.py:59-68, two launches per pick.  A row's exact score -- the sum of all its live
+//   launch_bulyan_loop_large    defences.py:59-68, three launches per batch of picks.  A row's exact score -- the sum of all its live
 //                               distances minus the sum of the `drop` largest, both carried in fp64 and updated in O(1) when a
 //                               row leaves -- bounds the reference's sequential fp32 sum from both sides ((1 +- u)^(m-1),
 //                               u = 2^-24); every live row whose lower bound does not exceed the smallest upper bound is a
@@ -104,32 +104,44 @@ __global__ __launch_bounds__(256) void large_row_keys_kernel(const float* __rest
     keys[static_cast<int64_t>(blockIdx.y) * n_pad + c] = key;
 }
 
-// the per-row state of the Bulyan loop (ctx->large_state): doubles first, then the 32-bit words, then the bytes
+// the state of the Bulyan loop (ctx->large_state): doubles first, then the 32-bit words
+constexpr int kBatchMax = 32;          // picks decided on the exact scores before their contenders are scored together
+constexpr int kNever = 0x7fffffff;     // gone_at of a row that is still there
 struct LargeState {
     double* total;        // [n] sum of the row's live distances (regular rows)
     double* top;          // [n] sum of its `drop` largest live distances
-    double* scale;        // [1] the largest first total: what the absolute rounding slack of the running sums is taken from
+    double* total_kept;   // [n] the three of them as they were when the batch began (what a roll-back starts from)
+    double* top_kept;     // [n]
+    double* scale;        // [2] the largest first total: what the absolute rounding slack of the running sums is taken from
     int32_t* top_first;   // [n] the lowest rank that belongs to the `drop` largest live entries
+    int32_t* first_kept;  // [n]
     int32_t* irregular;   // [n] the row holds a negative or non-finite distance: it is scored the reference's way at every pick
-    int32_t* contender;   // [n] the rows to be scored the reference's way at the current pick
-    int32_t* n_contenders;// [1]
-    float* score;         // [n] their scores
-    uint8_t* gone;        // [n] picked already
+    int32_t* gone_at;     // [n] the pick that took the row (kNever: still there); live in the state of pick t <=> gone_at >= t
+    int32_t* pair_row;    // [kBatchMax n] the contenders of the batch's picks, pick after pick
+    float* pair_score;    // [kBatchMax n] their scores in the state of their pick
+    int32_t* pair_begin;  // [kBatchMax + 1] where a pick's contenders begin
+    int32_t* guess;       // [kBatchMax] the row with the smallest exact score at that pick (-1: none)
+    int32_t* words;       // [4] the next pick, the picks of the current batch, (unused)
 };
 __host__ __device__ inline size_t large_state_bytes(int64_t n) {
-    return static_cast<size_t>(2 * n + 2) * sizeof(double) + static_cast<size_t>(4 * n + 2) * sizeof(int32_t) + static_cast<size_t>(n) + 64;
+    return static_cast<size_t>(4 * n + 2) * sizeof(double) + static_cast<size_t>(4 * n + 2 * kBatchMax * n + 2 * kBatchMax + 8) * sizeof(int32_t) + 64;
 }
 __host__ __device__ inline LargeState large_state(void* p, int64_t n) {
     LargeState s;
     s.total = static_cast<double*>(p);
     s.top = s.total + n;
-    s.scale = s.top + n;
+    s.total_kept = s.top + n;
+    s.top_kept = s.total_kept + n;
+    s.scale = s.top_kept + n;
     s.top_first = reinterpret_cast<int32_t*>(s.scale + 2);
-    s.irregular = s.top_first + n;
-    s.contender = s.irregular + n;
-    s.n_contenders = s.contender + n;
-    s.score = reinterpret_cast<float*>(s.n_contenders + 2);
-    s.gone = reinterpret_cast<uint8_t*>(s.score + n);
+    s.first_kept = s.top_first + n;
+    s.irregular = s.first_kept + n;
+    s.gone_at = s.irregular + n;
+    s.pair_row = s.gone_at + n;
+    s.pair_score = reinterpret_cast<float*>(s.pair_row + static_cast<int64_t>(kBatchMax) * n);
+    s.pair_begin = reinterpret_cast<int32_t*>(s.pair_score + static_cast<int64_t>(kBatchMax) * n);
+    s.guess = s.pair_begin + kBatchMax + 1;
+    s.words = s.guess + kBatchMax;
     return s;
 }
 
@@ -200,12 +212,23 @@ __global__ __launch_bounds__(256) void large_row_tables_kernel(const unsigned lo
         if (tid == 0) {
             st.irregular[u] = red[0] != 0.0 ? 1 : 0;
             st.top_first[u] = first_top;       // (the self entry holds rank n - 1: the `drop` entries below it are the largest)
-            st.gone[u] = 0;
+            st.gone_at[u] = kNever;
         }
     }
 }
 
 // ---- the Bulyan loop ----------------------------------------------------------------------------------------------------
+// Three launches per BATCH of picks (first form: two per pick, 0.57 ms a pick at N = 20,000 -- the walk of one contender is ~15,000
+// dependent additions, and nothing ran beside it):
+//   large_decide_kernel   one workgroup: up to `batch` picks decided on the EXACT scores (the row with the smallest one, ties by
+//                         visit order, leaves and every row's sums follow), the contenders of every pick listed in the state of
+//                         that pick;
+//   large_rescore_kernel  every (pick, contender) pair scored the reference's way, one wave each, in the state of its pick (a
+//                         row is there at pick t while gone_at >= t);
+//   large_settle_kernel   one workgroup: pick after pick the reference's comparison loop over the contenders' fp32 scores; where
+//                         its winner is not the guess, the batch is cut there: the sums go back to what they were when the batch
+//                         began, the picks that stood and the true winner are replayed, and the next batch starts behind it.
+// The same selection pick for pick whatever the batch length (BYZ_LARGE_BATCH, 1 .. 32).
 struct Pick {
     float score;
     int pos;
@@ -214,6 +237,12 @@ struct Pick {
 __device__ __forceinline__ bool better(const Pick& a, const Pick& b) {
     return a.score < b.score || (a.score == b.score && a.pos < b.pos);   // strict '<'; an equal score keeps the earlier visitor
 }
+struct Guess {
+    double score;
+    int pos;
+    int row;
+};
+__device__ __forceinline__ bool better(const Guess& a, const Guess& b) { return a.score < b.score || (a.score == b.score && a.pos < b.pos); }
 
 // how many live values pick t adds per row: users_count - len(selection_set) - corrupted_count of the n - t - 1 that are left
 // (defences.py:26, 34, 61)
@@ -222,167 +251,263 @@ __device__ __forceinline__ int values_per_row(int n, int t, int users_count, int
     return want < left ? (want > 0 ? want : 0) : left;
 }
 
-// One workgroup.  Closes pick t - 1 (the reference's comparison loop over the contenders' scores, the winner's removal from
-// every row's sums) and opens pick t (exact scores, their minimum, the contenders).
-__global__ __launch_bounds__(1024) void large_pick_kernel(int t, int n, int theta, int drop, int users_count, int corrupted,
-                                                          const float* __restrict__ sorted_val, const uint32_t* __restrict__ sorted_idx,
-                                                          const uint32_t* __restrict__ rank_rows, LargeState st,
-                                                          int32_t* __restrict__ selection, int32_t* __restrict__ status,
-                                                          int32_t* __restrict__ rescored) {
-    __shared__ Pick picks[1024];
-    __shared__ double mins[1024];
-    __shared__ int n_listed;
-    const int tid = threadIdx.x;
-    if (*status != 0) return;
-    if (t > 0) {
-        const int listed = *st.n_contenders;
-        Pick mine{kKrumInit, 0x7fffffff, -1};
-        for (int i = tid; i < listed; i += 1024) {
-            const int u = st.contender[i];
-            const float s = st.score[u];
-            if (s < kKrumInit) {   // false for NaN, as in the reference's comparison
-                const Pick o{s, visit_position(u), u};
-                if (better(o, mine)) mine = o;
-            }
+// Row w leaves at pick t (gone_at[w] == t already): every row that stays takes d(u, w) out of its sums.  The whole workgroup.
+__device__ __forceinline__ void remove_from_rows(int w, int t, int n, int drop, const float* __restrict__ sorted_val,
+                                                 const uint32_t* __restrict__ sorted_idx, const uint32_t* __restrict__ rank_rows,
+                                                 const LargeState& st) {
+    constexpr int kRows = 4;     // rows per thread and step: their dependent loads (the rank, then the value) side by side
+    for (int base = threadIdx.x; base < n; base += kRows * 1024) {
+        bool stays[kRows];
+        int r[kRows];
+        float v[kRows];
+#pragma unroll
+        for (int j = 0; j < kRows; ++j) {
+            const int u = base + j * 1024;
+            stays[j] = u < n && st.gone_at[u] > t && st.irregular[u] == 0;
+            r[j] = stays[j] ? static_cast<int>(rank_rows[static_cast<int64_t>(u) * n + w]) : 0;
         }
-        picks[tid] = mine;
-        __syncthreads();
-        for (int s = 512; s > 0; s >>= 1) {
-            if (tid < s && better(picks[tid + s], picks[tid])) picks[tid] = picks[tid + s];
-            __syncthreads();
-        }
-        const int w = picks[0].row;
-        __syncthreads();
-        if (w < 0) {   // minimal_error_index stays -1: the reference's distances.pop(-1) raises KeyError
-            if (tid == 0) *status = 1;
-            return;
-        }
-        if (tid == 0) {
-            selection[t - 1] = w;
-            st.gone[w] = 1;
-        }
-        __threadfence_block();
-        __syncthreads();
-        for (int u = tid; u < n; u += 1024) {
-            if (st.gone[u] || st.irregular[u]) continue;
+#pragma unroll
+        for (int j = 0; j < kRows; ++j) v[j] = stays[j] ? sorted_val[static_cast<int64_t>(base + j * 1024) * n + r[j]] : 0.0f;
+#pragma unroll
+        for (int j = 0; j < kRows; ++j) {
+            if (!stays[j]) continue;
+            const int u = base + j * 1024;
             const int64_t row = static_cast<int64_t>(u) * n;
-            const int r = static_cast<int>(rank_rows[row + w]);
-            const double v = static_cast<double>(sorted_val[row + r]);
-            st.total[u] -= v;
-            if (drop > 0 && r >= st.top_first[u]) {
+            const double d = static_cast<double>(v[j]);
+            st.total[u] -= d;
+            if (drop > 0 && r[j] >= st.top_first[u]) {
                 // the winner was one of the `drop` largest: the next live entry below them takes its place
                 int p = st.top_first[u] - 1;
-                while (p >= 0 && st.gone[sorted_idx[row + p]]) --p;
-                st.top[u] += (p >= 0 ? static_cast<double>(sorted_val[row + p]) : 0.0) - v;
+                while (p >= 0 && st.gone_at[sorted_idx[row + p]] <= t) --p;
+                st.top[u] += (p >= 0 ? static_cast<double>(sorted_val[row + p]) : 0.0) - d;
                 st.top_first[u] = p;
             }
         }
-        __syncthreads();
-    }
-    if (t >= theta) return;
-    if (t == 0) {
-        double big = 0.0;
-        for (int u = tid; u < n; u += 1024) big = st.irregular[u] ? big : (st.total[u] > big ? st.total[u] : big);
-        mins[tid] = big;
-        __syncthreads();
-        for (int s = 512; s > 0; s >>= 1) {
-            if (tid < s && mins[tid + s] > mins[tid]) mins[tid] = mins[tid + s];
-            __syncthreads();
-        }
-        if (tid == 0) *st.scale = mins[0];
-        __syncthreads();
-    }
-    const int m = values_per_row(n, t, users_count, corrupted);
-    const bool all_of_them = users_count - t - corrupted >= n - t - 1;     // nothing is dropped: the score is the whole total
-    double low = __builtin_inf();
-    for (int u = tid; u < n; u += 1024) {
-        if (st.gone[u] || st.irregular[u]) continue;
-        const double s = all_of_them ? st.total[u] : st.total[u] - st.top[u];
-        low = s < low ? s : low;
-    }
-    mins[tid] = low;
-    if (tid == 0) n_listed = 0;
-    __syncthreads();
-    for (int s = 512; s > 0; s >>= 1) {
-        if (tid < s && mins[tid + s] < mins[tid]) mins[tid] = mins[tid + s];
-        __syncthreads();
-    }
-    low = mins[0];
-    // fl(sum) of m non-negative terms added one by one lies in [s (1 - u)^(m-1), s (1 + u)^(m-1)], u = 2^-24: a row can reach
-    // the smallest sum only from below s_min ((1 + u) / (1 - u))^(m-1) <= s_min (1 + 2.1 m u) for m u <= 2^-6; the running fp64
-    // sums carry at most 2^17 roundings of 2^-53 of the largest first total each.  A minimum at or beyond 1e20 (no row may
-    // score below the reference's starting value) or a non-finite one: every live row is scored.
-    double bound = low * (1.0 + 2.1 * static_cast<double>(m) * 5.9604644775390625e-08 + 1e-9) + *st.scale * 1.4551915228366852e-11;
-    if (!(low < 9e19)) bound = __builtin_inf();
-    if (m > (1 << 18)) bound = __builtin_inf();
-    for (int u = tid; u < n; u += 1024) {
-        if (st.gone[u]) continue;
-        bool in = st.irregular[u] != 0;
-        if (!in) {
-            const double s = all_of_them ? st.total[u] : st.total[u] - st.top[u];
-            in = s <= bound;
-        }
-        if (in) st.contender[atomicAdd(&n_listed, 1)] = u;
-    }
-    __syncthreads();
-    if (tid == 0) {
-        *st.n_contenders = n_listed;
-        *rescored += n_listed;
     }
 }
 
-// One wave per contender: defences.py:33-34 on the row as the reference sees it at pick t -- the sorted distances to the
-// rows still there, the first m of them added left to right in fp32.
-__global__ __launch_bounds__(256) void large_rescore_kernel(int t, int n, int users_count, int corrupted,
+__global__ __launch_bounds__(1024) void large_decide_kernel(int n, int theta, int drop, int users_count, int corrupted, int batch,
                                                             const float* __restrict__ sorted_val,
+                                                            const uint32_t* __restrict__ sorted_idx,
+                                                            const uint32_t* __restrict__ rank_rows, LargeState st,
+                                                            const int32_t* __restrict__ status, int32_t* __restrict__ rescored) {
+    __shared__ Guess best[16];
+    __shared__ int n_listed;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int t0 = st.words[0];
+    if (*status != 0 || t0 >= theta) {
+        if (tid == 0) st.words[1] = 0;
+        return;
+    }
+    if (t0 == 0) {
+        double big = 0.0;
+        for (int u = tid; u < n; u += 1024) big = st.irregular[u] ? big : (st.total[u] > big ? st.total[u] : big);
+#pragma unroll
+        for (int m = 32; m > 0; m >>= 1) {
+            const double o = __shfl_xor(big, m, 64);
+            big = o > big ? o : big;
+        }
+        if (lane == 0) best[wave].score = big;
+        __syncthreads();
+        if (tid == 0) {
+            double all = 0.0;
+            for (int w = 0; w < 16; ++w) all = best[w].score > all ? best[w].score : all;
+            *st.scale = all;
+        }
+        __syncthreads();
+    }
+    for (int u = tid; u < n; u += 1024) {
+        st.total_kept[u] = st.total[u];
+        st.top_kept[u] = st.top[u];
+        st.first_kept[u] = st.top_first[u];
+    }
+    if (tid == 0) {
+        n_listed = 0;
+        st.pair_begin[0] = 0;
+    }
+    const double slack = *st.scale * 1.4551915228366852e-11;     // 2^17 roundings of 2^-53 of the largest first total
+    int done = 0;
+    for (int k = 0; k < batch && t0 + k < theta; ++k) {
+        const int t = t0 + k;
+        const int m = values_per_row(n, t, users_count, corrupted);
+        const bool all_of_them = users_count - t - corrupted >= n - t - 1;     // nothing is dropped: the score is the whole total
+        Guess mine{__builtin_inf(), 0x7fffffff, -1};
+        for (int u = tid; u < n; u += 1024) {
+            if (st.gone_at[u] < t || st.irregular[u]) continue;
+            const Guess o{all_of_them ? st.total[u] : st.total[u] - st.top[u], visit_position(u), u};
+            if (better(o, mine)) mine = o;
+        }
+#pragma unroll
+        for (int x = 32; x > 0; x >>= 1) {
+            const Guess o{__shfl_xor(mine.score, x, 64), __shfl_xor(mine.pos, x, 64), __shfl_xor(mine.row, x, 64)};
+            if (better(o, mine)) mine = o;
+        }
+        __syncthreads();      // (best[] may still be read from the pick before)
+        if (lane == 0) best[wave] = mine;
+        __syncthreads();
+        mine = best[0];
+        for (int w = 1; w < 16; ++w)
+            if (better(best[w], mine)) mine = best[w];
+        const double low = mine.score;
+        // fl(sum) of m non-negative terms added one by one lies in [s (1 - u)^(m-1), s (1 + u)^(m-1)], u = 2^-24: a row can reach
+        // the smallest sum only from below s_min ((1 + u) / (1 - u))^(m-1) <= s_min (1 + 2.1 m u) for m u <= 2^-6 (scripts/proto/
+        // band_loop.py, tests/test_proto_rules.py).  A minimum at or beyond 1e20 (no row may score below the reference's starting
+        // value), a non-finite one, or more values than the bound was derived for: every live row is scored.
+        double bound = low * (1.0 + 2.1 * static_cast<double>(m) * 5.9604644775390625e-08 + 1e-9) + slack;
+        if (!(low < 9e19) || m > (1 << 18)) bound = __builtin_inf();
+        for (int u = tid; u < n; u += 1024) {
+            if (st.gone_at[u] < t) continue;
+            bool in = st.irregular[u] != 0;
+            if (!in) in = (all_of_them ? st.total[u] : st.total[u] - st.top[u]) <= bound;
+            if (in) st.pair_row[atomicAdd(&n_listed, 1)] = u;
+        }
+        __syncthreads();
+        const int w = mine.row;
+        if (tid == 0) {
+            st.pair_begin[k + 1] = n_listed;
+            st.guess[k] = w;
+            if (w >= 0) st.gone_at[w] = t;
+        }
+        done = k + 1;
+        if (w < 0) break;      // no regular row is left: the contenders' scores decide this pick, and the batch ends with it
+        __threadfence_block();
+        __syncthreads();
+        remove_from_rows(w, t, n, drop, sorted_val, sorted_idx, rank_rows, st);
+        __syncthreads();
+    }
+    if (tid == 0) {
+        st.words[1] = done;
+        const int pairs = n_listed;
+        *rescored = *rescored > 0x7fffffff - pairs ? 0x7fffffff : *rescored + pairs;
+    }
+}
+
+// One wave per (pick, contender): defences.py:33-34 on the row as the reference sees it at that pick -- the sorted distances to
+// the rows still there, the first m of them added left to right in fp32.
+__global__ __launch_bounds__(256) void large_rescore_kernel(int n, int users_count, int corrupted, const float* __restrict__ sorted_val,
                                                             const uint32_t* __restrict__ sorted_idx, LargeState st,
                                                             const int32_t* __restrict__ status) {
-    if (*status != 0) return;
+    const int picks = st.words[1];
+    if (*status != 0 || picks == 0) return;
     const int lane = threadIdx.x & 63;
     const int wave = (blockIdx.x * 256 + threadIdx.x) >> 6, n_waves = (gridDim.x * 256) >> 6;
-    const int listed = *st.n_contenders;
-    const int m = values_per_row(n, t, users_count, corrupted);
+    const int t0 = st.words[0];
+    const int listed = st.pair_begin[picks];
     for (int i = wave; i < listed; i += n_waves) {
-        const int u = st.contender[i];
+        int k = 0;
+        while (k + 1 < picks && st.pair_begin[k + 1] <= i) ++k;
+        const int t = t0 + k;
+        const int m = values_per_row(n, t, users_count, corrupted);
+        const int u = st.pair_row[i];
         const int64_t row = static_cast<int64_t>(u) * n;
         float s = 0.0f;
         int left = m;
         // 256 ranks per step, the next step's columns and values requested before this step's chain of additions: the walk is
-        // two dependent loads per rank (the column, then whether that row is gone) and nothing else covers them
+        // two dependent loads per rank (the column, then when that row left) and nothing else covers them
         constexpr int kAhead = 4;
         int col[kAhead];
         float val[kAhead];
 #pragma unroll
-        for (int k = 0; k < kAhead; ++k) {
-            const int r = 64 * k + lane;
-            col[k] = r < n ? static_cast<int>(sorted_idx[row + r]) : u;
-            val[k] = r < n ? sorted_val[row + r] : 0.0f;
+        for (int a = 0; a < kAhead; ++a) {
+            const int r = 64 * a + lane;
+            col[a] = r < n ? static_cast<int>(sorted_idx[row + r]) : u;
+            val[a] = r < n ? sorted_val[row + r] : 0.0f;
         }
         for (int r0 = 0; r0 < n && left > 0; r0 += 64 * kAhead) {
             bool live[kAhead];
 #pragma unroll
-            for (int k = 0; k < kAhead; ++k) live[k] = col[k] != u && st.gone[col[k]] == 0;
+            for (int a = 0; a < kAhead; ++a) live[a] = col[a] != u && st.gone_at[col[a]] >= t;
             float v[kAhead];
 #pragma unroll
-            for (int k = 0; k < kAhead; ++k) {
-                v[k] = val[k];
-                const int r = r0 + 64 * (kAhead + k) + lane;
-                col[k] = r < n ? static_cast<int>(sorted_idx[row + r]) : u;
-                val[k] = r < n ? sorted_val[row + r] : 0.0f;
+            for (int a = 0; a < kAhead; ++a) {
+                v[a] = val[a];
+                const int r = r0 + 64 * (kAhead + a) + lane;
+                col[a] = r < n ? static_cast<int>(sorted_idx[row + r]) : u;
+                val[a] = r < n ? sorted_val[row + r] : 0.0f;
             }
 #pragma unroll
-            for (int k = 0; k < kAhead; ++k) {
-                const unsigned long long mask = __ballot(live[k]);
+            for (int a = 0; a < kAhead; ++a) {
+                const unsigned long long mask = __ballot(live[a]);
                 if (mask == 0ull || left <= 0) continue;
                 const int before = __popcll(mask & ((1ull << lane) - 1ull));
-                const float x = live[k] && before < left ? v[k] : 0.0f;     // (s + 0.0 leaves s as it is: s is never -0.0, it starts at +0.0)
+                const float x = live[a] && before < left ? v[a] : 0.0f;     // (s + 0.0 leaves s as it is: s is never -0.0, it starts at +0.0)
                 const int last = 63 - __builtin_clzll(mask);
                 for (int l = 0; l <= last; ++l) s = __fadd_rn(s, __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), l)));
                 left -= __popcll(mask);
             }
         }
-        if (lane == 0) st.score[u] = s;
+        if (lane == 0) st.pair_score[i] = s;
     }
+}
+
+__global__ __launch_bounds__(1024) void large_settle_kernel(int n, int theta, int drop, const float* __restrict__ sorted_val,
+                                                            const uint32_t* __restrict__ sorted_idx,
+                                                            const uint32_t* __restrict__ rank_rows, LargeState st,
+                                                            int32_t* __restrict__ selection, int32_t* __restrict__ status) {
+    __shared__ Pick picks_sh[16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int picks = st.words[1];
+    if (*status != 0 || picks == 0) return;
+    const int t0 = st.words[0];
+    for (int k = 0; k < picks; ++k) {
+        // defences.py:27-37 over the rows that can win: strict '<' from 1e20 in the visit order 1, 0, 2, ...
+        Pick mine{kKrumInit, 0x7fffffff, -1};
+        for (int i = st.pair_begin[k] + tid; i < st.pair_begin[k + 1]; i += 1024) {
+            const float s = st.pair_score[i];
+            if (s < kKrumInit) {   // false for NaN, as in the reference's comparison
+                const int u = st.pair_row[i];
+                const Pick o{s, visit_position(u), u};
+                if (better(o, mine)) mine = o;
+            }
+        }
+#pragma unroll
+        for (int x = 32; x > 0; x >>= 1) {
+            const Pick o{__shfl_xor(mine.score, x, 64), __shfl_xor(mine.pos, x, 64), __shfl_xor(mine.row, x, 64)};
+            if (better(o, mine)) mine = o;
+        }
+        __syncthreads();
+        if (lane == 0) picks_sh[wave] = mine;
+        __syncthreads();
+        mine = picks_sh[0];
+        for (int w = 1; w < 16; ++w)
+            if (better(picks_sh[w], mine)) mine = picks_sh[w];
+        const int winner = mine.row;
+        if (winner == st.guess[k] && winner >= 0) {
+            if (tid == 0) selection[t0 + k] = winner;
+            continue;
+        }
+        // The guess did not stand.  The sums go back to the start of the batch; the rows the batch took from pick k on are there
+        // again; the picks that stood, and this pick's true winner, are replayed.  (No winner at all -- minimal_error_index stays
+        // -1, the reference's distances.pop(-1) raises KeyError -- ends the loop: status 1.)
+        __syncthreads();
+        for (int u = tid; u < n; u += 1024) {
+            st.total[u] = st.total_kept[u];
+            st.top[u] = st.top_kept[u];
+            st.top_first[u] = st.first_kept[u];
+            if (st.gone_at[u] >= t0 + k && st.gone_at[u] != kNever) st.gone_at[u] = kNever;
+        }
+        __syncthreads();
+        if (winner < 0) {
+            if (tid == 0) {
+                *status = 1;
+                st.words[0] = t0 + k;
+            }
+            return;
+        }
+        if (tid == 0) {
+            selection[t0 + k] = winner;
+            st.gone_at[winner] = t0 + k;
+        }
+        __threadfence_block();
+        __syncthreads();
+        for (int j = 0; j <= k; ++j) {
+            remove_from_rows(selection[t0 + j], t0 + j, n, drop, sorted_val, sorted_idx, rank_rows, st);
+            __syncthreads();
+        }
+        if (tid == 0) st.words[0] = t0 + k + 1;
+        return;
+    }
+    if (tid == 0) st.words[0] = t0 + picks;
 }
 
 }  // namespace
@@ -460,20 +585,41 @@ int launch_bulyan_loop_large(byz_ctx* ctx, const float* dist, int64_t n, int64_t
     BYZ_REQUIRE(ctx->large_state.bytes >= large_state_bytes(n) && ctx->large_idx.ptr && ctx->large_rank.ptr,
                 "bulyan loop (large): the row sort has not run");
     const LargeState st = large_state(ctx->large_state.ptr, n);
+    // BYZ_LARGE_BATCH=<k>: picks decided on the exact scores before their contenders are scored together (default 16, at most 32;
+    // 1: every pick settled before the next one is decided).  The same selection, pick for pick.
+    int batch = 16;
+    if (const char* e = std::getenv("BYZ_LARGE_BATCH")) batch = std::atoi(e);
+    batch = batch < 1 ? 1 : (batch > kBatchMax ? kBatchMax : batch);
     BYZ_HIP(hipMemsetAsync(status_dev, 0, 3 * sizeof(int32_t), stream));   // status, rows re-scored, (unused)
-    BYZ_HIP(hipMemsetAsync(st.n_contenders, 0, 2 * sizeof(int32_t), stream));
+    BYZ_HIP(hipMemsetAsync(st.words, 0, 4 * sizeof(int32_t), stream));
     KernelTimer timer(ctx, BYZ_K_BULYAN_LOOP, stream);
-    int64_t waves = static_cast<int64_t>(ctx->num_cus) * 16;
-    const unsigned rescore_grid = static_cast<unsigned>(waves / 4);
-    for (int64_t t = 0; t <= theta; ++t) {
-        large_pick_kernel<<<1, 1024, 0, stream>>>((int)t, (int)n, (int)theta, (int)drop_count, (int)users_count, (int)corrupted,
-                                                  ctx->sorted_val.as<float>(), ctx->large_idx.as<uint32_t>(),
-                                                  ctx->large_rank.as<uint32_t>(), st, selection_dev, status_dev, status_dev + 1);
-        if (t == theta) break;
-        large_rescore_kernel<<<rescore_grid, 256, 0, stream>>>((int)t, (int)n, (int)users_count, (int)corrupted,
-                                                               ctx->sorted_val.as<float>(), ctx->large_idx.as<uint32_t>(), st, status_dev);
+    const unsigned rescore_grid = static_cast<unsigned>(ctx->num_cus) * 4;      // 16 waves per CU
+    // The host does not know where a batch was cut: it queues as many batches as the picks left would take if every batch stood,
+    // a few more, and looks at the next pick; queued batches behind the last pick leave at once.
+    BYZ_TRY(ctx->pinned.ensure(4 * sizeof(int32_t)));
+    int64_t next = 0;
+    for (int round = 0; next < theta; ++round) {
+        const int64_t queued = ceil_div(theta - next, batch) + 4;
+        for (int64_t q = 0; q < queued; ++q) {
+            large_decide_kernel<<<1, 1024, 0, stream>>>((int)n, (int)theta, (int)drop_count, (int)users_count, (int)corrupted, batch,
+                                                        ctx->sorted_val.as<float>(), ctx->large_idx.as<uint32_t>(),
+                                                        ctx->large_rank.as<uint32_t>(), st, status_dev, status_dev + 1);
+            large_rescore_kernel<<<rescore_grid, 256, 0, stream>>>((int)n, (int)users_count, (int)corrupted, ctx->sorted_val.as<float>(),
+                                                                   ctx->large_idx.as<uint32_t>(), st, status_dev);
+            large_settle_kernel<<<1, 1024, 0, stream>>>((int)n, (int)theta, (int)drop_count, ctx->sorted_val.as<float>(),
+                                                        ctx->large_idx.as<uint32_t>(), ctx->large_rank.as<uint32_t>(), st, selection_dev,
+                                                        status_dev);
+        }
+        BYZ_TRY(check_launch("large_decide_kernel / large_rescore_kernel / large_settle_kernel"));
+        int32_t* host = static_cast<int32_t*>(ctx->pinned.ptr);
+        BYZ_HIP(hipMemcpyAsync(host, st.words, sizeof(int32_t), hipMemcpyDeviceToHost, stream));
+        BYZ_HIP(hipMemcpyAsync(host + 1, status_dev, sizeof(int32_t), hipMemcpyDeviceToHost, stream));
+        BYZ_HIP(hipStreamSynchronize(stream));
+        if (host[1] != 0) break;                 // the reference's KeyError: the caller reads the status word
+        BYZ_REQUIRE(host[0] > next || host[0] >= theta, "bulyan loop (large): no pick settled in %lld batches", (long long)queued);
+        next = host[0];
     }
-    return check_launch("large_pick_kernel / large_rescore_kernel");
+    return BYZ_OK;
 }
 
 }  // namespace byz

@@ -145,6 +145,31 @@ def test_forced_large_when_the_reference_gives_up(eng, large):
     assert eng.krum_select(huge, n, f) == -1 == scale.krum_pick(huge, n, f)
 
 
+@pytest.mark.parametrize('batch', ['1', '3', '16', '32'])
+def test_forced_large_batches_select_the_same(eng, large, batch):
+    """BYZ_LARGE_BATCH: picks decided on the exact scores before their contenders are scored together, the batch cut where the
+    reference's winner is not the guess.  Whatever the batch length: the reference's selection -- on data that contests most picks
+    (guesses fail), on twins and exact ties (they must not), with rows that always contend, and where the reference gives up in the
+    middle of a batch."""
+    large.setenv('BYZ_LARGE_BATCH', batch)
+    for seed, n, dim, identical, quantum in [(1, 300, 2, 0, None), (2, 900, 16, 216, None), (3, 520, 8, 0, 0.25), (4, 1500, 2000, 0, None)]:
+        dist = point_distances(8000 + seed, n, dim, identical, quantum)
+        f = int(0.24 * n)
+        assert np.asarray(eng.bulyan_select(dist, n, f)).tolist() == scale.bulyan_selection(dist, n, f), (seed, batch)
+    n, f = 400, 40
+    mid = point_distances(15, n, 3)
+    mid[50:, 50:] = np.inf
+    assert selection_or_error(eng.bulyan_select, mid, n, f) is KeyError
+    assert np.asarray(eng.bulyan_select(mid, 130, 40)).tolist() == scale.bulyan_selection(mid, 130, 40)
+    odd = point_distances(91, 512, 5)
+    rng = np.random.default_rng(5)
+    for _ in range(200):
+        i, j = rng.integers(0, 512, 2)
+        if i != j:
+            odd[i, j] = odd[j, i] = np.inf if _ % 5 == 0 else -abs(odd[i, j]) * 1e-3
+    assert selection_or_error(eng.bulyan_select, odd, 512, 100) == selection_or_error(scale.bulyan_selection, odd, 512, 100)
+
+
 @pytest.mark.parametrize('n,cols,c', [(50, 37, 10), (129, 8, 40), (1000, 23, 480), (2080, 9, 1920), (5000, 6, 2400)])
 def test_forced_large_trimmed_mean(eng, large, n, cols, c):
     rng = np.random.default_rng(6100 + n)
