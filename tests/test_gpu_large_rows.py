@@ -1,8 +1,8 @@
 """More rows than the LDS-resident kernels hold: csrc/large_rows.hip (needs an MI355X).
 
 The reference has no row limit (defences.py:23-70 are loops over Python lists); the kernels of select.hip / trimmed_mean.hip stop at
-16,384 rows.  Beyond that the rows (columns) are sorted in global memory and the Bulyan loop runs two launches per pick on exact fp64
-scores with every contender inside the rigorous rounding band scored again the reference's way.  Two halves:
+16,384 rows.  Beyond that the rows (columns) are sorted in global memory and the Bulyan loop decides batches of picks on exact fp64
+scores, with every contender inside the rigorous rounding band scored again the reference's way and a batch cut where a guess fails.  Two halves:
 
   * the large path FORCED at sizes the C oracle recomputes completely (BYZ_SELECT_LARGE=1 / BYZ_TM_LARGE=1): the selection pick for pick
     against oracle/scale.py (defences.py:26-37, :59-68 restated in C) and against the production kernels, on contested data, twins, exact
