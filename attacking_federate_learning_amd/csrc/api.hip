@@ -210,6 +210,8 @@ void byz_ctx_destroy(byz_ctx* ctx) {
     ctx->large_keys.release();
     ctx->large_idx.release();
     ctx->large_rank.release();
+    ctx->large_rank_t.release();
+    ctx->large_dist_t.release();
     ctx->large_state.release();
     ctx->rank_t.release();
     ctx->rank_rows.release();

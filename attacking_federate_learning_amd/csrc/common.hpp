@@ -136,6 +136,8 @@ struct byz_ctx {
     byz::Buffer large_keys;      // 64-bit sort keys of one batch of rows / columns
     byz::Buffer large_idx;       // n x n uint32: column index at every ascending rank
     byz::Buffer large_rank;      // n x n uint32: rank of column w in row u, [u][w]
+    byz::Buffer large_rank_t;    // n x n uint32: the same transposed, [w][u]: a pick reads the winner's row of it
+    byz::Buffer large_dist_t;    // n x n fp32: the distance matrix transposed, [w][u] = d(u, w) (a caller's matrix need not be symmetric)
     byz::Buffer large_state;     // the Bulyan loop's per-row state
     bool redo_valid = false;     // the last trimmed mean went through the ring selection (redo_tiles[0] is its count)
     byz::Buffer redo_tiles;      // trimmed mean: tiles the ring selection handed to the general kernel (count first)

@@ -219,6 +219,22 @@ __global__ __launch_bounds__(256) void large_row_tables_kernel(const unsigned lo
     }
 }
 
+// out[c][r] = in[r][c] of an n x n matrix of 32-bit words: 64 x 64 tiles through LDS, both sides in contiguous runs
+__global__ __launch_bounds__(256) void transpose32_kernel(const uint32_t* __restrict__ in, int n, uint32_t* __restrict__ out) {
+    __shared__ uint32_t tile[64][65];
+    const int c0 = blockIdx.x * 64, r0 = blockIdx.y * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    for (int i = ty; i < 64; i += 4) {
+        const int r = r0 + i, c = c0 + tx;
+        tile[i][tx] = r < n && c < n ? in[static_cast<int64_t>(r) * n + c] : 0u;
+    }
+    __syncthreads();
+    for (int i = ty; i < 64; i += 4) {
+        const int c = c0 + i, r = r0 + tx;
+        if (c < n && r < n) out[static_cast<int64_t>(c) * n + r] = tile[tx][i];
+    }
+}
+
 // ---- the Bulyan loop ----------------------------------------------------------------------------------------------------
 // Three launches per BATCH of picks (first form: two per pick, 0.57 ms a pick at N = 20,000 -- the walk of one contender is ~15,000
 // dependent additions, and nothing ran beside it):
@@ -254,9 +270,11 @@ __device__ __forceinline__ int values_per_row(int n, int t, int users_count, int
 }
 
 // Row w leaves at pick t (gone_at[w] == t already): every row that stays takes d(u, w) out of its sums.  The whole workgroup.
+// (rank_t[w][u] = the rank of column w in row u and dist_t[w][u] = d(u, w): the winner's ROWS of the transposed tables, read
+// contiguously; out of the rows' own tables they were two scattered lines per row and pick -- 5 MB through one CU at 20,000 rows)
 __device__ __forceinline__ void remove_from_rows(int w, int t, int n, int drop, const float* __restrict__ sorted_val,
-                                                 const uint32_t* __restrict__ sorted_idx, const uint32_t* __restrict__ rank_rows,
-                                                 const LargeState& st) {
+                                                 const uint32_t* __restrict__ sorted_idx, const uint32_t* __restrict__ rank_t,
+                                                 const float* __restrict__ dist_t, const LargeState& st) {
     constexpr int kRows = 4;     // rows per thread and step: their dependent loads (the rank, then the value) side by side
     for (int base = threadIdx.x; base < n; base += kRows * 1024) {
         bool stays[kRows];
@@ -266,10 +284,9 @@ __device__ __forceinline__ void remove_from_rows(int w, int t, int n, int drop, 
         for (int j = 0; j < kRows; ++j) {
             const int u = base + j * 1024;
             stays[j] = u < n && st.gone_at[u] > t && st.irregular[u] == 0;
-            r[j] = stays[j] ? static_cast<int>(rank_rows[static_cast<int64_t>(u) * n + w]) : 0;
+            r[j] = stays[j] ? static_cast<int>(rank_t[static_cast<int64_t>(w) * n + u]) : 0;
+            v[j] = stays[j] ? dist_t[static_cast<int64_t>(w) * n + u] : 0.0f;
         }
-#pragma unroll
-        for (int j = 0; j < kRows; ++j) v[j] = stays[j] ? sorted_val[static_cast<int64_t>(base + j * 1024) * n + r[j]] : 0.0f;
 #pragma unroll
         for (int j = 0; j < kRows; ++j) {
             if (!stays[j]) continue;
@@ -291,7 +308,8 @@ __device__ __forceinline__ void remove_from_rows(int w, int t, int n, int drop, 
 __global__ __launch_bounds__(1024) void large_decide_kernel(int n, int theta, int drop, int users_count, int corrupted, int batch,
                                                             const float* __restrict__ sorted_val,
                                                             const uint32_t* __restrict__ sorted_idx,
-                                                            const uint32_t* __restrict__ rank_rows, LargeState st,
+                                                            const uint32_t* __restrict__ rank_t,
+                                                            const float* __restrict__ dist_t, LargeState st,
                                                             const int32_t* __restrict__ status, int32_t* __restrict__ rescored) {
     __shared__ Guess best[16];
     __shared__ int n_listed;
@@ -342,11 +360,9 @@ __global__ __launch_bounds__(1024) void large_decide_kernel(int n, int theta, in
                 const int u = base + j * 1024;
                 there[j] = u < n && st.gone_at[u] >= t;
                 regular[j] = there[j] && st.irregular[u] == 0;
-                r[j] = regular[j] && w_prev >= 0 ? static_cast<int>(rank_rows[static_cast<int64_t>(u) * n + w_prev]) : 0;
+                r[j] = regular[j] && w_prev >= 0 ? static_cast<int>(rank_t[static_cast<int64_t>(w_prev) * n + u]) : 0;
+                v[j] = regular[j] && w_prev >= 0 ? dist_t[static_cast<int64_t>(w_prev) * n + u] : 0.0f;
             }
-#pragma unroll
-            for (int j = 0; j < kRows; ++j)
-                v[j] = regular[j] && w_prev >= 0 ? sorted_val[static_cast<int64_t>(base + j * 1024) * n + r[j]] : 0.0f;
 #pragma unroll
             for (int j = 0; j < kRows; ++j) {
                 const int u = base + j * 1024;
@@ -415,7 +431,7 @@ __global__ __launch_bounds__(1024) void large_decide_kernel(int n, int theta, in
         if (w < 0) break;      // no regular row is left: the contenders' scores decide this pick, and the batch ends with it
     }
     if (w_prev >= 0) {         // the batch's last guess leaves the sums too: the state the next batch starts from
-        remove_from_rows(w_prev, t0 + done - 1, n, drop, sorted_val, sorted_idx, rank_rows, st);
+        remove_from_rows(w_prev, t0 + done - 1, n, drop, sorted_val, sorted_idx, rank_t, dist_t, st);
         __syncthreads();
     }
     if (tid == 0) {
@@ -485,7 +501,8 @@ __global__ __launch_bounds__(256) void large_rescore_kernel(int n, int users_cou
 
 __global__ __launch_bounds__(1024) void large_settle_kernel(int n, int theta, int drop, const float* __restrict__ sorted_val,
                                                             const uint32_t* __restrict__ sorted_idx,
-                                                            const uint32_t* __restrict__ rank_rows, LargeState st,
+                                                            const uint32_t* __restrict__ rank_t,
+                                                            const float* __restrict__ dist_t, LargeState st,
                                                             int32_t* __restrict__ selection, int32_t* __restrict__ status) {
     __shared__ Pick picks_sh[16];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -545,7 +562,7 @@ __global__ __launch_bounds__(1024) void large_settle_kernel(int n, int theta, in
         __threadfence_block();
         __syncthreads();
         for (int j = 0; j <= k; ++j) {
-            remove_from_rows(selection[t0 + j], t0 + j, n, drop, sorted_val, sorted_idx, rank_rows, st);
+            remove_from_rows(selection[t0 + j], t0 + j, n, drop, sorted_val, sorted_idx, rank_t, dist_t, st);
             __syncthreads();
         }
         if (tid == 0) st.words[0] = t0 + k + 1;
@@ -619,6 +636,16 @@ int launch_row_sort_large(byz_ctx* ctx, const float* dist, int64_t n, int64_t pr
                 keys, (int)n, n_pad, (int)row0, (int)prefix_len, (int)drop_count, ctx->scores.as<float>(), nullptr, nullptr, nullptr, st);
         BYZ_TRY(check_launch("large_row_tables_kernel"));
     }
+    if (want_tables) {
+        // the winner's rank in every row and its distance to every row, as ROWS: what a pick reads (remove_from_rows)
+        BYZ_TRY(ctx->large_rank_t.ensure(static_cast<size_t>(n) * n * sizeof(uint32_t)));
+        BYZ_TRY(ctx->large_dist_t.ensure(static_cast<size_t>(n) * n * sizeof(float)));
+        const unsigned tiles = static_cast<unsigned>(ceil_div(n, 64));
+        transpose32_kernel<<<dim3(tiles, tiles), 256, 0, stream>>>(ctx->large_rank.as<uint32_t>(), (int)n, ctx->large_rank_t.as<uint32_t>());
+        transpose32_kernel<<<dim3(tiles, tiles), 256, 0, stream>>>(reinterpret_cast<const uint32_t*>(dist), (int)n,
+                                                                   ctx->large_dist_t.as<uint32_t>());
+        BYZ_TRY(check_launch("transpose32_kernel"));
+    }
     return BYZ_OK;
 }
 
@@ -626,7 +653,7 @@ int launch_bulyan_loop_large(byz_ctx* ctx, const float* dist, int64_t n, int64_t
                              int64_t corrupted, int32_t* selection_dev, int32_t* status_dev, hipStream_t stream) {
     BYZ_REQUIRE(dist && selection_dev && status_dev && n > 0 && theta >= 0 && theta <= n,
                 "bulyan loop (large): bad arguments (n=%lld theta=%lld)", (long long)n, (long long)theta);
-    BYZ_REQUIRE(ctx->large_state.bytes >= large_state_bytes(n) && ctx->large_idx.ptr && ctx->large_rank.ptr,
+    BYZ_REQUIRE(ctx->large_state.bytes >= large_state_bytes(n) && ctx->large_idx.ptr && ctx->large_rank_t.ptr && ctx->large_dist_t.ptr,
                 "bulyan loop (large): the row sort has not run");
     const LargeState st = large_state(ctx->large_state.ptr, n);
     // BYZ_LARGE_BATCH=<k>: picks decided on the exact scores before their contenders are scored together (default 16, at most 32;
@@ -647,12 +674,13 @@ int launch_bulyan_loop_large(byz_ctx* ctx, const float* dist, int64_t n, int64_t
         for (int64_t q = 0; q < queued; ++q) {
             large_decide_kernel<<<1, 1024, 0, stream>>>((int)n, (int)theta, (int)drop_count, (int)users_count, (int)corrupted, batch,
                                                         ctx->sorted_val.as<float>(), ctx->large_idx.as<uint32_t>(),
-                                                        ctx->large_rank.as<uint32_t>(), st, status_dev, status_dev + 1);
+                                                        ctx->large_rank_t.as<uint32_t>(), ctx->large_dist_t.as<float>(), st, status_dev,
+                                                        status_dev + 1);
             large_rescore_kernel<<<rescore_grid, 256, 0, stream>>>((int)n, (int)users_count, (int)corrupted, ctx->sorted_val.as<float>(),
                                                                    ctx->large_idx.as<uint32_t>(), st, status_dev);
             large_settle_kernel<<<1, 1024, 0, stream>>>((int)n, (int)theta, (int)drop_count, ctx->sorted_val.as<float>(),
-                                                        ctx->large_idx.as<uint32_t>(), ctx->large_rank.as<uint32_t>(), st, selection_dev,
-                                                        status_dev);
+                                                        ctx->large_idx.as<uint32_t>(), ctx->large_rank_t.as<uint32_t>(),
+                                                        ctx->large_dist_t.as<float>(), st, selection_dev, status_dev);
         }
         BYZ_TRY(check_launch("large_decide_kernel / large_rescore_kernel / large_settle_kernel"));
         int32_t* host = static_cast<int32_t*>(ctx->pinned.ptr);
