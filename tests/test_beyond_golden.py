@@ -44,10 +44,29 @@ def rows_close(got_rows, want_rows, rows, rtol):
     return ok
 
 
+def fp64_distances(g, rows=1024):
+    """oracle.ideal.distance_matrix's arithmetic (the Gram identity in fp64, rounded to fp32 once) a block of rows at a time: its
+    three n x n fp64 temporaries and the transposed pass take two minutes at this size on the build container.  (No identical rows in
+    this case, so the symmetrising minimum of the original is not needed.)"""
+    p = g.astype(np.float64)
+    n = len(p)
+    sq = (p * p).sum(1)
+    out = np.empty((n, n), dtype=np.float32)
+    for s in range(0, n, rows):
+        d2 = sq[s:s + rows, None] + sq[None, :] - 2.0 * (p[s:s + rows] @ p.T)
+        np.maximum(d2, 0.0, out=d2)
+        np.sqrt(d2, out=d2)
+        out[s:s + rows] = d2
+    np.fill_diagonal(out, np.inf)
+    return out
+
+
 def test_oracle_reproduces_the_reference_beyond_16384_rows(beyond):
     g, want = beyond
     assert float(want['krum_margin']) > 1e-5
-    dist = ideal.distance_matrix(g).astype(np.float32)
+    small = ideal.distance_matrix(g[:300]).astype(np.float32)
+    dist = fp64_distances(g)
+    assert np.allclose(dist[:300, :300], small, rtol=1e-6, atol=0.0, equal_nan=True)      # the same arithmetic as the oracle's
     assert rows_close(dist[want['sampled_rows']], want['distance_rows'], want['sampled_rows'], 1e-5)
     assert scale.krum_pick(dist, CASE['n'], CASE['f']) == int(want['krum_index'])
 
