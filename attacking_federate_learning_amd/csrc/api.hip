@@ -213,6 +213,7 @@ void byz_ctx_destroy(byz_ctx* ctx) {
     ctx->large_rank_t.release();
     ctx->large_dist_t.release();
     ctx->large_state.release();
+    ctx->large_grid.release();
     ctx->rank_t.release();
     ctx->rank_rows.release();
     ctx->sorted_val.release();

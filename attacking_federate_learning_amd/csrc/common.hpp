@@ -139,6 +139,7 @@ struct byz_ctx {
     byz::Buffer large_rank_t;    // n x n uint32: the same transposed, [w][u]: a pick reads the winner's row of it
     byz::Buffer large_dist_t;    // n x n fp32: the distance matrix transposed, [w][u] = d(u, w) (a caller's matrix need not be symmetric)
     byz::Buffer large_state;     // the Bulyan loop's per-row state
+    byz::Buffer large_grid;      // its deciding kernel on many workgroups: every workgroup's best score, the list's counter
     bool redo_valid = false;     // the last trimmed mean went through the ring selection (redo_tiles[0] is its count)
     byz::Buffer redo_tiles;      // trimmed mean: tiles the ring selection handed to the general kernel (count first)
     byz::Buffer twin_class;      // 2n int32: twin class of every row (scratch, then final)

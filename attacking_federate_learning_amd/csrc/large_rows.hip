@@ -19,6 +19,8 @@
 //                               with a negative or non-finite entry (an arbitrary caller-supplied matrix) always contend.
 #include "common.hpp"
 
+#include <hip/hip_cooperative_groups.h>
+
 #include <cstdlib>
 
 namespace byz {
@@ -441,6 +443,162 @@ __global__ __launch_bounds__(1024) void large_decide_kernel(int n, int theta, in
     }
 }
 
+// The largest first total (the absolute slack of the running fp64 sums is taken from it), once per loop.
+__global__ __launch_bounds__(1024) void large_scale_kernel(int n, LargeState st) {
+    __shared__ double part[16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    double big = 0.0;
+    for (int u = tid; u < n; u += 1024) big = st.irregular[u] ? big : (st.total[u] > big ? st.total[u] : big);
+#pragma unroll
+    for (int m = 32; m > 0; m >>= 1) {
+        const double o = __shfl_xor(big, m, 64);
+        big = o > big ? o : big;
+    }
+    if (lane == 0) part[wave] = big;
+    __syncthreads();
+    if (tid == 0) {
+        double all = 0.0;
+        for (int w = 0; w < 16; ++w) all = part[w] > all ? part[w] : all;
+        *st.scale = all;
+    }
+}
+
+// large_decide_kernel on MANY workgroups (a cooperative launch: all of them resident, two grid-wide barriers per pick): the rows
+// spread over the whole chip instead of one compute unit -- what a pick cost in the one-workgroup form was that one unit's pass
+// over every row's sums.  Per pick: every workgroup's best exact score -> barrier -> everybody forms the same minimum and bound,
+// lists its rows inside the band (one reservation of the global list per workgroup), thread 0 books the guess -> barrier.
+constexpr int kGridBlock = 256;
+constexpr int kGridMaxBlocks = 256;
+__global__ __launch_bounds__(kGridBlock) void large_decide_grid_kernel(int n, int theta, int drop, int users_count, int corrupted,
+                                                                       int batch, const float* __restrict__ sorted_val,
+                                                                       const uint32_t* __restrict__ sorted_idx,
+                                                                       const uint32_t* __restrict__ rank_t,
+                                                                       const float* __restrict__ dist_t, LargeState st,
+                                                                       const int32_t* __restrict__ status, int32_t* __restrict__ rescored,
+                                                                       Guess* __restrict__ wg_best, int32_t* __restrict__ n_listed) {
+    namespace cg = cooperative_groups;
+    cg::grid_group grid = cg::this_grid();
+    extern __shared__ int32_t lds_list[];      // the rows of this workgroup inside the band (at most its share of the rows)
+    __shared__ Guess best[kGridBlock / 64];
+    __shared__ int lds_count, lds_base;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int gtid = blockIdx.x * kGridBlock + tid, gthreads = gridDim.x * kGridBlock;
+    const int t0 = st.words[0];
+    if (*status != 0 || t0 >= theta) {          // (the same for every workgroup: nobody reaches a barrier)
+        if (gtid == 0) st.words[1] = 0;
+        return;
+    }
+    if (gtid == 0) {
+        *n_listed = 0;
+        st.pair_begin[0] = 0;
+    }
+    const double slack = *st.scale * 1.4551915228366852e-11;     // 2^17 roundings of 2^-53 of the largest first total
+    int done = 0;
+    int w_prev = -1;
+    for (int k = 0; k < batch && t0 + k < theta; ++k) {
+        const int t = t0 + k;
+        const int m = values_per_row(n, t, users_count, corrupted);
+        const bool all_of_them = users_count - t - corrupted >= n - t - 1;
+        Guess mine{__builtin_inf(), 0x7fffffff, -1};
+        for (int u = gtid; u < n; u += gthreads) {
+            const bool there = st.gone_at[u] >= t;
+            if (!there || st.irregular[u] != 0) {
+                st.exact[u] = there ? -__builtin_inf() : __builtin_nan("");
+                continue;
+            }
+            double tot = st.total[u], top = st.top[u];
+            if (k == 0) {     // what a roll-back starts from
+                st.total_kept[u] = tot;
+                st.top_kept[u] = top;
+                st.first_kept[u] = st.top_first[u];
+            }
+            if (w_prev >= 0) {
+                const int r = static_cast<int>(rank_t[static_cast<int64_t>(w_prev) * n + u]);
+                const double d = static_cast<double>(dist_t[static_cast<int64_t>(w_prev) * n + u]);
+                tot -= d;
+                st.total[u] = tot;
+                if (drop > 0 && r >= st.top_first[u]) {
+                    const int64_t row = static_cast<int64_t>(u) * n;
+                    int p = st.top_first[u] - 1;
+                    while (p >= 0 && st.gone_at[sorted_idx[row + p]] < t) --p;
+                    top += (p >= 0 ? static_cast<double>(sorted_val[row + p]) : 0.0) - d;
+                    st.top[u] = top;
+                    st.top_first[u] = p;
+                }
+            }
+            const Guess o{all_of_them ? tot : tot - top, visit_position(u), u};
+            st.exact[u] = o.score;
+            if (better(o, mine)) mine = o;
+        }
+#pragma unroll
+        for (int x = 32; x > 0; x >>= 1) {
+            const Guess o{__shfl_xor(mine.score, x, 64), __shfl_xor(mine.pos, x, 64), __shfl_xor(mine.row, x, 64)};
+            if (better(o, mine)) mine = o;
+        }
+        if (lane == 0) best[wave] = mine;
+        if (tid == 0) lds_count = 0;
+        __syncthreads();
+        if (tid == 0) {
+            Guess b = best[0];
+            for (int w = 1; w < kGridBlock / 64; ++w)
+                if (better(best[w], b)) b = best[w];
+            wg_best[blockIdx.x] = b;
+        }
+        grid.sync();
+        mine = Guess{__builtin_inf(), 0x7fffffff, -1};
+        for (int b = lane; b < static_cast<int>(gridDim.x); b += 64) {
+            const Guess o = wg_best[b];
+            if (better(o, mine)) mine = o;
+        }
+#pragma unroll
+        for (int x = 32; x > 0; x >>= 1) {
+            const Guess o{__shfl_xor(mine.score, x, 64), __shfl_xor(mine.pos, x, 64), __shfl_xor(mine.row, x, 64)};
+            if (better(o, mine)) mine = o;
+        }
+        const double low = mine.score;
+        double bound = low * (1.0 + 2.1 * static_cast<double>(m) * 5.9604644775390625e-08 + 1e-9) + slack;      // (large_decide_kernel)
+        if (!(low < 9e19) || m > (1 << 18)) bound = __builtin_inf();
+        for (int u = gtid; u < n; u += gthreads) {
+            if (st.exact[u] <= bound) lds_list[atomicAdd(&lds_count, 1)] = u;      // (false for the NaN of a row that is gone)
+        }
+        __syncthreads();
+        if (tid == 0) lds_base = lds_count > 0 ? atomicAdd(n_listed, lds_count) : 0;
+        __syncthreads();
+        for (int i = tid; i < lds_count; i += kGridBlock) st.pair_row[lds_base + i] = lds_list[i];
+        const int w = mine.row;
+        if (gtid == 0) {
+            st.guess[k] = w;
+            if (w >= 0) st.gone_at[w] = t;
+        }
+        done = k + 1;
+        w_prev = w;
+        grid.sync();
+        if (gtid == 0) st.pair_begin[k + 1] = *n_listed;
+        if (w < 0) break;
+    }
+    if (w_prev >= 0) {         // the batch's last guess leaves the sums too: the state the next batch starts from
+        const int t = t0 + done - 1;
+        for (int u = gtid; u < n; u += gthreads) {
+            if (st.gone_at[u] <= t || st.irregular[u] != 0) continue;
+            const int r = static_cast<int>(rank_t[static_cast<int64_t>(w_prev) * n + u]);
+            const double d = static_cast<double>(dist_t[static_cast<int64_t>(w_prev) * n + u]);
+            st.total[u] -= d;
+            if (drop > 0 && r >= st.top_first[u]) {
+                const int64_t row = static_cast<int64_t>(u) * n;
+                int p = st.top_first[u] - 1;
+                while (p >= 0 && st.gone_at[sorted_idx[row + p]] <= t) --p;
+                st.top[u] += (p >= 0 ? static_cast<double>(sorted_val[row + p]) : 0.0) - d;
+                st.top_first[u] = p;
+            }
+        }
+    }
+    if (gtid == 0) {
+        st.words[1] = done;
+        const int pairs = *n_listed;
+        *rescored = *rescored > 0x7fffffff - pairs ? 0x7fffffff : *rescored + pairs;
+    }
+}
+
 // One wave per (pick, contender): defences.py:33-34 on the row as the reference sees it at that pick -- the sorted distances to
 // the rows still there, the first m of them added left to right in fp32.
 __global__ __launch_bounds__(256) void large_rescore_kernel(int n, int users_count, int corrupted, const float* __restrict__ sorted_val,
@@ -663,7 +821,22 @@ int launch_bulyan_loop_large(byz_ctx* ctx, const float* dist, int64_t n, int64_t
     batch = batch < 1 ? 1 : (batch > kBatchMax ? kBatchMax : batch);
     BYZ_HIP(hipMemsetAsync(status_dev, 0, 3 * sizeof(int32_t), stream));   // status, rows re-scored, (unused)
     BYZ_HIP(hipMemsetAsync(st.words, 0, 4 * sizeof(int32_t), stream));
+    // The deciding kernel on many workgroups (a cooperative launch) where the device offers it; BYZ_LARGE_COOP=0: on one workgroup
+    // (the comparison, and the form for a device that cannot hold the grid at once).  The same selection.
+    int coop = 0;
+    BYZ_HIP(hipDeviceGetAttribute(&coop, hipDeviceAttributeCooperativeLaunch, ctx->device));
+    if (const char* e = std::getenv("BYZ_LARGE_COOP")) coop = coop != 0 && std::atoi(e) != 0 ? 1 : 0;
+    int grid_blocks = static_cast<int>(ceil_div(n, kGridBlock));
+    if (grid_blocks > kGridMaxBlocks) grid_blocks = kGridMaxBlocks;
+    if (grid_blocks > ctx->num_cus) grid_blocks = ctx->num_cus;
+    const size_t list_bytes = static_cast<size_t>(ceil_div(n, static_cast<int64_t>(grid_blocks) * kGridBlock)) * kGridBlock * sizeof(int32_t);
+    if (list_bytes > 60 * 1024) coop = 0;
+    BYZ_TRY(ctx->large_grid.ensure(static_cast<size_t>(kGridMaxBlocks) * sizeof(Guess) + 64));
+    Guess* wg_best = ctx->large_grid.as<Guess>();
+    int32_t* n_listed_dev = reinterpret_cast<int32_t*>(wg_best + kGridMaxBlocks);
     KernelTimer timer(ctx, BYZ_K_BULYAN_LOOP, stream);
+    large_scale_kernel<<<1, 1024, 0, stream>>>((int)n, st);
+    BYZ_TRY(check_launch("large_scale_kernel"));
     const unsigned rescore_grid = static_cast<unsigned>(ctx->num_cus) * 4;      // 16 waves per CU
     // The host does not know where a batch was cut: it queues as many batches as the picks left would take if every batch stood,
     // a few more, and looks at the next pick; queued batches behind the last pick leave at once.
@@ -672,10 +845,25 @@ int launch_bulyan_loop_large(byz_ctx* ctx, const float* dist, int64_t n, int64_t
     for (int round = 0; next < theta; ++round) {
         const int64_t queued = ceil_div(theta - next, batch) + 4;
         for (int64_t q = 0; q < queued; ++q) {
-            large_decide_kernel<<<1, 1024, 0, stream>>>((int)n, (int)theta, (int)drop_count, (int)users_count, (int)corrupted, batch,
-                                                        ctx->sorted_val.as<float>(), ctx->large_idx.as<uint32_t>(),
-                                                        ctx->large_rank_t.as<uint32_t>(), ctx->large_dist_t.as<float>(), st, status_dev,
-                                                        status_dev + 1);
+            if (coop != 0) {
+                int n_i = (int)n, theta_i = (int)theta, drop_i = (int)drop_count, users_i = (int)users_count, corrupted_i = (int)corrupted;
+                const float* val_p = ctx->sorted_val.as<float>();
+                const uint32_t* idx_p = ctx->large_idx.as<uint32_t>();
+                const uint32_t* rank_p = ctx->large_rank_t.as<uint32_t>();
+                const float* dist_p = ctx->large_dist_t.as<float>();
+                LargeState st_arg = st;
+                const int32_t* status_p = status_dev;
+                int32_t* rescored_p = status_dev + 1;
+                void* args[] = {&n_i, &theta_i, &drop_i, &users_i, &corrupted_i, &batch, &val_p, &idx_p, &rank_p, &dist_p, &st_arg,
+                                &status_p, &rescored_p, &wg_best, &n_listed_dev};
+                BYZ_HIP(hipLaunchCooperativeKernel(reinterpret_cast<const void*>(&large_decide_grid_kernel), dim3(grid_blocks),
+                                                   dim3(kGridBlock), args, static_cast<unsigned>(list_bytes), stream));
+            } else {
+                large_decide_kernel<<<1, 1024, 0, stream>>>((int)n, (int)theta, (int)drop_count, (int)users_count, (int)corrupted, batch,
+                                                            ctx->sorted_val.as<float>(), ctx->large_idx.as<uint32_t>(),
+                                                            ctx->large_rank_t.as<uint32_t>(), ctx->large_dist_t.as<float>(), st, status_dev,
+                                                            status_dev + 1);
+            }
             large_rescore_kernel<<<rescore_grid, 256, 0, stream>>>((int)n, (int)users_count, (int)corrupted, ctx->sorted_val.as<float>(),
                                                                    ctx->large_idx.as<uint32_t>(), st, status_dev);
             large_settle_kernel<<<1, 1024, 0, stream>>>((int)n, (int)theta, (int)drop_count, ctx->sorted_val.as<float>(),

@@ -145,13 +145,16 @@ def test_forced_large_when_the_reference_gives_up(eng, large):
     assert eng.krum_select(huge, n, f) == -1 == scale.krum_pick(huge, n, f)
 
 
-@pytest.mark.parametrize('batch', ['1', '3', '16', '32'])
+@pytest.mark.parametrize('batch', ['1', '3', '16', '32', '16 on one workgroup'])
 def test_forced_large_batches_select_the_same(eng, large, batch):
     """BYZ_LARGE_BATCH: picks decided on the exact scores before their contenders are scored together, the batch cut where the
-    reference's winner is not the guess.  Whatever the batch length: the reference's selection -- on data that contests most picks
+    reference's winner is not the guess.  Whatever the batch length, and whether the deciding kernel runs on the whole chip (a
+    cooperative launch, two grid barriers per pick) or on one workgroup (BYZ_LARGE_COOP=0): the reference's selection -- on data that contests most picks
     (guesses fail), on twins and exact ties (they must not), with rows that always contend, and where the reference gives up in the
     middle of a batch."""
-    large.setenv('BYZ_LARGE_BATCH', batch)
+    if batch.endswith('on one workgroup'):
+        large.setenv('BYZ_LARGE_COOP', '0')       # the deciding kernel without the cooperative launch (one workgroup walks all rows)
+    large.setenv('BYZ_LARGE_BATCH', batch.split()[0])
     for seed, n, dim, identical, quantum in [(1, 300, 2, 0, None), (2, 900, 16, 216, None), (3, 520, 8, 0, 0.25), (4, 1500, 2000, 0, None)]:
         dist = point_distances(8000 + seed, n, dim, identical, quantum)
         f = int(0.24 * n)
