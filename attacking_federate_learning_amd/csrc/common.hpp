@@ -293,7 +293,8 @@ size_t large_key_scratch_bytes();
 int launch_row_sort_large(byz_ctx* ctx, const float* dist, int64_t n, int64_t prefix_len, int64_t drop_count, bool want_tables,
                           hipStream_t stream);
 int launch_bulyan_loop_large(byz_ctx* ctx, const float* dist, int64_t n, int64_t theta, int64_t drop_count, int64_t users_count,
-                             int64_t corrupted, int32_t* selection_dev, int32_t* status_dev, hipStream_t stream);
+                             int64_t corrupted, const int32_t* twin_class, int32_t* selection_dev, int32_t* status_dev,
+                             hipStream_t stream);
 
 int launch_trimmed_mean(byz_ctx* ctx, const float* G, int64_t n_rows, int64_t n_cols, int64_t ld,
                         const int32_t* row_index, int64_t keep, float* out, hipStream_t stream);

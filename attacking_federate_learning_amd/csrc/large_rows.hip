@@ -120,6 +120,10 @@ struct LargeState {
     int32_t* first_kept;  // [n]
     int32_t* irregular;   // [n] the row holds a negative or non-finite distance: it is scored the reference's way at every pick
     int32_t* gone_at;     // [n] the pick that took the row (kNever: still there); live in the state of pick t <=> gone_at >= t
+    int32_t* leader;      // [n] by class (= its smallest row): the member the reference visits first among those still there (-1: none)
+    int32_t* leader_kept; // [n]
+    int32_t* next_twin;   // [n] the next member of the row's class in visit order (-1: the last one)
+    const int32_t* cls;   // [n] the row's twin class (select.hip's twin_class kernels; ctx->twin_class)
     int32_t* pair_row;    // [kBatchMax n] the contenders of the batch's picks, pick after pick
     float* pair_score;    // [kBatchMax n] their scores in the state of their pick
     int32_t* pair_begin;  // [kBatchMax + 1] where a pick's contenders begin
@@ -127,7 +131,7 @@ struct LargeState {
     int32_t* words;       // [4] the next pick, the picks of the current batch, (unused)
 };
 __host__ __device__ inline size_t large_state_bytes(int64_t n) {
-    return static_cast<size_t>(5 * n + 2) * sizeof(double) + static_cast<size_t>(4 * n + 2 * kBatchMax * n + 2 * kBatchMax + 8) * sizeof(int32_t) + 64;
+    return static_cast<size_t>(5 * n + 2) * sizeof(double) + static_cast<size_t>(7 * n + 2 * kBatchMax * n + 2 * kBatchMax + 8) * sizeof(int32_t) + 64;
 }
 __host__ __device__ inline LargeState large_state(void* p, int64_t n) {
     LargeState s;
@@ -141,7 +145,11 @@ __host__ __device__ inline LargeState large_state(void* p, int64_t n) {
     s.first_kept = s.top_first + n;
     s.irregular = s.first_kept + n;
     s.gone_at = s.irregular + n;
-    s.pair_row = s.gone_at + n;
+    s.leader = s.gone_at + n;
+    s.leader_kept = s.leader + n;
+    s.next_twin = s.leader_kept + n;
+    s.cls = nullptr;
+    s.pair_row = s.next_twin + n;
     s.pair_score = reinterpret_cast<float*>(s.pair_row + static_cast<int64_t>(kBatchMax) * n);
     s.pair_begin = reinterpret_cast<int32_t*>(s.pair_score + static_cast<int64_t>(kBatchMax) * n);
     s.guess = s.pair_begin + kBatchMax + 1;
@@ -369,6 +377,7 @@ __global__ __launch_bounds__(1024) void large_decide_kernel(int n, int theta, in
             for (int j = 0; j < kRows; ++j) {
                 const int u = base + j * 1024;
                 if (u >= n) continue;
+                if (k == 0) st.leader_kept[u] = st.leader[u];
                 if (!regular[j]) {
                     st.exact[u] = there[j] ? -__builtin_inf() : __builtin_nan("");
                     continue;
@@ -417,14 +426,19 @@ __global__ __launch_bounds__(1024) void large_decide_kernel(int n, int theta, in
         double bound = low * (1.0 + 2.1 * static_cast<double>(m) * 5.9604644775390625e-08 + 1e-9) + slack;
         if (!(low < 9e19) || m > (1 << 18)) bound = __builtin_inf();
         for (int u = tid; u < n; u += 1024) {
-            if (st.exact[u] <= bound) st.pair_row[atomicAdd(&n_listed, 1)] = u;      // (false for the NaN of a row that is gone)
+            const double e = st.exact[u];
+            // (false for the NaN of a row that is gone; of a twin class only the member the reference visits first; -inf: always)
+            if (e <= bound && (e == -__builtin_inf() || st.leader[st.cls[u]] == u)) st.pair_row[atomicAdd(&n_listed, 1)] = u;
         }
         __syncthreads();
         const int w = mine.row;
         if (tid == 0) {
             st.pair_begin[k + 1] = n_listed;
             st.guess[k] = w;
-            if (w >= 0) st.gone_at[w] = t;
+            if (w >= 0) {
+                st.gone_at[w] = t;
+                if (st.leader[st.cls[w]] == w) st.leader[st.cls[w]] = st.next_twin[w];
+            }
         }
         done = k + 1;
         w_prev = w;
@@ -441,6 +455,37 @@ __global__ __launch_bounds__(1024) void large_decide_kernel(int n, int theta, in
         const int pairs = n_listed;
         *rescored = *rescored > 0x7fffffff - pairs ? 0x7fffffff : *rescored + pairs;
     }
+}
+
+// Twin classes (select.hip: rows that are bitwise equal but for their own and each other's zero -- the attack's identical clients,
+// malicious.py:26-27): their live distance multisets stay equal through every removal, so their fp32 scores are one number and the
+// reference's strict '<' keeps the member it visits first.  Only that LEADER is ever listed and scored; when it leaves, the next
+// member in visit order leads.  (4,800 twins among 20,000 rows were 4,800 walks per pick.)
+__global__ __launch_bounds__(256) void large_twin_leader_kernel(int n, LargeState st) {
+    const int u = blockIdx.x * 256 + threadIdx.x;
+    if (u >= n) return;
+    // (before the loop: leader_kept holds the smallest visit POSITION of every class, 0x7fffffff where a row roots none; first_kept
+    // the classes' sizes)
+    atomicMin(&st.leader_kept[st.cls[u]], visit_position(u));
+    atomicAdd(&st.first_kept[st.cls[u]], 1);
+}
+__global__ __launch_bounds__(256) void large_twin_links_kernel(int n, LargeState st) {
+    const int u = blockIdx.x * 256 + threadIdx.x;
+    if (u >= n) return;
+    const int c = st.cls[u];
+    const int first = st.leader_kept[u];
+    st.leader[u] = first == 0x7fffffff ? -1 : visit_position(first);      // (the visit order 1, 0, 2, 3, ... is an involution)
+    int next = -1;
+    if (st.first_kept[c] > 1) {
+        for (int p = visit_position(u) + 1; p < n; ++p) {
+            const int v = visit_position(p);
+            if (st.cls[v] == c) {
+                next = v;
+                break;
+            }
+        }
+    }
+    st.next_twin[u] = next;
 }
 
 // The largest first total (the absolute slack of the running fp64 sums is taken from it), once per loop.
@@ -502,6 +547,7 @@ __global__ __launch_bounds__(kGridBlock) void large_decide_grid_kernel(int n, in
         Guess mine{__builtin_inf(), 0x7fffffff, -1};
         for (int u = gtid; u < n; u += gthreads) {
             const bool there = st.gone_at[u] >= t;
+            if (k == 0) st.leader_kept[u] = st.leader[u];
             if (!there || st.irregular[u] != 0) {
                 st.exact[u] = there ? -__builtin_inf() : __builtin_nan("");
                 continue;
@@ -559,7 +605,9 @@ __global__ __launch_bounds__(kGridBlock) void large_decide_grid_kernel(int n, in
         double bound = low * (1.0 + 2.1 * static_cast<double>(m) * 5.9604644775390625e-08 + 1e-9) + slack;      // (large_decide_kernel)
         if (!(low < 9e19) || m > (1 << 18)) bound = __builtin_inf();
         for (int u = gtid; u < n; u += gthreads) {
-            if (st.exact[u] <= bound) lds_list[atomicAdd(&lds_count, 1)] = u;      // (false for the NaN of a row that is gone)
+            const double e = st.exact[u];
+            // (false for the NaN of a row that is gone; of a twin class only the member the reference visits first; -inf: always)
+            if (e <= bound && (e == -__builtin_inf() || st.leader[st.cls[u]] == u)) lds_list[atomicAdd(&lds_count, 1)] = u;
         }
         __syncthreads();
         if (tid == 0) lds_base = lds_count > 0 ? atomicAdd(n_listed, lds_count) : 0;
@@ -573,7 +621,11 @@ __global__ __launch_bounds__(kGridBlock) void large_decide_grid_kernel(int n, in
         done = k + 1;
         w_prev = w;
         grid.sync();
-        if (gtid == 0) st.pair_begin[k + 1] = *n_listed;
+        if (gtid == 0) {
+            st.pair_begin[k + 1] = *n_listed;
+            // (only now: other workgroups were still listing THIS pick by its leaders; the next pick's list is behind the next barrier)
+            if (w >= 0 && st.leader[st.cls[w]] == w) st.leader[st.cls[w]] = st.next_twin[w];
+        }
         if (w < 0) break;
     }
     if (w_prev >= 0) {         // the batch's last guess leaves the sums too: the state the next batch starts from
@@ -699,6 +751,7 @@ __global__ __launch_bounds__(1024) void large_settle_kernel(int n, int theta, in
         // -1, the reference's distances.pop(-1) raises KeyError -- ends the loop: status 1.)
         __syncthreads();
         for (int u = tid; u < n; u += 1024) {
+            st.leader[u] = st.leader_kept[u];
             if (st.gone_at[u] < t0 || st.irregular[u]) continue;      // (gone before the batch / never summed: nothing was kept)
             st.total[u] = st.total_kept[u];
             st.top[u] = st.top_kept[u];
@@ -720,7 +773,9 @@ __global__ __launch_bounds__(1024) void large_settle_kernel(int n, int theta, in
         __threadfence_block();
         __syncthreads();
         for (int j = 0; j <= k; ++j) {
-            remove_from_rows(selection[t0 + j], t0 + j, n, drop, sorted_val, sorted_idx, rank_t, dist_t, st);
+            const int w = selection[t0 + j];
+            if (tid == 0 && st.leader[st.cls[w]] == w) st.leader[st.cls[w]] = st.next_twin[w];
+            remove_from_rows(w, t0 + j, n, drop, sorted_val, sorted_idx, rank_t, dist_t, st);
             __syncthreads();
         }
         if (tid == 0) st.words[0] = t0 + k + 1;
@@ -808,12 +863,15 @@ int launch_row_sort_large(byz_ctx* ctx, const float* dist, int64_t n, int64_t pr
 }
 
 int launch_bulyan_loop_large(byz_ctx* ctx, const float* dist, int64_t n, int64_t theta, int64_t drop_count, int64_t users_count,
-                             int64_t corrupted, int32_t* selection_dev, int32_t* status_dev, hipStream_t stream) {
+                             int64_t corrupted, const int32_t* twin_class, int32_t* selection_dev, int32_t* status_dev,
+                             hipStream_t stream) {
     BYZ_REQUIRE(dist && selection_dev && status_dev && n > 0 && theta >= 0 && theta <= n,
                 "bulyan loop (large): bad arguments (n=%lld theta=%lld)", (long long)n, (long long)theta);
     BYZ_REQUIRE(ctx->large_state.bytes >= large_state_bytes(n) && ctx->large_idx.ptr && ctx->large_rank_t.ptr && ctx->large_dist_t.ptr,
                 "bulyan loop (large): the row sort has not run");
-    const LargeState st = large_state(ctx->large_state.ptr, n);
+    LargeState st = large_state(ctx->large_state.ptr, n);
+    st.cls = twin_class;
+    BYZ_REQUIRE(twin_class != nullptr, "bulyan loop (large): no twin classes");
     // BYZ_LARGE_BATCH=<k>: picks decided on the exact scores before their contenders are scored together (default 16, at most 32;
     // 1: every pick settled before the next one is decided).  The same selection, pick for pick.
     int batch = 16;
@@ -834,9 +892,13 @@ int launch_bulyan_loop_large(byz_ctx* ctx, const float* dist, int64_t n, int64_t
     BYZ_TRY(ctx->large_grid.ensure(static_cast<size_t>(kGridMaxBlocks) * sizeof(Guess) + 64));
     Guess* wg_best = ctx->large_grid.as<Guess>();
     int32_t* n_listed_dev = reinterpret_cast<int32_t*>(wg_best + kGridMaxBlocks);
-    KernelTimer timer(ctx, BYZ_K_BULYAN_LOOP, stream);
-    large_scale_kernel<<<1, 1024, 0, stream>>>((int)n, st);
+    large_scale_kernel<<<1, 1024, 0, stream>>>((int)n, st);      // (timed by the caller: launch_bulyan_loop's KernelTimer)
     BYZ_TRY(check_launch("large_scale_kernel"));
+    BYZ_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(st.leader_kept), 0x7fffffff, static_cast<size_t>(n), stream));
+    BYZ_HIP(hipMemsetAsync(st.first_kept, 0, static_cast<size_t>(n) * sizeof(int32_t), stream));
+    large_twin_leader_kernel<<<static_cast<unsigned>(ceil_div(n, 256)), 256, 0, stream>>>((int)n, st);
+    large_twin_links_kernel<<<static_cast<unsigned>(ceil_div(n, 256)), 256, 0, stream>>>((int)n, st);
+    BYZ_TRY(check_launch("large_twin_links_kernel"));
     const unsigned rescore_grid = static_cast<unsigned>(ctx->num_cus) * 4;      // 16 waves per CU
     // The host does not know where a batch was cut: it queues as many batches as the picks left would take if every batch stood,
     // a few more, and looks at the next pick; queued batches behind the last pick leave at once.

@@ -1838,8 +1838,6 @@ int launch_bulyan_loop(byz_ctx* ctx, const float* dist, int64_t n, int64_t theta
                        hipStream_t stream) {
     BYZ_REQUIRE(dist && selection_dev && status_dev && n > 0 && theta >= 0 && theta <= n,
                 "bulyan loop: bad arguments (n=%lld theta=%lld)", (long long)n, (long long)theta);
-    if (select_large_applies(n))
-        return launch_bulyan_loop_large(ctx, dist, n, theta, drop_count, users_count, corrupted, selection_dev, status_dev, stream);
     BYZ_TRY(ctx->twin_class.ensure(static_cast<size_t>(2 * n) * sizeof(int32_t)));
     // granules: [2][A, B, R][64 workgroups], then the speculative loop's [2][32 picks of a batch][64], then its three counters
     constexpr size_t kGranules = static_cast<size_t>(2 * 3 + 2 * kSpecMax) * kGridMaxWgs;
@@ -1877,6 +1875,8 @@ int launch_bulyan_loop(byz_ctx* ctx, const float* dist, int64_t n, int64_t theta
     BYZ_TRY(check_launch("twin_class_kernel"));
     twin_class_fix_kernel<<<static_cast<unsigned>(ceil_div(n, 256)), 256, 0, stream>>>(cls_tmp, (int)n, cls);
     BYZ_TRY(check_launch("twin_class_fix_kernel"));
+    if (select_large_applies(n))      // beyond 16,384 rows (large_rows.hip, inside this launcher's timer); the twin classes serve it too
+        return launch_bulyan_loop_large(ctx, dist, n, theta, drop_count, users_count, corrupted, cls, selection_dev, status_dev, stream);
     const unsigned n_wgs = static_cast<unsigned>(ceil_div(n, kGridThreads));   // <= 64: all resident, they wait for each other
     // BYZ_BULYAN_BATCH=<k>: picks decided optimistically before their contested ones are verified together (bulyan_spec_kernel;
     // default 32 from 1000 rows, 16 from 6000; at most 32); 0: bulyan_grid_kernel, every contested pick re-scored before the next one (rounds 2-5; also taken for
