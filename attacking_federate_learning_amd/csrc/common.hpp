@@ -289,6 +289,7 @@ int launch_bulyan_loop(byz_ctx* ctx, const float* dist, int64_t n, int64_t theta
 constexpr int64_t kLargeMaxRows = int64_t{1} << 20;
 bool select_large_applies(int64_t n);
 int segment_sort_u64(byz_ctx* ctx, unsigned long long* keys, int64_t n_segments, int64_t n_pad, hipStream_t stream);
+int segment_sort_u32(byz_ctx* ctx, uint32_t* keys, int64_t n_segments, int64_t n_pad, hipStream_t stream);
 size_t large_key_scratch_bytes();
 int launch_row_sort_large(byz_ctx* ctx, const float* dist, int64_t n, int64_t prefix_len, int64_t drop_count, bool want_tables,
                           hipStream_t stream);

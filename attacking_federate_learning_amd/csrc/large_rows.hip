@@ -26,7 +26,6 @@
 namespace byz {
 namespace {
 
-constexpr int kChunk = 4096;          // keys of one LDS-resident merge (32 KiB)
 constexpr int kSortThreads = 1024;
 constexpr float kKrumInit = 1e20f;    // defences.py:27
 constexpr size_t kKeyScratchBytes = size_t{4} << 30;
@@ -40,16 +39,21 @@ __device__ __forceinline__ float from_ordered_bits(uint32_t o) {
 }
 __device__ __forceinline__ int visit_position(int u) { return u == 0 ? 1 : (u == 1 ? 0 : u); }
 
-// FIRST: every merge k = 2 .. len of one chunk; else the levels j = len / 2 .. 1 of the merge of size k_merge
-template <bool FIRST>
-__global__ __launch_bounds__(kSortThreads) void segment_sort_local_kernel(unsigned long long* __restrict__ keys, int64_t n_pad,
-                                                                          int chunks_per_seg, int64_t k_merge) {
-    __shared__ unsigned long long lds[kChunk];
+// FIRST: every merge k = 2 .. len of one chunk; else the levels j = len / 2 .. 1 of the merge of size k_merge.  A chunk is 32 KiB of
+// keys: 4096 of 64 bits (value | column: the selection), 8192 of 32 bits (values alone: the trimmed mean).
+template <typename K>
+constexpr int chunk_keys() { return static_cast<int>(32768 / sizeof(K)); }
+
+template <typename K, bool FIRST>
+__global__ __launch_bounds__(kSortThreads) void segment_sort_local_kernel(K* __restrict__ keys, int64_t n_pad, int chunks_per_seg,
+                                                                          int64_t k_merge) {
+    constexpr int CH = chunk_keys<K>();
+    __shared__ K lds[CH];
     const int64_t seg = blockIdx.x / chunks_per_seg;
     const int64_t ch = blockIdx.x % chunks_per_seg;
-    const int len = n_pad < kChunk ? static_cast<int>(n_pad) : kChunk;
-    const int64_t i0 = ch * kChunk;                       // position of lds[0] inside its segment
-    unsigned long long* const base = keys + seg * n_pad + i0;
+    const int len = n_pad < CH ? static_cast<int>(n_pad) : CH;
+    const int64_t i0 = ch * CH;                       // position of lds[0] inside its segment
+    K* const base = keys + seg * n_pad + i0;
     const int tid = threadIdx.x;
     for (int i = tid; i < len; i += kSortThreads) lds[i] = base[i];
     __syncthreads();
@@ -59,7 +63,7 @@ __global__ __launch_bounds__(kSortThreads) void segment_sort_local_kernel(unsign
             for (int p = tid; p < len / 2; p += kSortThreads) {
                 const int i = ((p & ~(j - 1)) << 1) | (p & (j - 1));
                 const int q = i | j;
-                const unsigned long long a = lds[i], b = lds[q];
+                const K a = lds[i], b = lds[q];
                 const bool up = ((i0 + i) & k) == 0;
                 if ((a > b) == up) {
                     lds[i] = b;
@@ -72,17 +76,18 @@ __global__ __launch_bounds__(kSortThreads) void segment_sort_local_kernel(unsign
     for (int i = tid; i < len; i += kSortThreads) base[i] = lds[i];
 }
 
-// one level (stride j >= kChunk) of the merge of size k, every segment at once
-__global__ __launch_bounds__(256) void segment_sort_global_kernel(unsigned long long* __restrict__ keys, int64_t n_pad,
-                                                                  int64_t n_pairs, int64_t k, int64_t j) {
+// one level (stride j >= a chunk) of the merge of size k, every segment at once
+template <typename K>
+__global__ __launch_bounds__(256) void segment_sort_global_kernel(K* __restrict__ keys, int64_t n_pad, int64_t n_pairs, int64_t k,
+                                                                  int64_t j) {
     const int64_t g = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
     if (g >= n_pairs) return;
     const int64_t half = n_pad >> 1;
     const int64_t seg = g / half, p = g % half;
     const int64_t i = ((p & ~(j - 1)) << 1) | (p & (j - 1));
     const int64_t q = i | j;
-    unsigned long long* const base = keys + seg * n_pad;
-    const unsigned long long a = base[i], b = base[q];
+    K* const base = keys + seg * n_pad;
+    const K a = base[i], b = base[q];
     const bool up = (i & k) == 0;
     if ((a > b) == up) {
         base[i] = b;
@@ -786,25 +791,35 @@ __global__ __launch_bounds__(1024) void large_settle_kernel(int n, int theta, in
 
 }  // namespace
 
-int segment_sort_u64(byz_ctx* ctx, unsigned long long* keys, int64_t n_segments, int64_t n_pad, hipStream_t stream) {
+template <typename K>
+static int segment_sort(K* keys, int64_t n_segments, int64_t n_pad, hipStream_t stream) {
     BYZ_REQUIRE(keys && n_segments > 0 && n_pad >= 2 && (n_pad & (n_pad - 1)) == 0, "segment sort: bad arguments");
-    (void)ctx;
-    const int64_t chunks = n_pad < kChunk ? 1 : n_pad / kChunk;
+    constexpr int CH = chunk_keys<K>();
+    const int64_t chunks = n_pad < CH ? 1 : n_pad / CH;
     BYZ_REQUIRE(n_segments * chunks <= 0x7fffffff && ceil_div(n_segments * (n_pad / 2), 256) <= 0x7fffffff,
                 "segment sort: too many keys for one launch");
     const unsigned local_grid = static_cast<unsigned>(n_segments * chunks);
-    segment_sort_local_kernel<true><<<local_grid, kSortThreads, 0, stream>>>(keys, n_pad, static_cast<int>(chunks), 0);
+    segment_sort_local_kernel<K, true><<<local_grid, kSortThreads, 0, stream>>>(keys, n_pad, static_cast<int>(chunks), 0);
     BYZ_TRY(check_launch("segment_sort_local_kernel"));
     const int64_t n_pairs = n_segments * (n_pad / 2);
-    for (int64_t k = 2 * static_cast<int64_t>(kChunk); k <= n_pad; k <<= 1) {
-        for (int64_t j = k / 2; j >= kChunk; j >>= 1) {
-            segment_sort_global_kernel<<<static_cast<unsigned>(ceil_div(n_pairs, 256)), 256, 0, stream>>>(keys, n_pad, n_pairs, k, j);
+    for (int64_t k = 2 * static_cast<int64_t>(CH); k <= n_pad; k <<= 1) {
+        for (int64_t j = k / 2; j >= CH; j >>= 1) {
+            segment_sort_global_kernel<K><<<static_cast<unsigned>(ceil_div(n_pairs, 256)), 256, 0, stream>>>(keys, n_pad, n_pairs, k, j);
             BYZ_TRY(check_launch("segment_sort_global_kernel"));
         }
-        segment_sort_local_kernel<false><<<local_grid, kSortThreads, 0, stream>>>(keys, n_pad, static_cast<int>(chunks), k);
+        segment_sort_local_kernel<K, false><<<local_grid, kSortThreads, 0, stream>>>(keys, n_pad, static_cast<int>(chunks), k);
         BYZ_TRY(check_launch("segment_sort_local_kernel"));
     }
     return BYZ_OK;
+}
+
+int segment_sort_u64(byz_ctx* ctx, unsigned long long* keys, int64_t n_segments, int64_t n_pad, hipStream_t stream) {
+    (void)ctx;
+    return segment_sort<unsigned long long>(keys, n_segments, n_pad, stream);
+}
+int segment_sort_u32(byz_ctx* ctx, uint32_t* keys, int64_t n_segments, int64_t n_pad, hipStream_t stream) {
+    (void)ctx;
+    return segment_sort<uint32_t>(keys, n_segments, n_pad, stream);
 }
 
 size_t large_key_scratch_bytes() {

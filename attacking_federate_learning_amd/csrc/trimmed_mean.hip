@@ -242,7 +242,8 @@ __global__ __launch_bounds__(1024) void trimmed_mean_lds_kernel(const float* __r
 }
 
 // ---- more than 16,384 rows: the columns sorted in global memory (large_rows.hip's segment sort), the same window code ----
-// Keys: order-preserving float bits << 32 | row; padding rows are all-ones keys behind every value, NaN included.
+// Keys: the order-preserving float bits alone (32 bits: the window code asks a sorted column for values only, and settles ties at its
+// edge by reading G in row order); padding rows are all-ones keys, behind every value (and decoding to a NaN like one).
 __device__ __forceinline__ uint32_t ordered_bits(float v) {
     const uint32_t b = __float_as_uint(v);
     return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
@@ -251,35 +252,42 @@ __device__ __forceinline__ float from_ordered_bits(uint32_t o) {     // (branch-
     return __uint_as_float(o ^ (~static_cast<uint32_t>(static_cast<int32_t>(o) >> 31) | 0x80000000u));
 }
 
-// column (c0 + blockIdx.y) of the batch; a column beyond the matrix is filled with zeros (its quad's other columns are real)
+// 64 rows x 64 columns of the batch per workgroup: read along the rows of G, written along the columns' key arrays (a thread per
+// (row, column) read 4 bytes out of every 64-byte sector it touched).  A column beyond the matrix is filled with zeros (its quad's
+// other columns are real); a padding row is an all-ones key.
 __global__ __launch_bounds__(256) void large_column_keys_kernel(const float* __restrict__ G, int n_rows, int64_t n_pad, int64_t c0,
-                                                                int64_t n_cols, int64_t ld, const int32_t* __restrict__ row_index,
-                                                                unsigned long long* __restrict__ keys) {
-    const int64_t r = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
-    if (r >= n_pad) return;
-    const int64_t c = c0 + blockIdx.y;
-    unsigned long long key = ~0ull;
-    if (r < n_rows) {
-        const int64_t src = row_index ? row_index[r] : r;
-        const float v = c < n_cols ? G[src * ld + c] : 0.0f;
-        key = (static_cast<unsigned long long>(ordered_bits(v)) << 32) | static_cast<unsigned>(r);
+                                                                int64_t n_batch_cols, int64_t n_cols, int64_t ld,
+                                                                const int32_t* __restrict__ row_index, uint32_t* __restrict__ keys) {
+    __shared__ uint32_t tile[64][65];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int64_t r0 = static_cast<int64_t>(blockIdx.x) * 64, b0 = static_cast<int64_t>(blockIdx.y) * 64;
+    for (int i = ty; i < 64; i += 4) {
+        const int64_t r = r0 + i, c = c0 + b0 + tx;
+        uint32_t key = ~0u;
+        if (r < n_rows) {
+            const int64_t src = row_index ? row_index[r] : r;
+            key = ordered_bits(c < n_cols ? G[src * ld + c] : 0.0f);
+        }
+        tile[i][tx] = key;
     }
-    keys[static_cast<int64_t>(blockIdx.y) * n_pad + r] = key;
+    __syncthreads();
+    for (int i = ty; i < 64; i += 4) {
+        const int64_t b = b0 + i, r = r0 + tx;
+        if (b < n_batch_cols && r < n_pad) keys[b * n_pad + r] = tile[tx][i];
+    }
 }
 
 struct SortedKeyQuad {
-    const unsigned long long* base;   // four columns of n_pad sorted keys each
+    const uint32_t* base;   // four columns of n_pad sorted keys each
     int64_t n_pad;
     __device__ __forceinline__ f32x4 at(int rank) const {
-        return f32x4{from_ordered_bits(static_cast<uint32_t>(base[rank] >> 32)),
-                     from_ordered_bits(static_cast<uint32_t>(base[n_pad + rank] >> 32)),
-                     from_ordered_bits(static_cast<uint32_t>(base[2 * n_pad + rank] >> 32)),
-                     from_ordered_bits(static_cast<uint32_t>(base[3 * n_pad + rank] >> 32))};
+        return f32x4{from_ordered_bits(base[rank]), from_ordered_bits(base[n_pad + rank]), from_ordered_bits(base[2 * n_pad + rank]),
+                     from_ordered_bits(base[3 * n_pad + rank])};
     }
 };
 
 // one wave per quad of columns
-__global__ __launch_bounds__(64) void large_window_kernel(const unsigned long long* __restrict__ keys, int64_t n_pad,
+__global__ __launch_bounds__(64) void large_window_kernel(const uint32_t* __restrict__ keys, int64_t n_pad,
                                                           const float* __restrict__ G, int64_t ld,
                                                           const int32_t* __restrict__ row_index, int n_rows, int keep, int64_t c0,
                                                           int64_t n_cols, float* __restrict__ out) {
@@ -291,8 +299,8 @@ __global__ __launch_bounds__(64) void large_window_kernel(const unsigned long lo
     // a NaN anywhere in the column: np.median is NaN and so is everything after it.  By the keys a NaN sorts to one of the
     // two ends (sign bit set: first, clear: last)
     if (lane < 4 && c + lane < n_cols) {
-        const uint32_t first = __float_as_uint(from_ordered_bits(static_cast<uint32_t>(sorted.base[lane * n_pad] >> 32)));
-        const uint32_t last = __float_as_uint(from_ordered_bits(static_cast<uint32_t>(sorted.base[lane * n_pad + n_rows - 1] >> 32)));
+        const uint32_t first = __float_as_uint(from_ordered_bits(sorted.base[lane * n_pad]));
+        const uint32_t last = __float_as_uint(from_ordered_bits(sorted.base[lane * n_pad + n_rows - 1]));
         if ((first & 0x7fffffffu) > 0x7f800000u || (last & 0x7fffffffu) > 0x7f800000u) out[c + lane] = __uint_as_float(0x7fc00000u);
     }
 }
@@ -324,19 +332,19 @@ int launch_trimmed_mean_large(byz_ctx* ctx, const float* G, int64_t n_rows, int6
         return BYZ_E_UNSUPPORTED;
     }
     const int64_t n_pad = next_pow2(n_rows < 2 ? 2 : n_rows);
-    int64_t batch = static_cast<int64_t>(large_key_scratch_bytes() / (static_cast<size_t>(n_pad) * 8)) & ~int64_t{3};
+    int64_t batch = static_cast<int64_t>(large_key_scratch_bytes() / (static_cast<size_t>(n_pad) * 4)) & ~int64_t{3};
     if (batch < 4) batch = 4;
     if (batch > 32768) batch = 32768;                       // (the keys kernel's grid.y)
     const int64_t cols4 = ceil_div(n_cols, 4) * 4;
     if (batch > cols4) batch = cols4;
-    BYZ_TRY(ctx->large_keys.ensure(static_cast<size_t>(batch) * n_pad * 8));
-    unsigned long long* keys = ctx->large_keys.as<unsigned long long>();
+    BYZ_TRY(ctx->large_keys.ensure(static_cast<size_t>(batch) * n_pad * 4));
+    uint32_t* keys = ctx->large_keys.as<uint32_t>();
     for (int64_t c0 = 0; c0 < n_cols; c0 += batch) {
         const int64_t cols = cols4 - c0 < batch ? cols4 - c0 : batch;     // a multiple of 4
-        large_column_keys_kernel<<<dim3(static_cast<unsigned>(ceil_div(n_pad, 256)), static_cast<unsigned>(cols)), 256, 0, stream>>>(
-            G, (int)n_rows, n_pad, c0, n_cols, ld, row_index, keys);
+        large_column_keys_kernel<<<dim3(static_cast<unsigned>(ceil_div(n_pad, 64)), static_cast<unsigned>(ceil_div(cols, 64))), 256, 0, stream>>>(
+            G, (int)n_rows, n_pad, c0, cols, n_cols, ld, row_index, keys);
         BYZ_TRY(check_launch("large_column_keys_kernel"));
-        BYZ_TRY(segment_sort_u64(ctx, keys, cols, n_pad, stream));
+        BYZ_TRY(segment_sort_u32(ctx, keys, cols, n_pad, stream));
         large_window_kernel<<<static_cast<unsigned>(cols / 4), 64, 0, stream>>>(keys, n_pad, G, ld, row_index, (int)n_rows, (int)keep, c0,
                                                                              n_cols, out);
         BYZ_TRY(check_launch("large_window_kernel"));
