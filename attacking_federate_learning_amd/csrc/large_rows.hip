@@ -111,6 +111,36 @@ __global__ __launch_bounds__(256) void large_row_keys_kernel(const float* __rest
     keys[static_cast<int64_t>(blockIdx.y) * n_pad + c] = key;
 }
 
+// Krum alone needs no columns: the sorted VALUES are all a score is made of (defences.py:33-34), so its keys are 32 bits (half the
+// bytes through the sort, 8192 keys per LDS chunk)
+__global__ __launch_bounds__(256) void large_row_keys32_kernel(const float* __restrict__ dist, int n, int64_t n_pad, int row0,
+                                                               uint32_t* __restrict__ keys) {
+    const int u = row0 + blockIdx.y;
+    const int64_t c = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
+    if (c >= n_pad) return;
+    uint32_t key = 0xffffffffu;      // padding, and the self entry: behind every real one (the prefix never reaches rank n - 1)
+    if (c < n && c != u) {
+        const float d = dist[static_cast<int64_t>(u) * n + c];
+        key = d != d ? 0xfffffffeu : ordered_bits(d);
+    }
+    keys[static_cast<int64_t>(blockIdx.y) * n_pad + c] = key;
+}
+
+// one wave per sorted row: Python's sum() over np.float32 scalars (defences.py:34): 0 + x0, then one fp32 addition per value
+__global__ __launch_bounds__(64) void large_row_scores32_kernel(const uint32_t* __restrict__ keys, int64_t n_pad, int row0,
+                                                                int prefix_len, float* __restrict__ scores) {
+    const int lane = threadIdx.x;
+    const uint32_t* const row = keys + static_cast<int64_t>(blockIdx.x) * n_pad;
+    float s = 0.0f;
+    for (int r0 = 0; r0 < prefix_len; r0 += 64) {
+        const int r = r0 + lane;
+        const float v = r < prefix_len ? from_ordered_bits(row[r]) : 0.0f;
+        const int cnt = prefix_len - r0 < 64 ? prefix_len - r0 : 64;
+        for (int i = 0; i < cnt; ++i) s = __fadd_rn(s, __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), i)));
+    }
+    if (lane == 0) scores[row0 + blockIdx.x] = s;
+}
+
 // the state of the Bulyan loop (ctx->large_state): doubles first, then the 32-bit words
 constexpr int kBatchMax = 32;          // picks decided on the exact scores before their contenders are scored together
 constexpr int kNever = 0x7fffffff;     // gone_at of a row that is still there
@@ -849,6 +879,22 @@ int launch_row_sort_large(byz_ctx* ctx, const float* dist, int64_t n, int64_t pr
     const LargeState st = large_state(ctx->large_state.ptr, n);
     unsigned long long* keys = ctx->large_keys.as<unsigned long long>();
     KernelTimer timer(ctx, BYZ_K_ROW_SORT, stream);
+    if (!want_tables) {      // Krum alone: 32-bit keys, twice the rows per batch
+        uint32_t* keys32 = ctx->large_keys.as<uint32_t>();
+        int64_t rows32 = 2 * rows_per_batch < n ? 2 * rows_per_batch : n;
+        if (rows32 > 32768) rows32 = 32768;
+        for (int64_t row0 = 0; row0 < n; row0 += rows32) {
+            const int64_t rows = n - row0 < rows32 ? n - row0 : rows32;
+            large_row_keys32_kernel<<<dim3(static_cast<unsigned>(ceil_div(n_pad, 256)), static_cast<unsigned>(rows)), 256, 0, stream>>>(
+                dist, (int)n, n_pad, (int)row0, keys32);
+            BYZ_TRY(check_launch("large_row_keys32_kernel"));
+            BYZ_TRY(segment_sort_u32(ctx, keys32, rows, n_pad, stream));
+            large_row_scores32_kernel<<<static_cast<unsigned>(rows), 64, 0, stream>>>(keys32, n_pad, (int)row0, (int)prefix_len,
+                                                                                      ctx->scores.as<float>());
+            BYZ_TRY(check_launch("large_row_scores32_kernel"));
+        }
+        return BYZ_OK;
+    }
     for (int64_t row0 = 0; row0 < n; row0 += rows_per_batch) {
         const int64_t rows = n - row0 < rows_per_batch ? n - row0 : rows_per_batch;
         large_row_keys_kernel<<<dim3(static_cast<unsigned>(ceil_div(n_pad, 256)), static_cast<unsigned>(rows)), 256, 0, stream>>>(
