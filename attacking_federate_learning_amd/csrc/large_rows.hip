@@ -192,8 +192,7 @@ __host__ __device__ inline LargeState large_state(void* p, int64_t n) {
     return s;
 }
 
-// One workgroup per sorted row: the Krum score, and for Bulyan the tables and the row's state.
-template <bool TABLES>
+// One workgroup per sorted row (Bulyan; Krum alone takes the 32-bit kernels above): the Krum score, the tables and the row's state.
 __global__ __launch_bounds__(256) void large_row_tables_kernel(const unsigned long long* __restrict__ keys, int n, int64_t n_pad,
                                                                int row0, int prefix_len, int drop, float* __restrict__ scores,
                                                                float* __restrict__ sorted_val, uint32_t* __restrict__ sorted_idx,
@@ -213,7 +212,7 @@ __global__ __launch_bounds__(256) void large_row_tables_kernel(const unsigned lo
         }
         if (tid == 0) scores[u] = s;
     }
-    if constexpr (TABLES) {
+    {
         double tot = 0.0, top = 0.0;
         int odd = 0;
         const int first_top = n - 1 - drop;
@@ -901,16 +900,12 @@ int launch_row_sort_large(byz_ctx* ctx, const float* dist, int64_t n, int64_t pr
             dist, (int)n, n_pad, (int)row0, keys);
         BYZ_TRY(check_launch("large_row_keys_kernel"));
         BYZ_TRY(segment_sort_u64(ctx, keys, rows, n_pad, stream));
-        if (want_tables)
-            large_row_tables_kernel<true><<<static_cast<unsigned>(rows), 256, 0, stream>>>(
-                keys, (int)n, n_pad, (int)row0, (int)prefix_len, (int)drop_count, ctx->scores.as<float>(), ctx->sorted_val.as<float>(),
-                ctx->large_idx.as<uint32_t>(), ctx->large_rank.as<uint32_t>(), st);
-        else
-            large_row_tables_kernel<false><<<static_cast<unsigned>(rows), 256, 0, stream>>>(
-                keys, (int)n, n_pad, (int)row0, (int)prefix_len, (int)drop_count, ctx->scores.as<float>(), nullptr, nullptr, nullptr, st);
+        large_row_tables_kernel<<<static_cast<unsigned>(rows), 256, 0, stream>>>(
+            keys, (int)n, n_pad, (int)row0, (int)prefix_len, (int)drop_count, ctx->scores.as<float>(), ctx->sorted_val.as<float>(),
+            ctx->large_idx.as<uint32_t>(), ctx->large_rank.as<uint32_t>(), st);
         BYZ_TRY(check_launch("large_row_tables_kernel"));
     }
-    if (want_tables) {
+    {
         // the winner's rank in every row and its distance to every row, as ROWS: what a pick reads (remove_from_rows)
         BYZ_TRY(ctx->large_rank_t.ensure(static_cast<size_t>(n) * n * sizeof(uint32_t)));
         BYZ_TRY(ctx->large_dist_t.ensure(static_cast<size_t>(n) * n * sizeof(float)));
