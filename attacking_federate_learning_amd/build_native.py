@@ -18,7 +18,7 @@ LIB = os.path.join(HERE, 'libbyzagg.so')
 ARCH = 'gfx950'
 
 SOURCES = ['api.hip', 'column_stats.hip', 'gram.hip', 'select.hip', 'trimmed_mean.hip', 'median_window.hip',
-           'round_edges.hip', 'dedup.hip', 'gram_planes.hip', 'krum_small.hip', 'window_lean.hip', 'large_rows.hip']
+           'round_edges.hip', 'dedup.hip', 'gram_planes.hip', 'krum_small.hip', 'window_lean.hip', 'large_rows.hip', 'tall_select.hip']
 # The sorting network only orders finite values and +/-inf padding; NaN inputs are unspecified in the
 # reference as well.  Without this flag every v_min/v_max is preceded by a
 # canonicalising v_max (sNaN quieting), +30% VALU work in the hot kernel.

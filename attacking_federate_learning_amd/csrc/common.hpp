@@ -301,6 +301,10 @@ int launch_trimmed_mean(byz_ctx* ctx, const float* G, int64_t n_rows, int64_t n_
                         const int32_t* row_index, int64_t keep, float* out, hipStream_t stream);
 int64_t trimmed_mean_max_rows();
 bool trimmed_mean_large_applies(int64_t n_rows);
+// tall_select.hip: more rows than the register kernels hold (5,632): order statistics by radix select, the column streamed from HBM
+bool trimmed_mean_tall_applies(int64_t n_rows);
+int launch_trimmed_mean_tall(byz_ctx* ctx, const float* G, int64_t n_rows, int64_t n_cols, int64_t ld, const int32_t* row_index,
+                             int64_t keep, float* out, hipStream_t stream);
 int launch_trimmed_mean_large(byz_ctx* ctx, const float* G, int64_t n_rows, int64_t n_cols, int64_t ld, const int32_t* row_index,
                               int64_t keep, float* out, hipStream_t stream);
 // window_lean.hip: the row-split ring selection, first stage of the trimmed mean (round 3)

@@ -944,6 +944,14 @@ int launch_trimmed_mean(byz_ctx* ctx, const float* G, int64_t n_rows, int64_t n_
     BYZ_REQUIRE(ceil_div(n_cols, kCols) <= 0x7fffffff, "trimmed_mean: too many columns");
     KernelTimer t(ctx, BYZ_K_TRIMMED_MEAN, stream);
     ctx->redo_valid = false;
+    {
+        // beyond the register kernels' 5,632 rows: a radix select over the column streamed from HBM (tall_select.hip); BYZ_TM_LARGE=1
+        // forces the global-memory sort at every height, BYZ_TM_TALL=0 leaves the heights to the two sorts of rounds 3-6
+        const char* forced_sort = std::getenv("BYZ_TM_LARGE");
+        const bool sort_anyway = forced_sort != nullptr && std::atoi(forced_sort) != 0;
+        if (!sort_anyway && trimmed_mean_tall_applies(n_rows))
+            return launch_trimmed_mean_tall(ctx, G, n_rows, n_cols, ld, row_index, keep, out, stream);
+    }
     if (trimmed_mean_large_applies(n_rows)) return launch_trimmed_mean_large(ctx, G, n_rows, n_cols, ld, row_index, keep, out, stream);
     const int64_t rpl = ceil_div(n_rows, 64);
     if (rpl > 88) return launch_trimmed_mean_sorted(ctx, G, n_rows, n_cols, ld, row_index, keep, out, stream);

@@ -276,3 +276,49 @@ def test_the_defences_end_to_end_beyond_the_lds_kernels(eng, attacked):
     cols = rng.integers(0, d, 4)
     want = faithful.trimmed_mean(g[np.asarray(selection)][:, cols], n - 2 * f, 2 * f)
     assert close(out.numpy()[cols], want)
+
+
+# ---- tall columns: the radix select of csrc/tall_select.hip (5,633 rows and more, the default there) --------------------------------
+@pytest.mark.parametrize('n,cols,c', [(5633, 70, 1400), (6000, 64, 2880), (7001, 33, 1), (8192, 65, 4000), (10000, 130, 4800), (16384, 9, 7000)])
+def test_tall_select_is_the_reference_trimmed_mean(eng, monkeypatch, n, cols, c):
+    """defences.py:44-52 on columns taller than the register kernels hold: odd and even counts (one or two middle values), quarter-integer
+    data (exact +t / -t ties at the window's edge: row order decides, defences.py:50), continuous data, a selection's row order, the
+    extremes of the trim, a NaN, infinities; against oracle.faithful, and the sort kernels of rounds 3-6 (BYZ_TM_TALL=0) agree."""
+    rng = np.random.default_rng(9000 + n)
+    g = (np.round(rng.standard_normal((n, cols)) * 64) / 64).astype(np.float32)
+    want = faithful.trimmed_mean(g, n, c)
+    gd = eng.to_device(g)
+    got = eng.trimmed_mean(gd, n, c).numpy()
+    assert close(got, want)
+    monkeypatch.setenv('BYZ_TM_TALL', '0')
+    assert close(eng.trimmed_mean(gd, n, c).numpy(), want)
+    monkeypatch.delenv('BYZ_TM_TALL')
+    g2 = rng.standard_normal((n, cols)).astype(np.float32) * np.exp(rng.uniform(-3, 3, cols)).astype(np.float32)
+    order = rng.permutation(n)[:max(5633, n - 300)].astype(np.int32)
+    c2 = len(order) // 3
+    assert close(eng.trimmed_mean(eng.to_device(g2), n, c2, row_index=order).numpy(), faithful.trimmed_mean(g2[order], len(order), c2))
+    for trim in (0, n - 2):      # keep = n - 1 values (everything but the farthest) and keep = 1 (the value nearest the median)
+        assert close(eng.trimmed_mean(eng.to_device(g2), n, trim).numpy(), faithful.trimmed_mean(g2, n, trim))
+    g2[3, 1] = np.nan
+    g2[n - 1, 2] = -np.nan
+    g2[5, 4] = np.inf
+    g2[6, 4] = -np.inf
+    got = eng.trimmed_mean(eng.to_device(g2), n, c).numpy()
+    want = faithful.trimmed_mean(g2, n, c)
+    assert np.isnan(got[1]) and np.isnan(got[2]) and close(np.delete(got, [1, 2]), np.delete(want, [1, 2]))
+
+
+def test_tall_select_on_a_strided_matrix_and_constant_columns(eng):
+    """A leading dimension beyond the column count (a view into a wider matrix), columns that are one value (every |x - med| ties at 0),
+    two values, and a column whose window edge ties across the median with both signs in a row order that matters."""
+    torch = pytest.importorskip('torch')
+    n, cols, c = 6400, 77, 3000
+    rng = np.random.default_rng(77)
+    wide = rng.standard_normal((n, cols + 19)).astype(np.float32)
+    wide[:, 3] = 1.25
+    wide[:, 4] = np.where(rng.random(n) < 0.5, -2.0, 2.0).astype(np.float32)
+    wide[:, 5] = rng.integers(-3, 4, n).astype(np.float32)
+    view = torch.from_numpy(wide).cuda()[:, :cols]
+    assert view.stride(0) == cols + 19
+    got = eng.trimmed_mean(view, n, c).cpu().numpy()
+    assert close(got, faithful.trimmed_mean(wide[:, :cols], n, c))
