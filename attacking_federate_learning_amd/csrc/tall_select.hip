@@ -13,8 +13,8 @@
 //     contiguous bytes per row;
 //   * a pass counts the keys that match the digits found so far into hist[digit][column] (LDS, one bank per column: no
 //     conflicts whatever the data), then one thread per column walks its 256 counters to the digit that holds the rank;
-//   * 4 passes give the lower median, one more the next larger value (even counts), 4 the window's edge, the last one the sums:
-//     10 passes, 40 bytes per value -- bound by HBM like the sort never was.
+//   * 4 passes give the lower median (and, on the way, the next larger value for an even count and whether a NaN is there), 4 the
+//     window's edge, the last one the sums: 9 passes, 36 bytes per value -- bound by HBM like the sort never was.
 // Ties at the edge with both signs present (+t and -t: the only place where row order matters) are settled by one thread per
 // column walking the rows in order; a NaN anywhere in the column makes the result NaN, like np.median.
 #include "common.hpp"
@@ -30,7 +30,7 @@ constexpr int kUnroll = 8;
 // hist[256][64] (the waves' partial sums and counts live in it once the selects are done), then per column: the digits found so
 // far, the rank left, and the sixteen 16-digit segment sums of the walk to the rank's digit
 constexpr int kHistWords = 256 * kTileCols;
-constexpr int kLdsWords = kHistWords + kTileCols * (2 + kWaves);
+constexpr int kLdsWords = kHistWords + kTileCols * (2 + kWaves + 3);
 
 __device__ __forceinline__ uint32_t ordered_bits(float v) {
     const uint32_t b = __float_as_uint(v);
@@ -63,8 +63,15 @@ __device__ __forceinline__ uint32_t key_of(float x, float med) {
 // the same in the four threads of a column.  `left_out` / `equal_out`: the rank inside the run of equal keys, and its length.
 template <int STAGE>
 __device__ __forceinline__ uint32_t radix_select(const Column& c, float med, int rank, uint32_t* hist, uint32_t* found, int* left,
-                                                 uint32_t* seg, int tx, int ty, int& left_out, int& equal_out) {
+                                                 uint32_t* seg, uint32_t* extra, int tx, int ty, int& left_out, int& equal_out) {
     static_assert(kWaves == 16, "the walk to the rank's digit takes sixteen 16-digit segments, one per wave");
+    // STAGE 1 also leaves (for the median of an even count, and np.median's NaN) in extra[0..63] whether the column holds a NaN and in
+    // extra[128..191] the smallest key above the answer: the first pass sees every value; the last pass knows the answer's upper 24 bits,
+    // so a larger key either shares them (the next occupied digit of the last histogram) or lies beyond them (a running minimum)
+    if (STAGE == 1 && ty == 0) {
+        extra[tx] = 0u;
+        extra[kTileCols + tx] = 0xffffffffu;
+    }
     const int tid = ty * kTileCols + tx;
     if (ty == 0) {
         found[tx] = 0u;
@@ -74,6 +81,8 @@ __device__ __forceinline__ uint32_t radix_select(const Column& c, float med, int
         for (int i = tid; i < kHistWords; i += kTileCols * kWaves) hist[i] = 0u;
         __syncthreads();
         const uint32_t prefix = found[tx];
+        uint32_t beyond = 0xffffffffu;
+        int nan = 0;
         for (int r0 = ty; r0 < c.n_rows; r0 += kWaves * kUnroll) {
             float v[kUnroll];
 #pragma unroll
@@ -87,7 +96,15 @@ __device__ __forceinline__ uint32_t radix_select(const Column& c, float med, int
                 const uint32_t key = key_of<STAGE>(v[j], med);
                 const bool match = shift == 24 || (key >> (shift + 8)) == prefix;
                 if (r < c.n_rows && match) atomicAdd(&hist[((key >> shift) & 255u) * kTileCols + tx], 1u);
+                if constexpr (STAGE == 1) {      // (a clamped row repeats a real value: harmless for both)
+                    if (shift == 24) nan |= (__float_as_uint(v[j]) & 0x7fffffffu) > 0x7f800000u ? 1 : 0;
+                    if (shift == 0) beyond = (key >> 8) > prefix && key < beyond ? key : beyond;
+                }
             }
+        }
+        if constexpr (STAGE == 1) {
+            if (shift == 24 && nan != 0) atomicOr(&extra[tx], 1u);
+            if (shift == 0 && beyond != 0xffffffffu) atomicMin(&extra[kTileCols + tx], beyond);
         }
         __syncthreads();
         {   // the digit that holds the rank: sixteen segment sums per column first, then one thread walks 16 + 16 counters
@@ -120,7 +137,19 @@ __device__ __forceinline__ uint32_t radix_select(const Column& c, float med, int
             }
             found[tx] = (prefix << 8) | static_cast<uint32_t>(digit);
             left[tx] = want;
-            if (shift == 0) seg[tx] = count;      // (the run of keys equal to the answer)
+            if (shift == 0) {
+                seg[tx] = count;      // (the run of keys equal to the answer)
+                if constexpr (STAGE == 1) {
+                    uint32_t next = extra[kTileCols + tx];
+                    for (int b = digit + 1; b < 256; ++b) {
+                        if (hist[b * kTileCols + tx] != 0u) {
+                            next = (prefix << 8) | static_cast<uint32_t>(b);
+                            break;
+                        }
+                    }
+                    extra[2 * kTileCols + tx] = next;
+                }
+            }
         }
         __syncthreads();
     }
@@ -139,12 +168,11 @@ __global__ __launch_bounds__(kTileCols * kWaves) void tall_select_kernel(const f
     uint32_t* const found = lds + kHistWords;
     int* const left = reinterpret_cast<int*>(found + kTileCols);
     uint32_t* const seg = reinterpret_cast<uint32_t*>(left + kTileCols);               // [kWaves][64]
+    uint32_t* const extra = seg + kWaves * kTileCols;                                   // [3][64]: NaN seen, minimum beyond, next key
     double* const part_sum = reinterpret_cast<double*>(hist);                           // [kWaves][64], over the dead histogram
     int* const part_less = reinterpret_cast<int*>(part_sum + kWaves * kTileCols);       // [kWaves][64]
     int* const part_pos = part_less + kWaves * kTileCols;
     int* const part_neg = part_pos + kWaves * kTileCols;
-    uint32_t* const part_next = reinterpret_cast<uint32_t*>(part_neg + kWaves * kTileCols);   // [kWaves][64] smallest key above the lower median
-    int* const part_nan = reinterpret_cast<int*>(part_next + kWaves * kTileCols);       // [kWaves][64]
     const int tx = threadIdx.x & (kTileCols - 1), ty = threadIdx.x / kTileCols;
     const int64_t col = static_cast<int64_t>(blockIdx.x) * kTileCols + tx;
     const bool real = col < n_cols;
@@ -153,37 +181,11 @@ __global__ __launch_bounds__(kTileCols * kWaves) void tall_select_kernel(const f
     // ---- the median: rank (n - 1) / 2, and for an even count the next value above it
     const int mid = (n_rows - 1) >> 1;
     int run_left, run_len;
-    const uint32_t lower_key = radix_select<1>(c, 0.0f, mid, hist, found, left, seg, tx, ty, run_left, run_len);
+    const uint32_t lower_key = radix_select<1>(c, 0.0f, mid, hist, found, left, seg, extra, tx, ty, run_left, run_len);
     float med = from_ordered_bits(lower_key);
     {
-        // one more pass: a NaN anywhere (np.median is NaN then), and the smallest key above the lower median
-        uint32_t next = 0xffffffffu;
-        int nan = 0;
-        for (int r0 = ty; r0 < n_rows; r0 += kWaves * kUnroll) {
-            float v[kUnroll];
-#pragma unroll
-            for (int j = 0; j < kUnroll; ++j) {
-                const int r = r0 + j * kWaves;
-                v[j] = c.at(r < n_rows ? r : n_rows - 1);
-            }
-#pragma unroll
-            for (int j = 0; j < kUnroll; ++j) {
-                const uint32_t key = ordered_bits(v[j]);      // (a clamped row repeats a real value: harmless for both)
-                nan |= (__float_as_uint(v[j]) & 0x7fffffffu) > 0x7f800000u ? 1 : 0;
-                next = key > lower_key && key < next ? key : next;
-            }
-        }
-        part_next[ty * kTileCols + tx] = next;
-        part_nan[ty * kTileCols + tx] = nan;
-        __syncthreads();
-        uint32_t above = 0xffffffffu;
-        int any_nan = 0;
-        for (int w = 0; w < kWaves; ++w) {
-            const uint32_t o = part_next[w * kTileCols + tx];
-            above = o < above ? o : above;
-            any_nan |= part_nan[w * kTileCols + tx];
-        }
-        __syncthreads();
+        const uint32_t above = extra[2 * kTileCols + tx];      // the smallest key above the lower median
+        const int any_nan = static_cast<int>(extra[tx]);        // a NaN anywhere: np.median is NaN then
         if (any_nan) {
             if (ty == 0 && real) out[col] = __uint_as_float(0x7fc00000u);
             // (the column goes on through the passes with the others of its tile -- the barriers are the workgroup's -- and its
@@ -200,7 +202,7 @@ __global__ __launch_bounds__(kTileCols * kWaves) void tall_select_kernel(const f
         }
         // ---- the window's edge: the keep-th smallest |fl(x - med)|
         int edge_left, edge_len;
-        const uint32_t t_bits = radix_select<2>(c, med, keep - 1, hist, found, left, seg, tx, ty, edge_left, edge_len);
+        const uint32_t t_bits = radix_select<2>(c, med, keep - 1, hist, found, left, seg, extra, tx, ty, edge_left, edge_len);
         // ---- the sums: everything closer than the edge, and the tied values at it by sign
         double sum = 0.0;      // (np.mean sums pairwise: close to exact; a lane's share of a 2^20-row column is 262,144 values)
         int n_less = 0, n_pos = 0, n_neg = 0;
